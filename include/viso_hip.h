@@ -1,0 +1,218 @@
+/*
+ * viso_hip.h — C-ABI of libviso_hip.so, the MI355X (gfx950) implementation of
+ * libviso's per-frame hot path: descriptor-window SAD matcher, circular-match
+ * join, rectified triangulation and the RANSAC + Gauss-Newton stereo
+ * reprojection pose solver.
+ *
+ * Every entry point replaces one free function of the reference
+ * (alexkreimer/libviso, paths relative to its root); the reference has no FFI
+ * of its own (plain C++ free functions over cv::Mat / std::vector), so this
+ * header is what a cgo/ctypes/C++ adapter binds instead.  INTEGRATION.md shows
+ * the reference-side adapter.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices are row-major and contiguous;
+ *   - "4xM" / "3xM" double matrices are SoA exactly like the reference's
+ *     cv::Mat(4,M,CV_64F): row r starts at p + r*M;
+ *   - return value: 1 = true, 0 = false (the reference's bool), negative =
+ *     VISO_ERR_* (the reference would assert/abort; we never abort across the ABI);
+ *   - the *_dev / batch family takes DEVICE pointers and a context (persistent
+ *     device buffers + one HIP stream); the plain family takes HOST pointers and
+ *     runs on a lazily created default context.
+ *   - nothing here computes on the CPU: if the HIP device is missing the calls
+ *     fail with VISO_ERR_HIP.
+ */
+#ifndef VISO_HIP_H_
+#define VISO_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VISO_OK 1
+#define VISO_FALSE 0
+#define VISO_ERR_ARG (-1)         /* bad argument (the reference asserts: src/viso.cpp:676,174-175) */
+#define VISO_ERR_HIP (-2)         /* HIP runtime error / no device */
+#define VISO_ERR_UNSUPPORTED (-3) /* size beyond what this build handles */
+#define VISO_ERR_NOMEM (-4)
+
+#define VISO_DESC_LEN 121 /* (2*5+1)^2, src/viso.cpp:1001,1174 */
+
+/* Mirrors `struct MatchParams` (src/viso.cpp:48-75).  `alg_thresh` and
+ * `allow_ann` are never read by match_desc and are omitted. */
+typedef struct viso_match_params {
+    int32_t enforce_epipolar;   /* src/viso.cpp:50 */
+    int32_t enforce_2nd_best;   /* :55 */
+    int32_t max_neighbors;      /* :59  K, columns of the neighbour matrix */
+    int32_t _pad;
+    double F[9];                /* :51  row-major fundamental matrix, x2' F x1 = 0 */
+    double sampson_thresh;      /* :53 */
+    double ratio_2nd_best;      /* :56 */
+    double radius;              /* :60  L1 pixel radius (cast to float at :685) */
+} viso_match_params;
+
+/* Mirrors `struct param` (src/viso.h:58-72). */
+typedef struct viso_param {
+    double base;                /* :61 */
+    int32_t ransac_iter;        /* :62 default 50 */
+    int32_t save_debug;         /* :65 unused by the hot path, kept for layout parity */
+    double inlier_threshold;    /* :63 default 2 */
+    double thresh;              /* :64 default 1e-4 */
+    double f, cu, cv;           /* :66-71 calib.{f,cu,cv} */
+} viso_param;
+
+/* MatchParams(F) ctor, src/viso.cpp:62-71: stereo L->R (epipolar on, K=200, r=80). */
+void viso_match_params_stereo(viso_match_params* mp, const double F[9]);
+/* MatchParams() ctor, src/viso.cpp:72-74: temporal (2nd-best 0.9, K=250, r=80). */
+void viso_match_params_temporal(viso_match_params* mp);
+/* param() ctor, src/viso.h:60. base/f/cu/cv are left 0. */
+void viso_param_default(viso_param* p);
+
+/* ---------------------------------------------------------------- context */
+typedef struct viso_ctx viso_ctx;
+
+/* device: HIP device ordinal.  stream: a hipStream_t to run on, or NULL to let
+ * the context create its own.  Returns NULL on failure (viso_last_error()). */
+viso_ctx* viso_ctx_create(int device, void* stream);
+void viso_ctx_destroy(viso_ctx* ctx);
+/* hipStream_t the context launches on. */
+void* viso_ctx_stream(viso_ctx* ctx);
+int viso_ctx_synchronize(viso_ctx* ctx);
+const char* viso_last_error(void);
+/* "libviso_hip <version> gfx950 ..." */
+const char* viso_version(void);
+
+/* ------------------------------------------------------ plain (host) family */
+
+/* match_desc, src/viso.cpp:669-726 (+ radiusSearch :170-203, sampsonDistance
+ * :655-666, kp2mat :246-256).  kp*: n x 2 float (x,y).  d*: n x dlen float.
+ * out_match: up to n1 rows (i1,i2,(int)dist), sorted by (dist asc, i1 asc) —
+ * the reference's std::sort is unstable (:724); this is the documented
+ * tightening.  *out_n = number of matches. */
+int viso_match_desc(const float* kp1, int n1, const float* kp2, int n2,
+                    const float* d1, const float* d2, int dlen,
+                    const viso_match_params* mp,
+                    int32_t* out_match, int* out_n);
+
+/* match_circle, src/viso.cpp:207-243.  Lists are n x 3 int32 (i1,i2,dist).
+ * circ: up to cap x 4, pcl: up to cap x 2 (positions into lr / lr_prev).
+ * Exact for arbitrary lists (duplicate keys included): output order is the
+ * reference's nested-loop order.  Returns VISO_ERR_ARG if more than cap rows
+ * would be produced (*out_n then holds the required count). */
+int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_prev, int n_lrp,
+                      const int32_t* m11, int n11, const int32_t* m22, int n22,
+                      int32_t* circ, int32_t* pcl, int cap, int* out_n);
+
+/* collect_matches(...,Mat& x) src/viso.cpp:501-514: x = 4 x n double
+ * (uL,vL,uR,vR). */
+int viso_collect_matches(const float* kp1, int n1, const float* kp2, int n2,
+                         const int32_t* match, int n, double* x4xn);
+
+/* triangulate_rectified<double>, src/viso.cpp:1137-1162. */
+int viso_triangulate_rectified(const double* x4xM, int m, const viso_param* p,
+                               double* X3xM);
+
+/* minimize_reproj, src/viso.cpp:1583-1623.  tr is in/out.  1 = converged,
+ * 0 = singular system or 100 iterations exhausted. */
+int viso_minimize_reproj(const double* X3xM, const double* obs4xM, int m,
+                         double tr[6], const viso_param* p,
+                         const int32_t* active, int n_active);
+
+/* get_inliers, src/viso.cpp:1509-1537.  inliers: up to m ascending indices.
+ * rms (may be NULL) reproduces the reference's last-point value (:1535). */
+int viso_get_inliers(const double* X3xM, const double* obs4xM, int m,
+                     const double tr[6], const viso_param* p,
+                     int32_t* inliers, int* n_inliers, double* rms);
+
+/* ransac_minimize_reproj, src/viso.cpp:1543-1580.  samples: ransac_iter x 3
+ * ascending distinct indices (what randomsample(3,m,.) :87-107 yields), or
+ * NULL to draw them from viso_ransac_samples(seed, frame, ...).  best_tr is
+ * in/out like the reference's.  best_inl: up to m indices. */
+int viso_ransac_minimize_reproj(const double* X3xM, const double* obs4xM, int m,
+                                double best_tr[6], int32_t* best_inl, int* n_inl,
+                                const viso_param* p, const int32_t* samples,
+                                uint64_t seed, uint64_t frame);
+
+/* Deterministic replacement for randomsample's per-call random_device
+ * (src/viso.cpp:87-107): selection sampling (same algorithm) driven by a
+ * splitmix64 stream keyed on (seed, frame, hypothesis).  out: iters x 3. */
+void viso_ransac_samples(uint64_t seed, uint64_t frame, int iters, int m, int32_t* out);
+
+/* tr2mat, src/viso.cpp:109-133. T: 4x4 row-major. Host arithmetic (six
+ * sin/cos; nothing to offload). */
+void viso_tr2mat(const double tr[6], double T[16]);
+/* pose <- pose * inv(tr2mat(tr)), src/viso.cpp:1315-1321. */
+void viso_pose_update(const double pose[16], const double tr[6], double out[16]);
+/* F_from_P<double>, src/mvg.h:41-66, followed by the normalisation of
+ * src/viso.cpp:1177-1180.  P1,P2: 3x4 row-major. */
+void viso_F_from_P(const double P1[12], const double P2[12], double F[9]);
+
+/* MyFeatureExtractor::computeImpl, src/viso.cpp:1004-1024: Sobel-x 3x3
+ * (BORDER_REFLECT_101) then (2r+1)^2 window per keypoint; zero where
+ * y<=0|y>=rows|x<=0|x>=cols.  img: rows x cols uint8.  desc: n x (2r+1)^2. */
+int viso_extract_descriptors(const uint8_t* img, int rows, int cols,
+                             const float* kp, int n, int radius, float* desc);
+
+/* ------------------------------------------- batched, device-resident family
+ *
+ * A frame set holds `n_frames` stereo frames resident in HBM:
+ *   kp   [n_frames][2][cap][2]   float   (x,y)   image 0 = left, 1 = right
+ *   desc [n_frames][2][cap][121] float            (the reference's boundary layout)
+ *   n    [n_frames][2]           int32   keypoints actually present (<= cap)
+ * viso_batch_* processes the pairs (t-1,t) for t = 1..n_frames-1 exactly like
+ * one iteration each of sequence_odometry's loop body (src/viso.cpp:1205-1327):
+ * stereo match of every frame, two temporal matches, circle join, gather,
+ * RANSAC/GN.  All stages run on the context's stream without host round trips.
+ */
+typedef struct viso_batch viso_batch;
+
+viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, int dlen);
+void viso_batch_destroy(viso_batch* b);
+
+/* Upload host data for frames [f0, f0+nf) (layout as above, tightly packed
+ * over nf frames).  Synchronous copy. */
+int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
+                      const float* desc, const int32_t* n);
+/* Device pointers of the boundary-layout buffers, for producers that already
+ * live on the GPU (a device-side extractor, torch): kp, desc, n as above. */
+int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, void** n);
+
+int viso_batch_set_params(viso_batch* b, const viso_match_params* stereo,
+                          const viso_match_params* temporal, const viso_param* p,
+                          uint64_t seed, uint64_t first_frame_index);
+
+/* Matcher stage only (BASELINE config 2): pack + 3 match_desc per frame
+ * (stereo for all frames, temporal L and R for t>=1) incl. the final sort. */
+int viso_batch_run_matcher(viso_batch* b);
+/* Full per-frame path (BASELINE config 3): matcher + triangulation + circle
+ * join + RANSAC/GN.  Asynchronous on the context's stream. */
+int viso_batch_run(viso_batch* b);
+
+/* Results (host copies; they synchronise the stream).
+ * which: 0 = stereo L->R of frame t, 1 = temporal left (t vs t-1), 2 = temporal right. */
+int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* out_match, int* out_n);
+int viso_batch_get_circle(viso_batch* b, int t, int32_t* circ, int32_t* pcl, int* out_n);
+/* tr[6], ok (1/0, 0 also when <3 circle matches, src/viso.cpp:1283), inliers. */
+int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok,
+                        int32_t* inliers, int* n_inl);
+/* All frames at once: tr [n_frames][6], ok [n_frames], n_inl [n_frames]
+ * (entry 0 is zero/0: the first frame has no predecessor, :1256-1260). */
+int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl);
+/* Work counters of the last run, for the algorithmic-bytes model of
+ * per (which,t) the number of scored (query,candidate) pairs C
+ * and matches emitted M_out.  scored/m_out: [3][n_frames] int64. */
+int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out);
+/* Name of the kernel that dominates a matcher run (for rocprof summaries) and
+ * its average duration in ms over the launches since the last reset, measured
+ * with hipEvents on the context's stream. */
+const char* viso_matcher_kernel_name(void);
+int viso_batch_kernel_timing(viso_batch* b, int enable);
+int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISO_HIP_H_ */

@@ -1,0 +1,5 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY (see oracle/viso_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.
+"""
