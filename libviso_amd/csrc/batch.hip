@@ -1,0 +1,331 @@
+// batch.hip — device-resident frame batches: the loop body of
+// sequence_odometry (reference src/viso.cpp:1205-1327) for many frames per
+// launch, every stage on one HIP stream with no host round trip in between.
+//
+// HBM layout (all allocations made once, at viso_batch_create):
+//   kp      [nf][2][cap] float2          boundary layout (x,y)
+//   desc    [nf][2][cap][dlen] float     boundary layout (reference Mat N x 121 CV_32F)
+//   packed  [nf][2][cap][128] u16        biased rows the matcher reads (256 B, 16-B aligned)
+//   res     [3][nf][cap] int2            per query (target | -1, SAD)
+//   sorted  [3][nf][cap][3] int          match lists in (dist,i1) order; pos = inverse
+//   x [nf][4][cap], X [nf][3][cap], x_c, Xp_c   double, SoA rows like cv::Mat(4,M)
+// `which` = 0 stereo L->R of frame t, 1 temporal left (t vs t-1), 2 temporal right.
+#include "common.h"
+
+#include <string.h>
+#include <vector>
+
+int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
+                       int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad,
+                       hipEvent_t e0, hipEvent_t e1);
+
+struct viso_batch {
+    viso_ctx* ctx;
+    int nf, cap, dlen, iters;
+    int n_probs;               // padded problem count (multiple of 24)
+    float2* kp; float* desc; int* n; uint16_t* packed; int* bad; int* zero;
+    MatchProblem* probs;
+    int2* res; int* sorted; int* pos; int* m_cnt; unsigned long long* scored;
+    double *x, *X, *x_c, *Xp_c;
+    TriItem* tri; JoinItem* join; SolverItem* sitems;
+    int *circ, *pcl, *mc;
+    double* tr_h; int *ok_h, *cnt_h;
+    double* tr; int *ok, *n_inl, *inl;
+    MatchParamsDev mp[2];
+    SolverParamsDev sp;
+    unsigned long long seed, first_frame;
+    bool params_set;
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+static inline int prob_slot(int which, int t) { return (t / 8) * 24 + which * 8 + (t % 8); }
+
+template <class T>
+static int dalloc(T** p, size_t count) {
+    *p = nullptr;
+    HIP_TRY(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    return VISO_OK;
+}
+
+static void free_solver_bufs(viso_batch* b) {
+    if (b->tr_h) hipFree(b->tr_h);
+    if (b->ok_h) hipFree(b->ok_h);
+    if (b->cnt_h) hipFree(b->cnt_h);
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
+}
+
+extern "C" void viso_batch_destroy(viso_batch* b) {
+    if (!b) return;
+    hipStreamSynchronize(b->ctx->stream);
+    for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    void* ptrs[] = {b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
+                    b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
+    for (void* p : ptrs) if (p) hipFree(p);
+    free_solver_bufs(b);
+    delete b;
+}
+
+static int build_items(viso_batch* b) {
+    const int nf = b->nf, cap = b->cap;
+    const size_t kpi = (size_t)cap, dsi = (size_t)cap * VISO_ROW, dfi = (size_t)cap * b->dlen;
+    std::vector<MatchProblem> P((size_t)b->n_probs);
+    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.n1p = b->zero; p.n2p = b->zero; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
+    auto img_kp = [&](int t, int side) { return b->kp + ((size_t)t * 2 + side) * kpi; };
+    auto img_u16 = [&](int t, int side) { return b->packed + ((size_t)t * 2 + side) * dsi; };
+    auto img_f32 = [&](int t, int side) { return b->desc + ((size_t)t * 2 + side) * dfi; };
+    auto img_n = [&](int t, int side) { return b->n + t * 2 + side; };
+    for (int t = 0; t < nf; ++t) {
+        for (int which = 0; which < 3; ++which) {
+            if (which > 0 && t == 0) continue;   // first frame has no predecessor (:1256-1260)
+            MatchProblem& p = P[(size_t)prob_slot(which, t)];
+            int qs, qt, ts, tt;                  // query side/frame, target side/frame
+            if (which == 0) { qs = 0; qt = t; ts = 1; tt = t; }          // match_desc(kp1,kp2,...) :1240
+            else if (which == 1) { qs = 0; qt = t; ts = 0; tt = t - 1; } // (kp1,kp1_prev) :1264
+            else { qs = 1; qt = t; ts = 1; tt = t - 1; }                 // (kp2,kp2_prev) :1275
+            p.kp1 = img_kp(qt, qs); p.kp2 = img_kp(tt, ts);
+            p.d1 = img_u16(qt, qs); p.d2 = img_u16(tt, ts);
+            p.f1 = img_f32(qt, qs); p.f2 = img_f32(tt, ts);
+            p.n1p = img_n(qt, qs); p.n2p = img_n(tt, ts);
+            const size_t o = (size_t)which * nf + t;
+            p.res = b->res + o * cap; p.sorted = b->sorted + o * cap * 3; p.pos = b->pos + o * cap;
+            p.m_cnt = b->m_cnt + o; p.scored = b->scored + o;
+            p.pidx = which == 0 ? 0 : 1; p.cap = cap;
+        }
+    }
+    HIP_TRY(hipMemcpy(b->probs, P.data(), sizeof(MatchProblem) * P.size(), hipMemcpyHostToDevice));
+    std::vector<TriItem> T((size_t)nf);
+    for (int t = 0; t < nf; ++t) {
+        TriItem& it = T[(size_t)t];
+        it.kp1 = img_kp(t, 0); it.kp2 = img_kp(t, 1);
+        it.match = b->sorted + ((size_t)0 * nf + t) * cap * 3; it.m_cnt = b->m_cnt + t;
+        it.x = b->x + (size_t)t * 4 * cap; it.X = b->X + (size_t)t * 3 * cap; it.ld = cap;
+    }
+    HIP_TRY(hipMemcpy(b->tri, T.data(), sizeof(TriItem) * T.size(), hipMemcpyHostToDevice));
+    if (nf > 1) {
+        std::vector<JoinItem> J((size_t)nf - 1);
+        for (int t = 1; t < nf; ++t) {
+            JoinItem& j = J[(size_t)t - 1];
+            j.lr = b->sorted + ((size_t)0 * nf + t) * cap * 3; j.lr_cnt = b->m_cnt + t;
+            j.res11 = b->res + ((size_t)1 * nf + t) * cap;
+            j.res22 = b->res + ((size_t)2 * nf + t) * cap;
+            j.pos_lrp = b->pos + ((size_t)0 * nf + (t - 1)) * cap;
+            j.res_lrp = b->res + ((size_t)0 * nf + (t - 1)) * cap;
+            j.x = b->x + (size_t)t * 4 * cap; j.ldx = cap;
+            j.Xp = b->X + (size_t)(t - 1) * 3 * cap; j.ldXp = cap;
+            j.circ = b->circ + (size_t)t * cap * 4; j.pcl = b->pcl + (size_t)t * cap * 2; j.mc = b->mc + t;
+            j.x_c = b->x_c + (size_t)t * 4 * cap; j.Xp_c = b->Xp_c + (size_t)t * 3 * cap; j.ldc = cap;
+        }
+        HIP_TRY(hipMemcpy(b->join, J.data(), sizeof(JoinItem) * J.size(), hipMemcpyHostToDevice));
+    }
+    return VISO_OK;
+}
+
+static int build_solver_items(viso_batch* b) {
+    const int nf = b->nf, cap = b->cap, iters = b->iters;
+    if (nf <= 1) return VISO_OK;
+    std::vector<SolverItem> S((size_t)nf - 1);
+    for (int t = 1; t < nf; ++t) {
+        SolverItem& s = S[(size_t)t - 1];
+        memset(&s, 0, sizeof(s));
+        s.X = b->Xp_c + (size_t)t * 3 * cap; s.obs = b->x_c + (size_t)t * 4 * cap;
+        s.m_ptr = b->mc + t; s.ld = cap; s.samples = nullptr;
+        s.frame = b->first_frame + (unsigned long long)t;
+        s.tr_h = b->tr_h + (size_t)t * iters * 6; s.ok_h = b->ok_h + (size_t)t * iters; s.cnt_h = b->cnt_h + (size_t)t * iters;
+        s.tr = b->tr + (size_t)t * 6; s.ok = b->ok + t; s.n_inl = b->n_inl + t; s.inl = b->inl + (size_t)t * cap;
+    }
+    HIP_TRY(hipMemcpy(b->sitems, S.data(), sizeof(SolverItem) * S.size(), hipMemcpyHostToDevice));
+    return VISO_OK;
+}
+
+extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, int dlen) {
+    if (!ctx || n_frames <= 0 || cap <= 0 || dlen <= 0) { viso_set_error("viso_batch_create: bad argument"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { viso_set_error("hipSetDevice failed"); return nullptr; }
+    viso_batch* b = new viso_batch();
+    b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
+    b->n_probs = ((n_frames + 7) / 8) * 24;
+    b->params_set = false; b->timing = false;
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
+    const size_t nf = (size_t)n_frames, c = (size_t)cap;
+    int r = VISO_OK;
+    auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
+    A(dalloc(&b->kp, nf * 2 * c)); A(dalloc(&b->desc, nf * 2 * c * dlen)); A(dalloc(&b->n, nf * 2));
+    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->bad, 4)); A(dalloc(&b->zero, 8));
+    A(dalloc(&b->probs, (size_t)b->n_probs));
+    A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
+    A(dalloc(&b->m_cnt, 3 * nf)); A(dalloc(&b->scored, 3 * nf));
+    A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
+    A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
+    A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
+    A(dalloc(&b->tr, nf * 6)); A(dalloc(&b->ok, nf)); A(dalloc(&b->n_inl, nf)); A(dalloc(&b->inl, nf * c));
+    if (r < 0) { viso_batch_destroy(b); return nullptr; }
+    bool ok = hipMemset(b->zero, 0, 8 * sizeof(int)) == hipSuccess &&
+              hipMemset(b->n, 0, nf * 2 * sizeof(int)) == hipSuccess &&
+              hipMemset(b->m_cnt, 0, 3 * nf * sizeof(int)) == hipSuccess &&
+              hipMemset(b->mc, 0, nf * sizeof(int)) == hipSuccess &&
+              hipMemset(b->tr, 0, nf * 6 * sizeof(double)) == hipSuccess &&
+              hipMemset(b->ok, 0, nf * sizeof(int)) == hipSuccess &&
+              hipMemset(b->n_inl, 0, nf * sizeof(int)) == hipSuccess &&
+              hipMemset(b->scored, 0, 3 * nf * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_destroy(b); return nullptr; }
+    return b;
+}
+
+extern "C" int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp, const float* desc,
+                                 const int32_t* n) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload: bad argument"); return VISO_ERR_ARG; }
+    for (int i = 0; i < 2 * nf; ++i)
+        if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
+    if (nf == 0) return VISO_OK;
+    const size_t c = (size_t)b->cap;
+    HIP_TRY(hipMemcpy(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice));
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, void** n) {
+    if (!b) return VISO_ERR_ARG;
+    if (kp) *kp = b->kp;
+    if (desc) *desc = b->desc;
+    if (n) *n = b->n;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* stereo,
+                                     const viso_match_params* temporal, const viso_param* p,
+                                     uint64_t seed, uint64_t first_frame_index) {
+    if (!b || !stereo || !temporal || !p || p->ransac_iter < 0 || stereo->max_neighbors <= 0 || temporal->max_neighbors <= 0) {
+        viso_set_error("viso_batch_set_params: bad argument");
+        return VISO_ERR_ARG;
+    }
+    fill_match_params(&b->mp[0], stereo);
+    fill_match_params(&b->mp[1], temporal);
+    fill_solver_params(&b->sp, p);
+    b->seed = seed; b->first_frame = first_frame_index;
+    if (p->ransac_iter != b->iters || !b->tr_h) {
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        free_solver_bufs(b);
+        b->iters = p->ransac_iter;
+        const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
+        int r;
+        if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0) return r;
+    }
+    int r = build_solver_items(b);
+    if (r < 0) return r;
+    b->params_set = true;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_kernel_timing(viso_batch* b, int enable) {
+    if (!b) return VISO_ERR_ARG;
+    b->timing = enable != 0;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_run_matcher(viso_batch* b) {
+    if (!b || !b->params_set) { viso_set_error("viso_batch_run_matcher: parameters not set"); return VISO_ERR_ARG; }
+    hipStream_t s = b->ctx->stream;
+    HIP_TRY(hipMemsetAsync(b->bad, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(b->scored, 0, sizeof(unsigned long long) * 3 * (size_t)b->nf, s));
+    int r;
+    if ((r = launch_pack(s, b->desc, b->packed, b->n, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        b->events.push_back({e0, e1});
+    }
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->cap, b->dlen, b->mp, b->bad, e0, e1)) < 0) return r;
+    if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_run(viso_batch* b) {
+    int r = viso_batch_run_matcher(b);
+    if (r < 0) return r;
+    hipStream_t s = b->ctx->stream;
+    HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, s));            // vector<double> tr(6,0), :1312
+    if ((r = launch_collect_triangulate(s, b->tri, b->nf, b->sp, b->cap)) < 0) return r;   // :1245-1247
+    if (b->nf > 1) {
+        if ((r = launch_circle_join(s, b->join, b->nf - 1)) < 0) return r;                // :1282, 1292-1305
+        if ((r = launch_ransac(s, b->sitems, b->nf - 1, b->iters, b->seed, b->sp)) < 0) return r;   // :1313
+    }
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches) {
+    if (!b) return VISO_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    double tot = 0;
+    int n = 0;
+    for (auto& e : b->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    b->events.clear();
+    if (matcher_ms_avg) *matcher_ms_avg = n ? tot / n : 0.0;
+    if (n_launches) *n_launches = n;
+    return VISO_OK;
+}
+
+static bool slot_ok(viso_batch* b, int which, int t) { return b && which >= 0 && which < 3 && t >= 0 && t < b->nf; }
+
+extern "C" int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* out_match, int* out_n) {
+    if (!slot_ok(b, which, t) || !out_n) { viso_set_error("viso_batch_get_matches: bad argument"); return VISO_ERR_ARG; }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const size_t o = (size_t)which * b->nf + t;
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, b->m_cnt + o, sizeof(int), hipMemcpyDeviceToHost));
+    if (m > 0 && out_match) HIP_TRY(hipMemcpy(out_match, b->sorted + o * b->cap * 3, sizeof(int) * 3 * (size_t)m, hipMemcpyDeviceToHost));
+    *out_n = m;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_get_circle(viso_batch* b, int t, int32_t* circ, int32_t* pcl, int* out_n) {
+    if (!slot_ok(b, 0, t) || !out_n) { viso_set_error("viso_batch_get_circle: bad argument"); return VISO_ERR_ARG; }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, b->mc + t, sizeof(int), hipMemcpyDeviceToHost));
+    if (m > 0 && circ) HIP_TRY(hipMemcpy(circ, b->circ + (size_t)t * b->cap * 4, sizeof(int) * 4 * (size_t)m, hipMemcpyDeviceToHost));
+    if (m > 0 && pcl) HIP_TRY(hipMemcpy(pcl, b->pcl + (size_t)t * b->cap * 2, sizeof(int) * 2 * (size_t)m, hipMemcpyDeviceToHost));
+    *out_n = m;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, int32_t* inliers, int* n_inl) {
+    if (!slot_ok(b, 0, t)) { viso_set_error("viso_batch_get_pose: bad argument"); return VISO_ERR_ARG; }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    int o = 0, n = 0;
+    if (tr) HIP_TRY(hipMemcpy(tr, b->tr + (size_t)t * 6, sizeof(double) * 6, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&o, b->ok + t, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, b->n_inl + t, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > 0 && inliers) HIP_TRY(hipMemcpy(inliers, b->inl + (size_t)t * b->cap, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (ok) *ok = o;
+    if (n_inl) *n_inl = n;
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl) {
+    if (!b) return VISO_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (tr) HIP_TRY(hipMemcpy(tr, b->tr, sizeof(double) * 6 * (size_t)b->nf, hipMemcpyDeviceToHost));
+    if (ok) HIP_TRY(hipMemcpy(ok, b->ok, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
+    if (n_inl) HIP_TRY(hipMemcpy(n_inl, b->n_inl, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out) {
+    if (!b) return VISO_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const size_t k = 3 * (size_t)b->nf;
+    if (scored) HIP_TRY(hipMemcpy(scored, b->scored, sizeof(int64_t) * k, hipMemcpyDeviceToHost));
+    if (m_out) {
+        std::vector<int> m(k);
+        HIP_TRY(hipMemcpy(m.data(), b->m_cnt, sizeof(int) * k, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; ++i) m_out[i] = m[i];
+    }
+    return VISO_OK;
+}

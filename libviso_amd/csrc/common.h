@@ -1,0 +1,124 @@
+// common.h — shared declarations of libviso_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/viso_hip.h"
+
+#define VISO_ROW 128          // packed descriptor row: 128 x u16 = 256 B (121 used, rest = bias)
+#define VISO_BIAS 32768       // u16 = int16 value + 32768 (SAD is translation invariant)
+#define VISO_WAVE 64
+#define VISO_QCAP 256         // per-wave candidate queue entries
+#define VISO_QPB 32           // queries per workgroup in the matcher
+#define VISO_MATCH_THREADS 256
+#define VISO_KP_LDS_MAX 12288 // target keypoints staged in LDS (96 KiB) at most
+
+void viso_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            viso_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,           \
+                           hipGetErrorString(_e));                                 \
+            return VISO_ERR_HIP;                                                   \
+        }                                                                          \
+    } while (0)
+
+// ---- device-side views -----------------------------------------------------
+struct MatchParamsDev {          // viso_match_params, device copy (kernarg)
+    int epi, second, K, _pad;
+    float radius, _padf;
+    double F[9];
+    double sampson_thresh, ratio;
+};
+
+struct MatchProblem {            // one match_desc call (reference src/viso.cpp:669)
+    const float2* kp1;           // queries  n1 x (x,y)
+    const float2* kp2;           // targets  n2 x (x,y)
+    const uint16_t* d1;          // packed rows (fast path)
+    const uint16_t* d2;
+    const float* f1;             // boundary-layout rows (general path)
+    const float* f2;
+    const int* n1p;              // counts live in device memory (ragged batches)
+    const int* n2p;
+    int2* res;                   // per query: (accepted target or -1, (int)best SAD)
+    int* sorted;                 // out: M x 3 (i1,i2,dist) sorted by (dist,i1)
+    int* pos;                    // out: per query, row in `sorted` or -1
+    int* m_cnt;                  // out: M
+    unsigned long long* scored;  // out: number of SAD evaluations (C of SURVEY 8(d))
+    int pidx;                    // 0 = stereo params, 1 = temporal params
+    int cap;                     // row capacity of res/sorted/pos
+};
+
+struct SolverParamsDev {         // viso_param, device copy
+    double base, f, cu, cv, inlier_threshold, thresh;
+    int ransac_iter, _pad;
+};
+
+struct viso_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    // grow-only scratch for the plain (host-pointer) family
+    void* scratch[16];
+    size_t scratch_bytes[16];
+};
+
+struct PlainLock { PlainLock(); ~PlainLock(); };   // serialises the plain family on the default context
+int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
+viso_ctx* viso_default_ctx();
+
+// ---- launchers (host) -------------------------------------------------------
+// pack boundary-layout float descriptors into biased u16 rows; sets *bad to 1
+// when a value is not an integer in [-32768, 32767] or dlen > 128.
+int launch_pack(hipStream_t s, const float* src, uint16_t* dst, const int* n_rows_per_img,
+                int n_img, int cap, int dlen, int* bad);
+int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
+                 int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad);
+int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
+void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
+void fill_solver_params(SolverParamsDev* d, const viso_param* h);
+
+
+// ---- solver / circle / triangulation items (device-resident descriptors) ---
+struct SolverItem {            // one ransac_minimize_reproj problem (one frame)
+    const double* X;           // 3 x ld  previous-frame 3-D points
+    const double* obs;         // 4 x ld  observations (uL,vL,uR,vR)
+    const int* m_ptr;          // number of points (device)
+    int ld;
+    int _pad;
+    const int* samples;        // iters x 3, or NULL -> splitmix64 stream
+    unsigned long long frame;  // stream key
+    double* tr_h;              // iters x 6   hypothesis transforms
+    int* ok_h;                 // iters
+    int* cnt_h;                // iters
+    double* tr;                // 6  in/out (best_tr)
+    int* ok;                   // 1
+    int* n_inl;                // 1
+    int* inl;                  // up to m
+};
+
+struct JoinItem {
+    const int* lr; const int* lr_cnt;        // sorted stereo matches of frame t
+    const int2* res11;                       // temporal-left results, per query
+    const int2* res22;                       // temporal-right results, per query
+    const int* pos_lrp; const int2* res_lrp; // previous frame's stereo: row of query / result
+    const double* x; int ldx;                // 4 x ldx   current frame (uL,vL,uR,vR)
+    const double* Xp; int ldXp;              // 3 x ldXp  previous frame 3-D points
+    int* circ; int* pcl; int* mc;            // outputs
+    double* x_c; double* Xp_c; int ldc;      // 4 x ldc, 3 x ldc
+};
+
+struct TriItem {
+    const float2* kp1; const float2* kp2;
+    const int* match; const int* m_cnt;   // n x 3 (i1,i2,dist)
+    double* x; double* X; int ld;         // 4 x ld, 3 x ld (X may be NULL)
+};
+
+int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
+                  unsigned long long seed, const SolverParamsDev& sp);
+int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
+int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
+                               const SolverParamsDev& sp, int cap);

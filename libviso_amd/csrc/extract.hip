@@ -1,0 +1,72 @@
+// extract.hip — descriptor extraction on device: MyFeatureExtractor::computeImpl
+// (reference src/viso.cpp:1004-1024).  cv::Sobel(image, CV_32F, dx=1, dy=0,
+// ksize=3, BORDER_REFLECT_101) sampled on a (2r+1)^2 window around each
+// keypoint; no Sobel image is materialised — every descriptor element
+// recomputes its 3x3 stencil from the uint8 image (L2-resident, 467 KB at
+// 1241x376).
+#include "common.h"
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void extract_desc_kernel(const uint8_t* __restrict__ img, int rows,
+                                                           int cols, const float2* __restrict__ kp,
+                                                           int n, int radius, float* __restrict__ desc) {
+    const int side = 2 * radius + 1, dlen = side * side;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n * dlen) return;
+    const int k = (int)(gid / dlen), col = (int)(gid % dlen);
+    const float2 p = kp[k];
+    // Point2i p = kp.pt (:1013): saturate_cast<int>(float) rounds to nearest even
+    const int px = (int)rintf(p.x), py = (int)rintf(p.y);
+    const int y = py + col / side - radius, x = px + col % side - radius;
+    float val = 0.f;
+    if (y > 0 && y < rows && x > 0 && x < cols) {   // strict > 0 (:1018)
+        const int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows);
+        const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+        const uint8_t* r0 = img + (size_t)ym * cols;
+        const uint8_t* r1 = img + (size_t)y * cols;
+        const uint8_t* r2 = img + (size_t)yp * cols;
+        const int v = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+        val = (float)v;
+    }
+    desc[gid] = val;
+}
+
+int launch_extract(hipStream_t s, const uint8_t* img, int rows, int cols, const float2* kp, int n,
+                   int radius, float* desc) {
+    const int side = 2 * radius + 1;
+    const long long total = (long long)n * side * side;
+    if (total <= 0) return VISO_OK;
+    hipLaunchKernelGGL(extract_desc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img,
+                       rows, cols, kp, n, radius, desc);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
+extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, const float* kp, int n,
+                                        int radius, float* desc) {
+    if (!img || rows <= 0 || cols <= 0 || n < 0 || radius < 0 || (n && (!kp || !desc))) {
+        viso_set_error("viso_extract_descriptors: bad argument");
+        return VISO_ERR_ARG;
+    }
+    if (n == 0) return VISO_OK;
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    const int side = 2 * radius + 1;
+    uint8_t* dimg; float2* dkp; float* dd;
+    int r;
+    if ((r = ctx_scratch(c, 0, (size_t)rows * cols, (void**)&dimg)) < 0) return r;
+    if ((r = ctx_scratch(c, 1, sizeof(float2) * (size_t)n, (void**)&dkp)) < 0) return r;
+    if ((r = ctx_scratch(c, 2, sizeof(float) * (size_t)n * side * side, (void**)&dd)) < 0) return r;
+    HIP_TRY(hipMemcpyAsync(dimg, img, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dkp, kp, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if ((r = launch_extract(c->stream, dimg, rows, cols, dkp, n, radius, dd)) < 0) return r;
+    HIP_TRY(hipMemcpyAsync(desc, dd, sizeof(float) * (size_t)n * side * side, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VISO_OK;
+}

@@ -1,0 +1,406 @@
+// solver.hip — RANSAC + Gauss-Newton stereo reprojection pose solver kernels
+// (reference src/viso.cpp:1543-1580 ransac_minimize_reproj, :1583-1623
+// minimize_reproj, :1509-1537 get_inliers).  Latency-bound fp64 work: all
+// hypotheses of all frames run concurrently (one lane per 3-point hypothesis),
+// support sets are counted one wave per hypothesis, and the all-inlier refit
+// builds J^T J / J^T r per iteration as a workgroup reduction with the 6x6 LU
+// solve on one lane — the whole loop stays on the device.
+#include "solver_dev.h"
+
+struct SolverArgs {
+    const SolverItem* items;
+    int n_items;
+    int iters;
+    unsigned long long seed;
+    SolverParamsDev sp;
+};
+
+// ---- stage 1: one lane per (frame, hypothesis): 3-point GN from zero -------
+__global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= a.n_items * a.iters) return;
+    const int item = gid / a.iters, h = gid % a.iters;
+    const SolverItem S = a.items[item];
+    const int m = *S.m_ptr;
+    int ok = 0;
+    double tr[6] = {0, 0, 0, 0, 0, 0};        // "start search from 0", :1557
+    if (m >= 3) {
+        int sample[3];
+        if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
+        else viso_sample3(a.seed, S.frame, h, m, sample);
+        bool valid = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
+        if (valid) ok = gn_serial(S.X, S.obs, S.ld, sample, 3, tr, a.sp);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];
+    S.ok_h[h] = ok;
+}
+
+// ---- stage 2: one wave per (frame, hypothesis): support set size -----------
+__global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= a.n_items * a.iters) return;
+    const int item = wave / a.iters, h = wave % a.iters;
+    const SolverItem S = a.items[item];
+    const int m = *S.m_ptr;
+    int cnt = 0;
+    if (S.ok_h[h]) {
+        double tr[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * h + j];
+        RotDev R;
+        make_rot(tr, R);
+        for (int base = 0; base < m; base += 64) {
+            const int i = base + lane;
+            const bool in = (i < m) && is_inlier(R, a.sp, S.X, S.obs, S.ld, i, nullptr);
+            cnt += __popcll(__ballot(in));
+        }
+    }
+    if (lane == 0) S.cnt_h[h] = cnt;
+}
+
+// ---- workgroup helpers ------------------------------------------------------
+#define REFIT_THREADS 256
+
+// ordered (ascending index) compaction of the inliers of `tr` into out[];
+// returns the count to every thread.  scratch: >= 8 ints of LDS.
+__device__ int block_inliers(const double* tr, const SolverParamsDev& sp, const double* X,
+                             const double* obs, int ld, int m, int* out, int* scratch,
+                             double* last_err2) {
+    RotDev R;
+    make_rot(tr, R);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int running = 0;
+    for (int base = 0; base < m; base += REFIT_THREADS) {
+        const int i = base + threadIdx.x;
+        double e2 = 0;
+        const bool in = (i < m) && is_inlier(R, sp, X, obs, ld, i, &e2);
+        if (last_err2 && i == m - 1) *last_err2 = e2;
+        const unsigned long long msk = __ballot(in);
+        if (lane == 0) scratch[wave] = __popcll(msk);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += scratch[w];
+        const int total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        if (in) out[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(msk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk, 0u))] = i;
+        running += total;
+        __syncthreads();
+    }
+    return running;
+}
+
+// minimize_reproj over an arbitrary active list, one workgroup.  Every thread
+// accumulates its points' contribution to the 21+6 sums, the workgroup reduces
+// them (wave shuffles, then a fixed-order sum over the waves in LDS), lane 0
+// solves the 6x6 system and broadcasts the step.  tr_s: 6 doubles in LDS
+// (in/out).  red: >= 4*27+8 doubles of LDS.  Returns 1/0 to every thread.
+__device__ int gn_block(const double* X, const double* obs, int ld, const int* active, int n,
+                        double* tr_s, const SolverParamsDev& sp, double* red) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (n <= 0) return 0;
+    for (int it = 0; it < 100; ++it) {
+        double tr[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
+        RotDev R;
+        make_rot(tr, R);
+        double A[6][6], B[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            B[p] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) A[p][q] = 0;
+        }
+        for (int i = threadIdx.x; i < n; i += REFIT_THREADS)
+            accumulate_point(R, sp, X, obs, ld, active[i], i, A, B);
+        // wave reduction of the 27 sums
+        int c = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+            for (int q = p; q < 6; ++q) {
+                double v = A[p][q];
+#pragma unroll
+                for (int mk = 32; mk >= 1; mk >>= 1) v += __shfl_xor(v, mk);
+                if (lane == 0) red[wave * 27 + c] = v;
+                ++c;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            double v = B[p];
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) v += __shfl_xor(v, mk);
+            if (lane == 0) red[wave * 27 + 21 + p] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double S[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) S[k] = ((red[k] + red[27 + k]) + red[54 + k]) + red[81 + k];
+            int cc = 0;
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = p; q < 6; ++q) A[p][q] = S[cc++];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) B[p] = S[21 + p];
+            symmetrize(A);
+            int status;   // 0 = continue, 1 = converged, 2 = singular
+            if (!lu_solve6(A, B)) status = 2;
+            else {
+                bool converged = true;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (B[j] > sp.thresh) converged = false;
+                status = converged ? 1 : 0;
+                if (!converged) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) tr_s[j] = tr[j] + B[j];
+                }
+            }
+            reinterpret_cast<int*>(red + 4 * 27)[0] = status;
+        }
+        __syncthreads();
+        const int status = reinterpret_cast<int*>(red + 4 * 27)[0];
+        __syncthreads();
+        if (status == 1) return 1;
+        if (status == 2) return 0;
+    }
+    return 0;
+}
+
+// ---- stage 3: best hypothesis -> support set -> refit -> final support ------
+__global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs a) {
+    __shared__ double tr_s[6];
+    __shared__ double red[4 * 27 + 8];
+    __shared__ int scratch[8];
+    const int item = blockIdx.x;
+    if (item >= a.n_items) return;
+    const SolverItem S = a.items[item];
+    const int m = *S.m_ptr;
+    if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
+        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        int best = -1, best_cnt = 0;
+        for (int h = 0; h < a.iters; ++h)
+            if (S.ok_h[h] && S.cnt_h[h] > best_cnt) { best_cnt = S.cnt_h[h]; best = h; }   // strict >, :1564
+        scratch[4] = best;
+        for (int j = 0; j < 6; ++j) tr_s[j] = best >= 0 ? S.tr_h[6 * best + j] : S.tr[j];
+    }
+    __syncthreads();
+    const int best = scratch[4];
+    __syncthreads();
+    if (best < 0) {   // no hypothesis found any support: best_inliers stays empty, :1571
+        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
+        return;
+    }
+    double tr[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
+    int n = block_inliers(tr, a.sp, S.X, S.obs, S.ld, m, S.inl, scratch, nullptr);
+    __syncthreads();
+    int ok = 0;
+    if (n >= 6) {
+        __threadfence_block();
+        ok = gn_block(S.X, S.obs, S.ld, S.inl, n, tr_s, a.sp, red);   // :1572
+        __syncthreads();
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
+            n = block_inliers(tr, a.sp, S.X, S.obs, S.ld, m, S.inl, scratch, nullptr);   // :1575-1576
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < 6; ++j) S.tr[j] = tr_s[j];
+        *S.ok = ok;
+        *S.n_inl = n;
+    }
+}
+
+int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
+                  unsigned long long seed, const SolverParamsDev& sp) {
+    if (n_items <= 0) return VISO_OK;
+    SolverArgs a;
+    a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp;
+    const long long nh = (long long)n_items * iters;
+    if (nh > 0) {
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ransac_refit_kernel, dim3(n_items), dim3(REFIT_THREADS), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
+// ---- single minimize_reproj / get_inliers (plain family) --------------------
+struct GnArgs {
+    const double* X; const double* obs; int m, ld;
+    const int* active; int n;
+    double* tr; int* ok; int* inl; int* n_inl; double* rms;
+    SolverParamsDev sp;
+};
+
+__global__ __launch_bounds__(REFIT_THREADS) void minimize_reproj_kernel(GnArgs a) {
+    __shared__ double tr_s[6];
+    __shared__ double red[4 * 27 + 8];
+    if (threadIdx.x < 6) tr_s[threadIdx.x] = a.tr[threadIdx.x];
+    __syncthreads();
+    const int ok = gn_block(a.X, a.obs, a.ld, a.active, a.n, tr_s, a.sp, red);
+    __syncthreads();
+    if (threadIdx.x < 6) a.tr[threadIdx.x] = tr_s[threadIdx.x];
+    if (threadIdx.x == 0) *a.ok = ok;
+}
+
+__global__ __launch_bounds__(REFIT_THREADS) void get_inliers_kernel(GnArgs a) {
+    __shared__ int scratch[8];
+    __shared__ double last;
+    double tr[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tr[j] = a.tr[j];
+    if (threadIdx.x == 0) last = 0;
+    __syncthreads();
+    const int n = block_inliers(tr, a.sp, a.X, a.obs, a.ld, a.m, a.inl, scratch, &last);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *a.n_inl = n;
+        *a.rms = sqrt(last / a.m);   // Q8: error of the last point only, :1535
+    }
+}
+
+// ------------------------------------------------------------ host entry points
+void fill_solver_params(SolverParamsDev* d, const viso_param* h) {
+    d->base = h->base; d->f = h->f; d->cu = h->cu; d->cv = h->cv;
+    d->inlier_threshold = h->inlier_threshold; d->thresh = h->thresh;
+    d->ransac_iter = h->ransac_iter; d->_pad = 0;
+}
+
+extern "C" int viso_minimize_reproj(const double* X, const double* obs, int m, double tr[6],
+                                    const viso_param* p, const int32_t* active, int n_active) {
+    if (!X || !obs || !tr || !p || m < 0 || n_active < 0 || (n_active > 0 && !active)) {
+        viso_set_error("viso_minimize_reproj: bad argument");
+        return VISO_ERR_ARG;
+    }
+    for (int i = 0; i < n_active; ++i)
+        if (active[i] < 0 || active[i] >= m || i >= m) { viso_set_error("viso_minimize_reproj: active index out of range"); return VISO_ERR_ARG; }
+    if (n_active == 0) return 0;
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    double *dX, *dobs, *dtr; int *dact, *dok;
+    int r;
+    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
+    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
+    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
+    if ((r = ctx_scratch(c, 3, sizeof(int) * n_active, (void**)&dact)) < 0) return r;
+    if ((r = ctx_scratch(c, 4, sizeof(int) * 4, (void**)&dok)) < 0) return r;
+    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dtr, tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dact, active, sizeof(int) * n_active, hipMemcpyHostToDevice, c->stream));
+    GnArgs a{};
+    a.X = dX; a.obs = dobs; a.m = m; a.ld = m; a.active = dact; a.n = n_active; a.tr = dtr; a.ok = dok;
+    fill_solver_params(&a.sp, p);
+    hipLaunchKernelGGL(minimize_reproj_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    int ok = 0;
+    HIP_TRY(hipMemcpyAsync(tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ok, dok, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ok ? 1 : 0;
+}
+
+extern "C" int viso_get_inliers(const double* X, const double* obs, int m, const double tr[6],
+                                const viso_param* p, int32_t* inliers, int* n_inliers, double* rms) {
+    if (!X || !obs || !tr || !p || m < 0 || !inliers || !n_inliers) {
+        viso_set_error("viso_get_inliers: bad argument");
+        return VISO_ERR_ARG;
+    }
+    *n_inliers = 0;
+    if (m == 0) { if (rms) *rms = NAN; return VISO_OK; }
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    double *dX, *dobs, *dtr; int *dinl, *dn;
+    int r;
+    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
+    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
+    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
+    if ((r = ctx_scratch(c, 3, sizeof(int) * m, (void**)&dinl)) < 0) return r;
+    if ((r = ctx_scratch(c, 4, sizeof(int) * 4, (void**)&dn)) < 0) return r;
+    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dtr, tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    GnArgs a{};
+    a.X = dX; a.obs = dobs; a.m = m; a.ld = m; a.tr = dtr; a.inl = dinl; a.n_inl = dn; a.rms = dtr + 6;
+    fill_solver_params(&a.sp, p);
+    hipLaunchKernelGGL(get_inliers_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    int n = 0;
+    double rmsv = 0;
+    HIP_TRY(hipMemcpyAsync(&n, dn, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&rmsv, dtr + 6, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n > 0) HIP_TRY(hipMemcpy(inliers, dinl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    *n_inliers = n;
+    if (rms) *rms = rmsv;
+    return VISO_OK;
+}
+
+extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, int m,
+                                           double best_tr[6], int32_t* best_inl, int* n_inl,
+                                           const viso_param* p, const int32_t* samples,
+                                           uint64_t seed, uint64_t frame) {
+    if (!X || !obs || !best_tr || !p || m < 0 || !best_inl || !n_inl || p->ransac_iter < 0) {
+        viso_set_error("viso_ransac_minimize_reproj: bad argument");
+        return VISO_ERR_ARG;
+    }
+    *n_inl = 0;
+    if (m < 3) return 0;
+    const int iters = p->ransac_iter;
+    if (samples)
+        for (int i = 0; i < 3 * iters; ++i)
+            if (samples[i] < 0 || samples[i] >= m) { viso_set_error("viso_ransac_minimize_reproj: sample index out of range"); return VISO_ERR_ARG; }
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    double *dX, *dobs, *dtr, *dtrh; int *dinl, *dmisc, *dsamp = nullptr; SolverItem* ditem;
+    int r;
+    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
+    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
+    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
+    if ((r = ctx_scratch(c, 3, sizeof(int) * m, (void**)&dinl)) < 0) return r;
+    if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dmisc)) < 0) return r;
+    if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)(iters + 1), (void**)&dtrh)) < 0) return r;
+    if ((r = ctx_scratch(c, 6, sizeof(SolverItem), (void**)&ditem)) < 0) return r;
+    if (samples) {
+        if ((r = ctx_scratch(c, 7, sizeof(int) * 3 * (size_t)(iters + 1), (void**)&dsamp)) < 0) return r;
+        HIP_TRY(hipMemcpyAsync(dsamp, samples, sizeof(int) * 3 * iters, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dtr, best_tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    int hm[4] = {m, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, c->stream));
+    SolverItem it{};
+    it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.samples = dsamp; it.frame = frame;
+    it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + iters;
+    it.tr = dtr; it.ok = dmisc + 1; it.n_inl = dmisc + 2; it.inl = dinl;
+    HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    SolverParamsDev sp;
+    fill_solver_params(&sp, p);
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp)) < 0) return r;
+    int res[4];
+    HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(best_tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_inl = res[2];
+    if (res[2] > 0) HIP_TRY(hipMemcpy(best_inl, dinl, sizeof(int) * res[2], hipMemcpyDeviceToHost));
+    return res[1] ? 1 : 0;
+}

@@ -1,0 +1,224 @@
+// solver_dev.h — device functions of the stereo reprojection Gauss-Newton
+// solver: compute_J / minimize_reproj / get_inliers (reference
+// src/viso.cpp:1401-1497, 1583-1623, 1509-1537).  fp64 throughout; every
+// expression keeps the reference's operand order (the library is built with
+// -ffp-contract=off), so the only differences from the CPU path are the
+// last-ulp behaviour of sin/cos and the summation tree of the block reduction.
+#pragma once
+#include "common.h"
+
+#include <float.h>
+#include <math.h>
+
+struct RotDev {
+    double r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    double rdrx10, rdrx11, rdrx12, rdrx20, rdrx21, rdrx22;
+    double rdry00, rdry01, rdry02, rdry10, rdry11, rdry12, rdry20, rdry21, rdry22;
+    double rdrz00, rdrz01, rdrz10, rdrz11, rdrz20, rdrz21;
+    double tx, ty, tz;
+};
+
+// src/viso.cpp:1405-1424
+__device__ __forceinline__ void make_rot(const double* tr, RotDev& R) {
+    const double rx = tr[0], ry = tr[1], rz = tr[2];
+    R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
+    const double sx = sin(rx), cx = cos(rx), sy = sin(ry);
+    const double cy = cos(ry), sz = sin(rz), cz = cos(rz);
+    R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
+    R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
+    R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
+    R.rdrx10 = +cx * sy * cz - sx * sz; R.rdrx11 = -cx * sy * sz - sx * cz; R.rdrx12 = -cx * cy;
+    R.rdrx20 = +sx * sy * cz + cx * sz; R.rdrx21 = -sx * sy * sz + cx * cz; R.rdrx22 = -sx * cy;
+    R.rdry00 = -sy * cz;      R.rdry01 = +sy * sz;      R.rdry02 = +cy;
+    R.rdry10 = +sx * cy * cz; R.rdry11 = -sx * cy * sz; R.rdry12 = +sx * sy;
+    R.rdry20 = -cx * cy * cz; R.rdry21 = +cx * cy * sz; R.rdry22 = -cx * sy;
+    R.rdrz00 = -cy * sz;                R.rdrz01 = -cy * cz;
+    R.rdrz10 = -sx * sy * sz + cx * cz; R.rdrz11 = -sx * sy * cz - cx * sz;
+    R.rdrz20 = +cx * sy * sz + sx * cz; R.rdrz21 = +cx * sy * cz - sx * sz;
+}
+
+// prediction of one point (src/viso.cpp:1441-1443, 1452, 1486-1489)
+__device__ __forceinline__ void predict_point(const RotDev& R, const SolverParamsDev& sp,
+                                              double X1p, double Y1p, double Z1p, double pred[4],
+                                              double& X1c, double& Y1c, double& Z1c, double& X2c) {
+    X1c = R.r00 * X1p + R.r01 * Y1p + R.r02 * Z1p + R.tx;
+    Y1c = R.r10 * X1p + R.r11 * Y1p + R.r12 * Z1p + R.ty;
+    Z1c = R.r20 * X1p + R.r21 * Y1p + R.r22 * Z1p + R.tz;
+    X2c = X1c - sp.base;
+    pred[0] = sp.f * X1c / Z1c + sp.cu;
+    pred[1] = sp.f * Y1c / Z1c + sp.cv;
+    pred[2] = sp.f * X2c / Z1c + sp.cu;
+    pred[3] = sp.f * Y1c / Z1c + sp.cv;
+}
+
+// squared reprojection error test of get_inliers (src/viso.cpp:1524-1533)
+__device__ __forceinline__ bool is_inlier(const RotDev& R, const SolverParamsDev& sp, const double* X,
+                                          const double* obs, int ld, int i, double* err2_out) {
+    double pred[4], X1c, Y1c, Z1c, X2c;
+    predict_point(R, sp, X[0 * ld + i], X[1 * ld + i], X[2 * ld + i], pred, X1c, Y1c, Z1c, X2c);
+    const double e0 = obs[0 * ld + i] - pred[0];
+    const double e1 = obs[1 * ld + i] - pred[1];
+    const double e2 = obs[2 * ld + i] - pred[2];
+    const double e3 = obs[3 * ld + i] - pred[3];
+    const double err2 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    if (err2_out) *err2_out = err2;
+    return err2 < sp.inlier_threshold * sp.inlier_threshold;
+}
+
+// Adds the 4 Jacobian rows and residuals of one active point to the normal
+// equations A (upper triangle, 21 sums) and B (6 sums), rows in the
+// reference's order 4i..4i+3 (row 4i+3 equals row 4i+1, src/viso.cpp:1479,1481).
+// `pos` is the position in the active list: the weight reads observe(0,pos),
+// not observe(0,active[pos]) (Q6, src/viso.cpp:1449).
+__device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverParamsDev& sp,
+                                                 const double* X, const double* obs, int ld,
+                                                 int a, int pos, double A[6][6], double B[6]) {
+    const double X1p = X[0 * ld + a], Y1p = X[1 * ld + a], Z1p = X[2 * ld + a];
+    double pred[4], X1c, Y1c, Z1c, X2c;
+    predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
+    const double weight = 1.0 / (fabs(obs[0 * ld + pos] - sp.cu) / fabs(sp.cu) + 0.05);
+    double Jr[3][6];   // rows u_left, v_left, u_right
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double X1cd, Y1cd, Z1cd;
+        switch (j) {
+        case 0: X1cd = 0;
+            Y1cd = R.rdrx10 * X1p + R.rdrx11 * Y1p + R.rdrx12 * Z1p;
+            Z1cd = R.rdrx20 * X1p + R.rdrx21 * Y1p + R.rdrx22 * Z1p;
+            break;
+        case 1: X1cd = R.rdry00 * X1p + R.rdry01 * Y1p + R.rdry02 * Z1p;
+            Y1cd = R.rdry10 * X1p + R.rdry11 * Y1p + R.rdry12 * Z1p;
+            Z1cd = R.rdry20 * X1p + R.rdry21 * Y1p + R.rdry22 * Z1p;
+            break;
+        case 2: X1cd = R.rdrz00 * X1p + R.rdrz01 * Y1p;
+            Y1cd = R.rdrz10 * X1p + R.rdrz11 * Y1p;
+            Z1cd = R.rdrz20 * X1p + R.rdrz21 * Y1p;
+            break;
+        case 3: X1cd = 1; Y1cd = 0; Z1cd = 0; break;
+        case 4: X1cd = 0; Y1cd = 1; Z1cd = 0; break;
+        default: X1cd = 0; Y1cd = 0; Z1cd = 1; break;
+        }
+        Jr[0][j] = weight * sp.f * (X1cd * Z1c - X1c * Z1cd) / (Z1c * Z1c);
+        Jr[1][j] = weight * sp.f * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
+        Jr[2][j] = weight * sp.f * (X1cd * Z1c - X2c * Z1cd) / (Z1c * Z1c);
+    }
+    double res[4];
+    res[0] = weight * (obs[0 * ld + a] - pred[0]);
+    res[1] = weight * (obs[1 * ld + a] - pred[1]);
+    res[2] = weight * (obs[2 * ld + a] - pred[2]);
+    res[3] = weight * (obs[3 * ld + a] - pred[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int jr = (r == 3) ? 1 : r;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+            for (int q = p; q < 6; ++q) A[p][q] += Jr[jr][p] * Jr[jr][q];
+            B[p] += Jr[jr][p] * res[r];
+        }
+    }
+}
+
+// cv::solve(A, b, x, DECOMP_LU) for 6x6 (OpenCV 3.0 LUImpl: first strict
+// maximum pivot, singular iff |pivot| < DBL_EPSILON).  All indices static so
+// the matrix stays in registers; row swaps are predicated.
+__device__ __forceinline__ int lu_solve6(double A[6][6], double b[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int k = i;
+        double best = fabs(A[i][i]);
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const double v = fabs(A[j][i]);
+            if (v > best) { best = v; k = j; }
+        }
+        if (best < DBL_EPSILON) return 0;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            if (k == j) {
+#pragma unroll
+                for (int c = i; c < 6; ++c) { const double t = A[i][c]; A[i][c] = A[j][c]; A[j][c] = t; }
+                const double t = b[i]; b[i] = b[j]; b[j] = t;
+            }
+        }
+        const double d = -1 / A[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const double alpha = A[j][i] * d;
+#pragma unroll
+            for (int c = i + 1; c < 6; ++c) A[j][c] += alpha * A[i][c];
+            b[j] += alpha * b[i];
+        }
+        A[i][i] = -d;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int c = i + 1; c < 6; ++c) s -= A[i][c] * b[c];
+        b[i] = s * A[i][i];
+    }
+    return 1;
+}
+
+__device__ __forceinline__ void symmetrize(double A[6][6]) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = 0; q < p; ++q) A[p][q] = A[q][p];
+}
+
+// One thread runs the whole Gauss-Newton loop over `n` active points in the
+// reference's summation order (used for the 3-point RANSAC hypotheses: one
+// lane per hypothesis).  Returns 1 (converged) / 0; tr is in/out.
+__device__ inline int gn_serial(const double* X, const double* obs, int ld, const int* active,
+                                int n, double tr[6], const SolverParamsDev& sp) {
+    for (int it = 0; it < 100; ++it) {
+        RotDev R;
+        make_rot(tr, R);
+        double A[6][6], B[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            B[p] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) A[p][q] = 0;
+        }
+        for (int i = 0; i < n; ++i) accumulate_point(R, sp, X, obs, ld, active[i], i, A, B);
+        symmetrize(A);
+        if (!lu_solve6(A, B)) return 0;           // src/viso.cpp:1602-1606
+        bool converged = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (B[j] > sp.thresh) converged = false;   // Q7: fabs(p > thresh), :1610
+        if (converged) return 1;                  // step not applied, :1616-1617
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tr[j] = tr[j] + B[j];
+    }
+    return 0;                                     // :1622
+}
+
+// splitmix64-driven selection sampling == viso_ransac_samples (hostmath.cpp)
+__host__ __device__ inline unsigned long long viso_splitmix64(unsigned long long* s) {
+    unsigned long long z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__host__ __device__ inline void viso_sample3(unsigned long long seed, unsigned long long frame, int h,
+                                             int N, int out[3]) {
+    unsigned long long s = seed ^ (0xD1B54A32D192ED03ULL * (frame + 1)) ^
+                           (0x8CB92BA72F3D8DD7ULL * ((unsigned long long)h + 1));
+    int n = 3, t = 0, m = 0;
+    out[0] = out[1] = out[2] = 0;
+    if (N < n) return;
+    while (m < n) {
+        const double u = (double)(viso_splitmix64(&s) >> 11) * (1.0 / 9007199254740992.0);
+        if ((double)(N - t) * u >= (double)(n - m)) {
+            t++;
+        } else {
+            out[m] = t;
+            t++; m++;
+        }
+    }
+}

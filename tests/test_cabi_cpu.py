@@ -1,0 +1,93 @@
+"""No-GPU checks of the boundary: the C-ABI library loads, exports every
+symbol include/viso_hip.h declares, host-only entry points compute the
+reference's values, and device entry points fail loudly (never fall back to
+CPU) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams, Param
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(libviso_amd.SO_PATH):
+        libviso_amd.build()
+    return libviso_amd.load()
+
+
+def test_every_declared_symbol_is_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "viso_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(viso_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_layout_matches_header(L):
+    # sizes the C compiler produces for include/viso_hip.h
+    assert C.sizeof(MatchParams) == 16 + 9 * 8 + 3 * 8
+    assert C.sizeof(Param) == 8 + 8 + 5 * 8
+    mp = MatchParams()
+    F = np.arange(9, dtype=np.float64)
+    L.viso_match_params_stereo(C.byref(mp), F.ctypes.data_as(C.POINTER(C.c_double)))
+    ref = MatchParams.stereo(F)
+    assert bytes(mp) == bytes(ref)          # MatchParams(F), reference src/viso.cpp:62-71
+    L.viso_match_params_temporal(C.byref(mp))
+    assert bytes(mp) == bytes(MatchParams.temporal())
+    p = Param()
+    L.viso_param_default(C.byref(p))
+    assert bytes(p) == bytes(Param.default())
+
+
+def test_host_entry_points_match_oracle(L, oracle):
+    tr = np.array([0.01, -0.02, 0.03, 0.1, -0.2, 1.1])
+    assert np.array_equal(libviso_amd.tr2mat(tr), oracle.tr2mat(tr))
+    pose = oracle.pose_update(np.eye(4), tr * 0.5)
+    assert np.allclose(libviso_amd.pose_update(pose, tr), oracle.pose_update(pose, tr), rtol=0, atol=1e-14)
+    F = libviso_amd.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+    Fo = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+    assert np.allclose(F, Fo, rtol=1e-9, atol=1e-9)
+    P1 = np.hstack([np.eye(3), np.zeros((3, 1))]); P2 = P1.copy(); P2[0, 3] = 1
+    assert np.array_equal(libviso_amd.F_from_P(P1, P2), np.array([[0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]))
+    for m in (3, 10, 500):
+        assert np.array_equal(libviso_amd.ransac_samples(42, 7, 50, m), oracle.ransac_samples(42, 7, 50, m))
+
+
+def test_argument_errors_do_not_abort(L):
+    n = C.c_int(0)
+    mp = MatchParams.temporal()
+    r = L.viso_match_desc(None, -1, None, 0, None, None, 121, C.byref(mp), None, C.byref(n))
+    assert r == -1 and b"bad argument" in L.viso_last_error()
+
+
+def test_device_calls_fail_loudly_without_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rng = np.random.default_rng(0)
+    kp = rng.integers(0, 50, (8, 2)).astype(np.float32)
+    d = rng.integers(-5, 5, (8, 121)).astype(np.float32)
+    with pytest.raises(libviso_amd.VisoError):
+        libviso_amd.match_desc(kp, kp, d, d, MatchParams.temporal())
+    with pytest.raises(libviso_amd.VisoError):
+        libviso_amd.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    # the oracle is test infrastructure; the shipped path must not reach it
+    for base, _, files in os.walk(os.path.join(ROOT, "libviso_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(base, f), errors="replace").read()
+                bad = re.findall(r"^\s*(?:from|import)\s+oracle|#include\s+[\"<][^\n]*oracle|libviso_oracle|oracle_[a-z_0-9]+\s*\(",
+                                 txt, flags=re.M)
+                assert not bad, (os.path.join(base, f), bad)

@@ -1,0 +1,276 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  Integer work (match indices, SAD, circle rows, inlier
+sets) must be bit-exact; poses within 1e-5 relative Frobenius (north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams, Param
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5   # relative Frobenius norm of tr2mat(tr), BASELINE.json north_star
+
+
+def rel_fro(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def rand_problem(rng, n1, n2, width=200, height=100, dlen=121, planted=0.5, lo=-300, hi=300):
+    kp2 = np.stack([rng.integers(0, width, n2), rng.integers(0, height, n2)], 1).astype(np.float32)
+    d2 = rng.integers(lo, hi, (n2, dlen)).astype(np.float32)
+    kp1 = np.stack([rng.integers(0, width, n1), rng.integers(0, height, n1)], 1).astype(np.float32)
+    d1 = rng.integers(lo, hi, (n1, dlen)).astype(np.float32)
+    k = int(planted * min(n1, n2))
+    if k:
+        src = rng.choice(n2, k, replace=False)
+        kp1[:k] = kp2[src] + rng.integers(-6, 7, (k, 2))
+        d1[:k] = d2[src] + rng.integers(-5, 6, (k, dlen))
+    return kp1, kp2, d1, d2
+
+
+@pytest.fixture(scope="module")
+def F(oracle):
+    return oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+
+
+# ------------------------------------------------------------------ matcher
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 3), (63, 64), (64, 65), (65, 63), (300, 280), (1000, 900)])
+def test_match_desc_bit_exact(viso, oracle, F, n1, n2):
+    rng = np.random.default_rng(n1 * 1000 + n2)
+    kp1, kp2, d1, d2 = rand_problem(rng, n1, n2)
+    for mp in (MatchParams.temporal(), MatchParams.stereo(F)):
+        got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+        want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+        assert np.array_equal(got, want)
+
+
+def test_match_desc_empty_sets(viso, oracle):
+    rng = np.random.default_rng(1)
+    kp1, kp2, d1, d2 = rand_problem(rng, 10, 10)
+    mp = MatchParams.temporal()
+    assert len(libviso_amd.match_desc(kp1[:0], kp2, d1[:0], d2, mp)) == 0
+    assert len(libviso_amd.match_desc(kp1, kp2[:0], d1, d2[:0], mp)) == 0
+
+
+def test_match_desc_k_cap_and_dense_clusters(viso, oracle, F):
+    # every target within the radius of every query: exercises the K cap (slow
+    # path: selection of the K-th key) and the > QCAP streaming path
+    rng = np.random.default_rng(7)
+    kp1, kp2, d1, d2 = rand_problem(rng, 90, 700, width=30, height=20, planted=0.3)
+    for K in (1, 7, 200, 250, 300, 5000):
+        for base in (MatchParams.temporal(), MatchParams.stereo(F)):
+            base.max_neighbors = K
+            got = libviso_amd.match_desc(kp1, kp2, d1, d2, base)
+            want, sc = oracle.match_desc(kp1, kp2, d1, d2, base, return_scored=True)
+            assert np.array_equal(got, want), K
+    # duplicate keypoints: ties on the keypoint distance are broken by index
+    kp2[:] = kp2[0]
+    kp2[5:300] += 1
+    mp = MatchParams.temporal(); mp.max_neighbors = 40
+    assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
+
+
+def test_match_desc_quirks_q1_q2_q3(viso, oracle):
+    d = np.zeros((3, 121), np.float32)
+    kp2 = np.array([[10, 10], [14, 10], [30, 10]], np.float32)
+    d2 = d.copy(); d2[1] += 5; d2[2] += 1
+    mp = MatchParams.temporal(); mp.enforce_2nd_best = 0
+    for q in ([10, 10], [13, 10], [29, 10]):       # Q1: target 0 never matches and truncates
+        kp1 = np.array([q], np.float32)
+        assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d[:1], d2, mp), oracle.match_desc(kp1, kp2, d[:1], d2, mp))
+    kp2 = np.array([[0, 0], [10, 10], [11, 10], [12, 10], [13, 10]], np.float32)
+    d2 = np.zeros((5, 121), np.float32); d2[1] += 2; d2[2] += 2; d2[3] += 3; d2[4] += 2
+    kp1 = np.array([[10, 10]], np.float32)
+    got = libviso_amd.match_desc(kp1, kp2, d[:1], d2, mp)
+    assert got.tolist() == [[0, 4, 242]]            # Q2: last of the equal SADs wins
+    mp.enforce_2nd_best = 1
+    assert len(libviso_amd.match_desc(kp1, kp2, d[:1], d2, mp)) == 0   # Q3
+    assert libviso_amd.match_desc(kp1, kp2[:2], d[:1], d2[:2], mp).tolist() == [[0, 1, 242]]
+
+
+def test_match_desc_many_ties(viso, oracle, F):
+    rng = np.random.default_rng(3)
+    kp1, kp2, d1, d2 = rand_problem(rng, 400, 400, lo=-2, hi=3, planted=0.0)   # tiny range: many equal SADs
+    for mp in (MatchParams.temporal(), MatchParams.stereo(F)):
+        mp.enforce_2nd_best = 0
+        assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
+
+
+def test_match_desc_extreme_values_and_general_path(viso, oracle):
+    rng = np.random.default_rng(9)
+    kp1, kp2, d1, d2 = rand_problem(rng, 120, 130, lo=-32768, hi=32768)   # full int16 range (fast path)
+    mp = MatchParams.temporal()
+    assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
+    # non-integer / out-of-range descriptors and other lengths take the general (double) path
+    for dlen, scale in ((121, 0.25), (9, 1.0), (200, 1.0), (121, 300.0)):
+        kp1, kp2, d1, d2 = rand_problem(rng, 70, 80, dlen=dlen)
+        d1 = (d1 * scale).astype(np.float32); d2 = (d2 * scale).astype(np.float32)
+        got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+        assert np.array_equal(got, oracle.match_desc(kp1, kp2, d1, d2, mp)), (dlen, scale)
+
+
+def test_match_desc_float_keypoints(viso, oracle, F):
+    rng = np.random.default_rng(21)
+    kp1, kp2, d1, d2 = rand_problem(rng, 150, 160)
+    kp1 = kp1 + rng.uniform(-0.5, 0.5, kp1.shape).astype(np.float32)
+    kp2 = kp2 + rng.uniform(-0.5, 0.5, kp2.shape).astype(np.float32)
+    for mp in (MatchParams.temporal(), MatchParams.stereo(F)):
+        assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
+
+
+# ------------------------------------------------------ circle / geometry
+def test_match_circle_general(viso, oracle):
+    rng = np.random.default_rng(2)
+    for dup in (False, True):
+        hi = 12 if dup else 400
+        lists = [np.stack([rng.integers(0, hi, 300), rng.integers(0, hi, 300), rng.integers(0, 999, 300)], 1).astype(np.int32)
+                 for _ in range(4)]
+        if not dup:
+            for a in lists:
+                a[:, 0] = rng.permutation(400)[:300]
+            # plant consistent circles: lr (i,a) m11 (i,b) lr_prev (b,c) m22 (a,c)
+            lr, lrp, m11, m22 = lists
+            m22[:, 0] = 1000 + np.arange(300)
+            for j in range(0, 300, 3):
+                m11[j, 0], m11[j, 1] = lr[j, 0], lrp[j, 0]
+                m22[j, 0], m22[j, 1] = lr[j, 1], lrp[j, 1]
+        r0, c0, p0, n0 = oracle.match_circle(*lists, cap=200000)
+        r1, c1, p1, n1 = libviso_amd.match_circle(*lists, cap=200000)
+        assert (r0, n0) == (r1, n1) and np.array_equal(c0, c1) and np.array_equal(p0, p1)
+        assert n0 > 0
+    r1, _, _, n1 = libviso_amd.match_circle(*lists, cap=3)
+    assert r1 == -1 and n1 == n0
+
+
+def test_collect_triangulate_bit_exact(viso, oracle):
+    rng = np.random.default_rng(4)
+    kp1, kp2, d1, d2 = rand_problem(rng, 200, 200)
+    m = oracle.match_desc(kp1, kp2, d1, d2, MatchParams.temporal())
+    x = libviso_amd.collect_matches(kp1, kp2, m)
+    assert np.array_equal(x, oracle.collect_matches(kp1, kp2, m))
+    p = Param.kitti00()
+    with np.errstate(all="ignore"):
+        assert np.array_equal(libviso_amd.triangulate_rectified(x, p), oracle.triangulate_rectified(x, p), equal_nan=True)
+
+
+def test_extract_descriptors_bit_exact(viso, oracle):
+    img = synth.make_images(6, 60, 90)
+    rng = np.random.default_rng(6)
+    kp = np.stack([rng.integers(0, 90, 200), rng.integers(0, 60, 200)], 1).astype(np.float32)
+    kp[:4] = [[0, 0], [89, 59], [5, 5], [1, 1]]
+    assert np.array_equal(libviso_amd.extract_descriptors(img, kp), oracle.extract_descriptors(img, kp))
+
+
+# ------------------------------------------------------------------ solver
+@pytest.mark.parametrize("seed", range(3))
+def test_minimize_reproj_and_inliers(viso, oracle, seed):
+    X, obs, tr_gt, param = synth.make_solver_case(seed, m=150, outlier_frac=0.0, noise=0.3)
+    for active in (np.arange(150), np.array([3, 77, 120]), np.arange(0, 150, 7)):
+        ok0, tr0, _ = oracle.minimize_reproj(X, obs, np.zeros(6), param, active)
+        ok1, tr1 = libviso_amd.minimize_reproj(X, obs, np.zeros(6), param, active)
+        assert ok0 == ok1
+        if ok0:
+            assert rel_fro(libviso_amd.tr2mat(tr1), oracle.tr2mat(tr0)) < POSE_TOL
+    inl0, rms0 = oracle.get_inliers(X, obs, tr_gt, param)
+    inl1, rms1 = libviso_amd.get_inliers(X, obs, tr_gt, param)
+    assert np.array_equal(inl0, inl1) and abs(rms0 - rms1) <= 1e-12 * max(1, rms0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_ransac_minimize_reproj(viso, oracle, seed):
+    X, obs, tr_gt, param = synth.make_solver_case(10 + seed, m=400, outlier_frac=0.3, noise=0.25)
+    ok0, tr0, inl0 = oracle.ransac_minimize_reproj(X, obs, param, seed=seed, frame=3)
+    ok1, tr1, inl1 = libviso_amd.ransac_minimize_reproj(X, obs, param, seed=seed, frame=3)
+    assert ok0 == ok1 == 1 and np.array_equal(inl0, inl1)
+    assert rel_fro(libviso_amd.tr2mat(tr1), oracle.tr2mat(tr0)) < POSE_TOL
+    # explicit sample triples
+    s = oracle.ransac_samples(99, 0, param.ransac_iter, 400)
+    ok0, tr0, inl0 = oracle.ransac_minimize_reproj(X, obs, param, samples=s)
+    ok1, tr1, inl1 = libviso_amd.ransac_minimize_reproj(X, obs, param, samples=s)
+    assert ok0 == ok1 and np.array_equal(inl0, inl1) and rel_fro(libviso_amd.tr2mat(tr1), oracle.tr2mat(tr0)) < POSE_TOL
+
+
+def test_ransac_failure_modes(viso, oracle):
+    X, obs, tr_gt, param = synth.make_solver_case(5, m=40, outlier_frac=0.0, noise=0.1)
+    assert libviso_amd.ransac_minimize_reproj(X[:, :2].copy(), obs[:, :2].copy(), param)[0] == 0   # m < 3
+    rng = np.random.default_rng(0)
+    obs_bad = obs + rng.uniform(-300, 300, obs.shape)                                               # no support
+    ok0, _, inl0 = oracle.ransac_minimize_reproj(X, obs_bad, param, seed=1)
+    ok1, _, inl1 = libviso_amd.ransac_minimize_reproj(X, obs_bad, param, seed=1)
+    assert ok0 == ok1 == 0 and np.array_equal(inl0, inl1)
+
+
+# ------------------------------------------------------------------ batches
+@pytest.fixture(scope="module")
+def seq_small():
+    return synth.make_sequence(11, 11, n_kp=500, width=620, height=188, ragged=True, dup_frac=0.05)
+
+
+def test_batch_matcher_equals_per_call_oracle(viso, oracle, seq_small):
+    s = seq_small
+    nf, _, cap, _ = s["kp"].shape
+    st, tm = MatchParams.stereo(s["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, cap)
+    b.upload(s["kp"], s["desc"], s["n"])
+    b.set_params(st, tm, s["param"], seed=5)
+    b.run_matcher()
+    sc, mo = b.counters()
+    for t in range(nf):
+        n1, n2 = s["n"][t]
+        kL, kR, dL, dR = s["kp"][t, 0, :n1], s["kp"][t, 1, :n2], s["desc"][t, 0, :n1], s["desc"][t, 1, :n2]
+        want, wsc = oracle.match_desc(kL, kR, dL, dR, st, return_scored=True)
+        assert np.array_equal(b.matches(0, t), want) and sc[0, t] == wsc and mo[0, t] == len(want)
+        if t == 0:
+            assert len(b.matches(1, 0)) == 0 and len(b.matches(2, 0)) == 0
+            continue
+        p1, p2 = s["n"][t - 1]
+        want, wsc = oracle.match_desc(kL, s["kp"][t - 1, 0, :p1], dL, s["desc"][t - 1, 0, :p1], tm, return_scored=True)
+        assert np.array_equal(b.matches(1, t), want) and sc[1, t] == wsc
+        want, wsc = oracle.match_desc(kR, s["kp"][t - 1, 1, :p2], dR, s["desc"][t - 1, 1, :p2], tm, return_scored=True)
+        assert np.array_equal(b.matches(2, t), want) and sc[2, t] == wsc
+    b.close(); ctx.close()
+
+
+def test_batch_full_pipeline_vs_oracle_sequence(viso, oracle, seq_small):
+    s = seq_small
+    nf, _, cap, _ = s["kp"].shape
+    st, tm = MatchParams.stereo(s["F"]), MatchParams.temporal()
+    want = oracle.sequence(s["kp"], s["desc"], s["n"], st, tm, s["param"], seed=5, first_frame=100)
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, cap)
+    b.upload(s["kp"], s["desc"], s["n"])
+    b.set_params(st, tm, s["param"], seed=5, first_frame=100)
+    for _ in range(2):            # running twice must give the same answer (state is reset)
+        b.run()
+        tr, ok, n_inl = b.poses()
+        assert np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"])
+        assert ok[1:].all()
+        for t in range(1, nf):
+            assert rel_fro(libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])) < POSE_TOL
+            assert np.abs(tr[t] - s["tr_gt"][t]).max() < 2e-2
+    # circle join == literal nested loops on the match lists
+    for t in (1, nf - 1):
+        r, circ, pcl, n = oracle.match_circle(b.matches(0, t), b.matches(0, t - 1), b.matches(1, t), b.matches(2, t))
+        c1, p1 = b.circle(t)
+        assert np.array_equal(c1, circ) and np.array_equal(p1, pcl) and n > 20
+    b.close(); ctx.close()
+
+
+def test_batch_degenerate_frames(viso, oracle):
+    # frames with almost no keypoints: circle < 3 => no pose, like :1283-1288
+    s = synth.make_sequence(2, 4, n_kp=300, width=400, height=200)
+    s["n"][2] = [2, 2]
+    st, tm = MatchParams.stereo(s["F"]), MatchParams.temporal()
+    want = oracle.sequence(s["kp"], s["desc"], s["n"], st, tm, s["param"], seed=1)
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 4, 300)
+    b.upload(s["kp"], s["desc"], s["n"]); b.set_params(st, tm, s["param"], seed=1); b.run()
+    tr, ok, n_inl = b.poses()
+    assert np.array_equal(ok, want["ok"]) and ok.tolist() == [0, 1, 0, 0]
+    assert np.array_equal(n_inl, want["n_inl"])
+    b.close(); ctx.close()
