@@ -1,0 +1,130 @@
+// viso.hpp — C++ host mirror of the reference's call surface for the hot path
+// (alexkreimer/libviso src/viso.h:51-79,138-139,162 and the file-local
+// match_desc / MatchParams / match_circle / collect_matches /
+// triangulate_rectified of src/viso.cpp), forwarding to the C-ABI of
+// include/viso_hip.h.  Same names, same argument meaning, same outputs.
+//
+// The reference's types come from OpenCV (cv::Mat, cv::KeyPoint, cv::Vec3i),
+// which is not available to this build, so minimal stand-ins with the same
+// member names live in namespace viso (Mat_<T> = dense row-major matrix with
+// .rows/.cols/.at(r,c)); INTEGRATION.md shows the 20-line adapter from the
+// real OpenCV types.  Error behaviour: where the reference asserts
+// (BOOST_ASSERT_MSG / assert, e.g. src/viso.cpp:676) this mirror throws
+// std::invalid_argument; HIP failures throw std::runtime_error.  Solver
+// functions return the reference's bool.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/viso_hip.h"
+
+namespace viso {
+
+template <class T>
+struct Mat_ {
+    int rows = 0, cols = 0;
+    std::vector<T> data;
+    Mat_() = default;
+    Mat_(int r, int c, T v = T()) : rows(r), cols(c), data((size_t)r * c, v) {}
+    void create(int r, int c) { rows = r; cols = c; data.assign((size_t)r * c, T()); }
+    T& at(int r, int c) { return data[(size_t)r * cols + c]; }
+    const T& at(int r, int c) const { return data[(size_t)r * cols + c]; }
+    T* ptr(int r = 0) { return data.data() + (size_t)r * cols; }
+    const T* ptr(int r = 0) const { return data.data() + (size_t)r * cols; }
+    bool empty() const { return data.empty(); }
+    static Mat_ eye(int n) { Mat_ m(n, n); for (int i = 0; i < n; ++i) m.at(i, i) = T(1); return m; }
+};
+using Matd = Mat_<double>;
+using Matf = Mat_<float>;
+
+struct Point2f { float x = 0, y = 0; };
+struct KeyPoint { Point2f pt; float size = 0, response = 0; };   // cv::KeyPoint fields the path reads
+using KeyPoints = std::vector<KeyPoint>;
+using Match = std::array<int, 3>;          // Vec3i: i1, i2, dist   (src/viso.h:52)
+using Matches = std::vector<Match>;
+using Vec4i = std::array<int, 4>;
+using Descriptors = Matf;                  // N x 121 CV_32F        (src/viso.h:55)
+
+// struct param, src/viso.h:58-72
+struct param {
+    param() : ransac_iter(50), inlier_threshold(2), thresh(1e-4), save_debug(true) { base = 0; calib.f = calib.cu = calib.cv = 0; }
+    double base;
+    int ransac_iter;
+    double inlier_threshold;
+    double thresh;
+    bool save_debug;
+    struct { double f, cu, cv; } calib;
+    // deterministic replacement for randomsample's random_device (src/viso.cpp:93): stream key
+    uint64_t ransac_seed = 0, frame_index = 0;
+};
+
+// struct MatchParams, src/viso.cpp:48-75
+struct MatchParams {
+    bool enforce_epipolar;
+    Matd F;
+    double alg_thresh = 0;
+    double sampson_thresh = 0;
+    bool enforce_2nd_best;
+    double ratio_2nd_best;
+    bool allow_ann = true;
+    int max_neighbors;
+    double radius;
+    explicit MatchParams(const Matd& F_)
+        : enforce_epipolar(true), F(F_), sampson_thresh(1), enforce_2nd_best(false), ratio_2nd_best(.8),
+          max_neighbors(200), radius(80) {}
+    MatchParams() : enforce_epipolar(false), enforce_2nd_best(true), ratio_2nd_best(.9), max_neighbors(250), radius(80) {}
+};
+
+// src/viso.cpp:669-726
+void match_desc(const KeyPoints& kp1, const KeyPoints& kp2, const Descriptors& d1, const Descriptors& d2,
+                Matches& match, const MatchParams& sp = MatchParams());
+// src/viso.cpp:207-243
+void match_circle(const Matches& match_lr, const Matches& match_lr_prev, const Matches& match11,
+                  const Matches& match22, std::vector<Vec4i>& circ_match, Matches& match_pcl);
+// src/viso.cpp:501-514
+void collect_matches(const KeyPoints& kp1, const KeyPoints& kp2, const Matches& match, Matd& x);
+// src/viso.cpp:1137-1162 (T = double is the only instantiation the stereo path uses, :1247)
+Matd triangulate_rectified(const Matd& x, const param& param);
+// src/viso.h:74-79
+bool ransac_minimize_reproj(const Matd& X, const Matd& observe, std::vector<double>& best_tr,
+                            std::vector<int>& best_inliers, const param& param);
+bool minimize_reproj(const Matd& X, const Matd& observe, std::vector<double>& tr, const param& param,
+                     const std::vector<int>& active);
+// src/viso.h:162
+void tr2mat(std::vector<double> tr, Matd& Tr);
+// src/mvg.h:41-66 (+ the normalisation of src/viso.cpp:1177-1180)
+Matd F_from_P(const Matd& P1, const Matd& P2);
+// src/estimation.h:7-9 — Procrustes; dead on the stereo path, kept for the header surface.
+// A, B: 3 x n.  T: 4 x 4 with [R|t] minimising sum |R b_i + t - a_i|^2 (the reference's argument order).
+void solveRigidMotion(const Matf& A, const Matf& B, Matf& T);
+
+// One stereo frame as the front-end hands it to the hot path: what
+// detector.detect + extractor.compute produce at src/viso.cpp:1226-1231.
+struct StereoFeatures {
+    KeyPoints kp1, kp2;
+    Descriptors d1, d2;
+};
+// Generator in the style of StereoImageGenerator (src/viso.h:81-100): returns
+// std::nullopt at end of stream.
+using StereoFeatureGenerator = std::function<std::optional<StereoFeatures>()>;
+
+struct OdometryResult {
+    std::vector<Matd> poses;        // what the reference returns: poses[0] = I, then one per solved frame
+    std::vector<int> frame_of_pose; // frame index of poses[i] (0 for the identity) — the reference drops failed frames silently (:1287,:1323)
+    std::vector<int> ok, n_inliers; // per frame
+    std::vector<std::array<double, 6>> tr;
+};
+
+// sequence_odometry, src/viso.cpp:1167-1330, minus the front-end and the debug
+// dumps: frames are pulled from `frames`, processed on the GPU in chunks of
+// `chunk` frames (one-frame halo between chunks), poses chained on the host.
+OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGenerator frames,
+                                 int chunk = 64, uint64_t ransac_seed = 0);
+
+}  // namespace viso

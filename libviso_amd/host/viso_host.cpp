@@ -1,0 +1,324 @@
+// viso_host.cpp — implementation of the C++ host mirror (viso.hpp) on top of
+// the C-ABI (include/viso_hip.h).  No arithmetic of the hot path happens here:
+// this file reshapes containers into the ABI's plain arrays and chains poses.
+#include "viso.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace viso {
+
+static void hip_check(int r, const char* where) {
+    if (r < 0) throw std::runtime_error(std::string(where) + ": " + viso_last_error());
+}
+
+static std::vector<float> kp2mat(const KeyPoints& kp) {   // src/viso.cpp:246-256
+    std::vector<float> m(kp.size() * 2);
+    for (size_t i = 0; i < kp.size(); ++i) { m[2 * i] = kp[i].pt.x; m[2 * i + 1] = kp[i].pt.y; }
+    return m;
+}
+
+static viso_match_params to_abi(const MatchParams& sp) {
+    viso_match_params mp;
+    std::memset(&mp, 0, sizeof(mp));
+    mp.enforce_epipolar = sp.enforce_epipolar;
+    mp.enforce_2nd_best = sp.enforce_2nd_best;
+    mp.max_neighbors = sp.max_neighbors;
+    mp.sampson_thresh = sp.sampson_thresh;
+    mp.ratio_2nd_best = sp.ratio_2nd_best;
+    mp.radius = sp.radius;
+    if (sp.enforce_epipolar) {
+        if (sp.F.rows != 3 || sp.F.cols != 3) throw std::invalid_argument("MatchParams::F must be 3x3 double");
+        for (int i = 0; i < 9; ++i) mp.F[i] = sp.F.data[i];
+    }
+    return mp;
+}
+
+static viso_param to_abi(const param& p) {
+    viso_param q;
+    std::memset(&q, 0, sizeof(q));
+    q.base = p.base; q.ransac_iter = p.ransac_iter; q.save_debug = p.save_debug;
+    q.inlier_threshold = p.inlier_threshold; q.thresh = p.thresh;
+    q.f = p.calib.f; q.cu = p.calib.cu; q.cv = p.calib.cv;
+    return q;
+}
+
+void match_desc(const KeyPoints& kp1, const KeyPoints& kp2, const Descriptors& d1, const Descriptors& d2,
+                Matches& match, const MatchParams& sp) {
+    match.clear();                                             // :675
+    if (d1.cols != d2.cols && d1.rows && d2.rows) throw std::invalid_argument("match_desc: d1.cols != d2.cols");   // :676
+    if ((int)kp1.size() != d1.rows || (int)kp2.size() != d2.rows) throw std::invalid_argument("match_desc: keypoint/descriptor count mismatch");
+    const int dlen = d1.rows ? d1.cols : d2.cols;
+    if (kp1.empty()) return;
+    std::vector<float> k1 = kp2mat(kp1), k2 = kp2mat(kp2);
+    std::vector<int32_t> out(kp1.size() * 3);
+    int n = 0;
+    viso_match_params mp = to_abi(sp);
+    hip_check(viso_match_desc(k1.data(), (int)kp1.size(), k2.data(), (int)kp2.size(), d1.ptr(), d2.ptr(),
+                              dlen > 0 ? dlen : 1, &mp, out.data(), &n), "match_desc");
+    match.resize((size_t)n);
+    for (int i = 0; i < n; ++i) match[(size_t)i] = {out[3 * i], out[3 * i + 1], out[3 * i + 2]};
+}
+
+static std::vector<int32_t> flat(const Matches& m) {
+    std::vector<int32_t> v(m.size() * 3);
+    for (size_t i = 0; i < m.size(); ++i) { v[3 * i] = m[i][0]; v[3 * i + 1] = m[i][1]; v[3 * i + 2] = m[i][2]; }
+    return v;
+}
+
+void match_circle(const Matches& match_lr, const Matches& match_lr_prev, const Matches& match11,
+                  const Matches& match22, std::vector<Vec4i>& circ_match, Matches& match_pcl) {
+    std::vector<int32_t> a = flat(match_lr), b = flat(match_lr_prev), c = flat(match11), d = flat(match22);
+    int cap = (int)std::max<size_t>(16, match_lr.size() * 2), n = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<int32_t> circ((size_t)cap * 4), pcl((size_t)cap * 2);
+        int r = viso_match_circle(a.data(), (int)match_lr.size(), b.data(), (int)match_lr_prev.size(),
+                                  c.data(), (int)match11.size(), d.data(), (int)match22.size(),
+                                  circ.data(), pcl.data(), cap, &n);
+        if (r == VISO_ERR_ARG && n > cap) { cap = n; continue; }   // duplicate keys produced more rows: retry
+        hip_check(r, "match_circle");
+        // the reference appends (push_back) to both outputs, :233-234
+        for (int i = 0; i < n; ++i) {
+            circ_match.push_back({circ[4 * i], circ[4 * i + 1], circ[4 * i + 2], circ[4 * i + 3]});
+            match_pcl.push_back({pcl[2 * i], pcl[2 * i + 1], 0});
+        }
+        return;
+    }
+    throw std::runtime_error("match_circle: capacity retry failed");
+}
+
+void collect_matches(const KeyPoints& kp1, const KeyPoints& kp2, const Matches& match, Matd& x) {
+    x.create(4, (int)match.size());
+    if (match.empty()) return;
+    std::vector<float> k1 = kp2mat(kp1), k2 = kp2mat(kp2);
+    std::vector<int32_t> m = flat(match);
+    int r = viso_collect_matches(k1.data(), (int)kp1.size(), k2.data(), (int)kp2.size(), m.data(),
+                                 (int)match.size(), x.ptr());
+    if (r == VISO_ERR_ARG) throw std::out_of_range("collect_matches: match index out of range");   // vector::at
+    hip_check(r, "collect_matches");
+}
+
+Matd triangulate_rectified(const Matd& x, const param& p) {
+    if (x.rows != 4) throw std::invalid_argument("triangulate_rectified: x must be 4 x M");
+    Matd X(3, x.cols);
+    viso_param q = to_abi(p);
+    hip_check(viso_triangulate_rectified(x.ptr(), x.cols, &q, X.ptr()), "triangulate_rectified");
+    return X;
+}
+
+bool minimize_reproj(const Matd& X, const Matd& observe, std::vector<double>& tr, const param& p,
+                     const std::vector<int>& active) {
+    if (X.rows != 3 || observe.rows != 4 || X.cols != observe.cols || tr.size() != 6)
+        throw std::invalid_argument("minimize_reproj: X 3xM, observe 4xM, tr[6] expected");
+    viso_param q = to_abi(p);
+    std::vector<int32_t> a(active.begin(), active.end());
+    int r = viso_minimize_reproj(X.ptr(), observe.ptr(), X.cols, tr.data(), &q, a.data(), (int)a.size());
+    hip_check(r, "minimize_reproj");
+    return r == 1;
+}
+
+bool ransac_minimize_reproj(const Matd& X, const Matd& observe, std::vector<double>& best_tr,
+                            std::vector<int>& best_inliers, const param& p) {
+    if (X.rows != 3 || observe.rows != 4 || X.cols != observe.cols)
+        throw std::invalid_argument("ransac_minimize_reproj: X 3xM, observe 4xM expected");
+    if (best_tr.size() != 6) best_tr.assign(6, 0.0);
+    best_inliers.clear();                                      // :1554
+    viso_param q = to_abi(p);
+    std::vector<int32_t> inl((size_t)std::max(1, X.cols));
+    int n = 0;
+    int r = viso_ransac_minimize_reproj(X.ptr(), observe.ptr(), X.cols, best_tr.data(), inl.data(), &n, &q,
+                                        nullptr, p.ransac_seed, p.frame_index);
+    hip_check(r, "ransac_minimize_reproj");
+    best_inliers.assign(inl.begin(), inl.begin() + n);
+    return r == 1;
+}
+
+void tr2mat(std::vector<double> tr, Matd& Tr) {
+    if (tr.size() != 6) throw std::invalid_argument("tr2mat: tr must have 6 entries");
+    if (Tr.rows != 4 || Tr.cols != 4) Tr.create(4, 4);
+    viso_tr2mat(tr.data(), Tr.ptr());
+}
+
+Matd F_from_P(const Matd& P1, const Matd& P2) {
+    if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("F_from_P: 3x4 expected");
+    Matd F(3, 3);
+    viso_F_from_P(P1.ptr(), P2.ptr(), F.ptr());
+    return F;
+}
+
+// ---- 3x3 SVD by one-sided Jacobi (host; used only by solveRigidMotion) -----
+static void svd3(const double C[9], double U[9], double S[3], double V[9]) {
+    double A[9];
+    std::memcpy(A, C, sizeof(A));
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int k = 0; k < 3; ++k) { a += A[3 * k + p] * A[3 * k + p]; b += A[3 * k + q] * A[3 * k + q]; c += A[3 * k + p] * A[3 * k + q]; }
+                off = std::max(off, std::fabs(c) / std::sqrt(std::max(a * b, 1e-300)));
+                if (std::fabs(c) < 1e-300) continue;
+                const double zeta = (b - a) / (2 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double x = A[3 * k + p], y = A[3 * k + q];
+                    A[3 * k + p] = cs * x - sn * y; A[3 * k + q] = sn * x + cs * y;
+                    const double vx = V[3 * k + p], vy = V[3 * k + q];
+                    V[3 * k + p] = cs * vx - sn * vy; V[3 * k + q] = sn * vx + cs * vy;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    for (int j = 0; j < 3; ++j) {
+        double n = 0;
+        for (int k = 0; k < 3; ++k) n += A[3 * k + j] * A[3 * k + j];
+        S[j] = std::sqrt(n);
+    }
+    // order by decreasing singular value (Eigen's JacobiSVD convention)
+    int idx[3] = {0, 1, 2};
+    std::sort(idx, idx + 3, [&](int a, int b) { return S[a] > S[b]; });
+    double A2[9], V2[9], S2[3];
+    for (int j = 0; j < 3; ++j) { S2[j] = S[idx[j]]; for (int k = 0; k < 3; ++k) { A2[3 * k + j] = A[3 * k + idx[j]]; V2[3 * k + j] = V[3 * k + idx[j]]; } }
+    std::memcpy(V, V2, sizeof(V2)); std::memcpy(S, S2, sizeof(S2));
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) U[3 * k + j] = S[j] > 1e-300 ? A2[3 * k + j] / S[j] : 0.0;
+    // complete a rank-deficient U with cross products so that it stays orthonormal
+    auto col = [&](int j, double out[3]) { for (int k = 0; k < 3; ++k) out[k] = U[3 * k + j]; };
+    if (S[2] <= 1e-12 * std::max(S[0], 1e-300)) {
+        double u0[3], u1[3];
+        col(0, u0); col(1, u1);
+        if (S[1] <= 1e-12 * std::max(S[0], 1e-300)) {   // rank 1: pick any vector orthogonal to u0
+            double e[3] = {0, 0, 0};
+            int m = std::fabs(u0[0]) < std::fabs(u0[1]) ? (std::fabs(u0[0]) < std::fabs(u0[2]) ? 0 : 2) : (std::fabs(u0[1]) < std::fabs(u0[2]) ? 1 : 2);
+            e[m] = 1;
+            u1[0] = u0[1] * e[2] - u0[2] * e[1]; u1[1] = u0[2] * e[0] - u0[0] * e[2]; u1[2] = u0[0] * e[1] - u0[1] * e[0];
+            const double n = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+            for (int k = 0; k < 3; ++k) { u1[k] /= n; U[3 * k + 1] = u1[k]; }
+        }
+        U[0 + 2] = u0[1] * u1[2] - u0[2] * u1[1];
+        U[3 + 2] = u0[2] * u1[0] - u0[0] * u1[2];
+        U[6 + 2] = u0[0] * u1[1] - u0[1] * u1[0];
+    }
+}
+
+static double det3(const double M[9]) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// src/estimation.cpp:29-51
+void solveRigidMotion(const Matf& A, const Matf& B, Matf& T) {
+    if (A.cols <= 1) throw std::invalid_argument("solveRigidMotion: A.cols() > 1 required");                 // :32
+    if (A.cols != B.cols || A.rows != B.rows) throw std::invalid_argument("solveRigidMotion: shape mismatch");   // :35-38
+    if (A.rows != 3) throw std::invalid_argument("solveRigidMotion: A.rows() == 3 required");              // :39
+    const int n = A.cols;
+    double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+    for (int r = 0; r < 3; ++r) { for (int i = 0; i < n; ++i) { m1[r] += A.at(r, i); m2[r] += B.at(r, i); } m1[r] /= n; m2[r] /= n; }
+    double C[9] = {0};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int i = 0; i < n; ++i) s += (A.at(r, i) - m1[r]) * (B.at(c, i) - m2[c]); C[3 * r + c] = s; }
+    double U[9], S[3], V[9], UVt[9], R[9];
+    svd3(C, U, S, V);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += U[3 * r + k] * V[3 * c + k]; UVt[3 * r + c] = s; }
+    const double d = det3(UVt);
+    const double v[3] = {1, 1, d};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += U[3 * r + k] * v[k] * V[3 * c + k]; R[3 * r + c] = s; }
+    T.create(4, 4);
+    for (int r = 0; r < 3; ++r) {
+        double t = m1[r];
+        for (int c = 0; c < 3; ++c) { T.at(r, c) = (float)R[3 * r + c]; t -= R[3 * r + c] * m2[c]; }
+        T.at(r, 3) = (float)t;
+    }
+    T.at(3, 3) = 1.f;
+}
+
+// ---- sequence_odometry ------------------------------------------------------
+namespace {
+struct Ctx {
+    viso_ctx* c;
+    Ctx() : c(viso_ctx_create(0, nullptr)) { if (!c) throw std::runtime_error(std::string("viso_ctx_create: ") + viso_last_error()); }
+    ~Ctx() { viso_ctx_destroy(c); }
+};
+}
+
+OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGenerator frames, int chunk,
+                                 uint64_t ransac_seed) {
+    if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("sequence_odometry: P1,P2 must be 3x4");
+    if (chunk < 1) chunk = 1;
+    Matd F = F_from_P(P1, P2);                                        // :1176-1180
+    param prm;
+    prm.base = std::fabs(P2.at(0, 3) / P2.at(0, 0));                  // :1184
+    prm.calib.f = P1.at(0, 0); prm.calib.cu = P1.at(0, 2); prm.calib.cv = P1.at(1, 2);   // :1185-1187
+    viso_match_params st = to_abi(MatchParams(F)), tm = to_abi(MatchParams());
+    viso_param vp = to_abi(prm);
+    OdometryResult out;
+    out.poses.push_back(Matd::eye(4));                                // :1189-1190
+    out.frame_of_pose.push_back(0);
+    Ctx ctx;
+    std::vector<StereoFeatures> buf;                                  // frames of the current chunk (buf[0] = halo)
+    int global0 = 0;                                                  // global index of buf[0]
+    bool eos = false;
+    double pose[16];
+    std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
+    while (!eos) {
+        while ((int)buf.size() < chunk + 1) {
+            std::optional<StereoFeatures> f = frames();
+            if (!f) { eos = true; break; }
+            buf.push_back(std::move(*f));
+        }
+        const int nf = (int)buf.size();
+        if (nf == 0 || (nf == 1 && global0 > 0)) break;
+        int cap = 1, dlen = VISO_DESC_LEN;
+        for (auto& f : buf) {
+            cap = std::max({cap, (int)f.kp1.size(), (int)f.kp2.size()});
+            if (f.d1.rows) dlen = f.d1.cols; else if (f.d2.rows) dlen = f.d2.cols;
+            if ((int)f.kp1.size() != f.d1.rows || (int)f.kp2.size() != f.d2.rows) throw std::invalid_argument("sequence_odometry: keypoint/descriptor count mismatch");
+        }
+        std::vector<float> kp((size_t)nf * 2 * cap * 2, 0.f), desc((size_t)nf * 2 * cap * dlen, 0.f);
+        std::vector<int32_t> n((size_t)nf * 2);
+        for (int t = 0; t < nf; ++t)
+            for (int side = 0; side < 2; ++side) {
+                const KeyPoints& k = side ? buf[(size_t)t].kp2 : buf[(size_t)t].kp1;
+                const Descriptors& d = side ? buf[(size_t)t].d2 : buf[(size_t)t].d1;
+                if (d.rows && d.cols != dlen) throw std::invalid_argument("sequence_odometry: descriptor length changes between frames");
+                n[(size_t)t * 2 + side] = (int)k.size();
+                float* kd = kp.data() + ((size_t)t * 2 + side) * cap * 2;
+                for (size_t i = 0; i < k.size(); ++i) { kd[2 * i] = k[i].pt.x; kd[2 * i + 1] = k[i].pt.y; }
+                if (d.rows) std::memcpy(desc.data() + ((size_t)t * 2 + side) * cap * dlen, d.ptr(), sizeof(float) * (size_t)d.rows * dlen);
+            }
+        viso_batch* b = viso_batch_create(ctx.c, nf, cap, dlen);
+        if (!b) throw std::runtime_error(std::string("viso_batch_create: ") + viso_last_error());
+        std::vector<double> tr((size_t)nf * 6);
+        std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        int r = viso_batch_upload(b, 0, nf, kp.data(), desc.data(), n.data());
+        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
+        if (r >= 0) r = viso_batch_run(b);
+        if (r >= 0) r = viso_batch_get_poses(b, tr.data(), ok.data(), ninl.data());
+        viso_batch_destroy(b);
+        hip_check(r, "sequence_odometry");
+        for (int t = (global0 == 0 ? 0 : 1); t < nf; ++t) {
+            const int g = global0 + t;
+            out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
+            out.n_inliers.push_back(t == 0 ? 0 : ninl[(size_t)t]);
+            std::array<double, 6> a{};
+            if (t > 0) for (int j = 0; j < 6; ++j) a[(size_t)j] = tr[(size_t)t * 6 + j];
+            out.tr.push_back(a);
+            if (t > 0 && ok[(size_t)t]) {                              // :1313-1321
+                viso_pose_update(pose, a.data(), pose);
+                Matd P(4, 4);
+                std::memcpy(P.ptr(), pose, sizeof(pose));
+                out.poses.push_back(P);
+                out.frame_of_pose.push_back(g);
+            }
+        }
+        // keep the last frame as the next chunk's halo
+        StereoFeatures last = std::move(buf.back());
+        buf.clear();
+        buf.push_back(std::move(last));
+        global0 += nf - 1;
+    }
+    return out;
+}
+
+}  // namespace viso
