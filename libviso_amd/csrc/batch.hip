@@ -15,15 +15,13 @@
 #include <string.h>
 #include <vector>
 
-int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad,
-                       hipEvent_t e0, hipEvent_t e1);
-
 struct viso_batch {
     viso_ctx* ctx;
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
     float2* kp; float* desc; int* n; uint16_t* packed; int* bad; int* zero;
+    float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
+    ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
     int2* res; int* sorted; int* pos; int* m_cnt; unsigned long long* scored;
     double *x, *X, *x_c, *Xp_c;
@@ -59,7 +57,8 @@ extern "C" void viso_batch_destroy(viso_batch* b) {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
+    void* ptrs[] = {b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+                    b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -70,12 +69,26 @@ extern "C" void viso_batch_destroy(viso_batch* b) {
 static int build_items(viso_batch* b) {
     const int nf = b->nf, cap = b->cap;
     const size_t kpi = (size_t)cap, dsi = (size_t)cap * VISO_ROW, dfi = (size_t)cap * b->dlen;
+    // image views: index t*2+side, plus one empty view (n -> 0) for padding problems
+    std::vector<ImageView> V((size_t)nf * 2 + 1);
+    for (int t = 0; t < nf; ++t)
+        for (int side = 0; side < 2; ++side) {
+            const size_t i = (size_t)t * 2 + side;
+            ImageView& v = V[i];
+            v.kp = b->kp + i * kpi; v.frows = b->desc + i * dfi; v.n = b->n + i;
+            v.skp = b->skp + i * kpi; v.sidx = b->sidx + i * kpi; v.rank = b->rank + i * kpi;
+            v.bstart = b->bstart + i * (VISO_NB + 1); v.xinfo = b->xinfo + i * 2;
+            v.rows = b->packed + i * dsi;
+        }
+    {
+        ImageView& e = V[(size_t)nf * 2];
+        e = V[0];
+        e.n = b->zero;
+    }
+    HIP_TRY(hipMemcpy(b->views, V.data(), sizeof(ImageView) * V.size(), hipMemcpyHostToDevice));
     std::vector<MatchProblem> P((size_t)b->n_probs);
-    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.n1p = b->zero; p.n2p = b->zero; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
+    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
     auto img_kp = [&](int t, int side) { return b->kp + ((size_t)t * 2 + side) * kpi; };
-    auto img_u16 = [&](int t, int side) { return b->packed + ((size_t)t * 2 + side) * dsi; };
-    auto img_f32 = [&](int t, int side) { return b->desc + ((size_t)t * 2 + side) * dfi; };
-    auto img_n = [&](int t, int side) { return b->n + t * 2 + side; };
     for (int t = 0; t < nf; ++t) {
         for (int which = 0; which < 3; ++which) {
             if (which > 0 && t == 0) continue;   // first frame has no predecessor (:1256-1260)
@@ -84,10 +97,8 @@ static int build_items(viso_batch* b) {
             if (which == 0) { qs = 0; qt = t; ts = 1; tt = t; }          // match_desc(kp1,kp2,...) :1240
             else if (which == 1) { qs = 0; qt = t; ts = 0; tt = t - 1; } // (kp1,kp1_prev) :1264
             else { qs = 1; qt = t; ts = 1; tt = t - 1; }                 // (kp2,kp2_prev) :1275
-            p.kp1 = img_kp(qt, qs); p.kp2 = img_kp(tt, ts);
-            p.d1 = img_u16(qt, qs); p.d2 = img_u16(tt, ts);
-            p.f1 = img_f32(qt, qs); p.f2 = img_f32(tt, ts);
-            p.n1p = img_n(qt, qs); p.n2p = img_n(tt, ts);
+            p.q = V[(size_t)qt * 2 + qs];
+            p.t = V[(size_t)tt * 2 + ts];
             const size_t o = (size_t)which * nf + t;
             p.res = b->res + o * cap; p.sorted = b->sorted + o * cap * 3; p.pos = b->pos + o * cap;
             p.m_cnt = b->m_cnt + o; p.scored = b->scored + o;
@@ -153,6 +164,8 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->kp, nf * 2 * c)); A(dalloc(&b->desc, nf * 2 * c * dlen)); A(dalloc(&b->n, nf * 2));
     A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->bad, 4)); A(dalloc(&b->zero, 8));
     A(dalloc(&b->probs, (size_t)b->n_probs));
+    A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
+    A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
     A(dalloc(&b->m_cnt, 3 * nf)); A(dalloc(&b->scored, 3 * nf));
     A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
@@ -230,14 +243,15 @@ extern "C" int viso_batch_run_matcher(viso_batch* b) {
     HIP_TRY(hipMemsetAsync(b->bad, 0, sizeof(int), s));
     HIP_TRY(hipMemsetAsync(b->scored, 0, sizeof(unsigned long long) * 3 * (size_t)b->nf, s));
     int r;
-    if ((r = launch_pack(s, b->desc, b->packed, b->n, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
+    if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
+    if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         b->events.push_back({e0, e1});
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->cap, b->dlen, b->mp, b->bad, e0, e1)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad, e0, e1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     return VISO_OK;
 }

@@ -12,7 +12,9 @@
 #define VISO_QCAP 256         // per-wave candidate queue entries
 #define VISO_QPB 32           // queries per workgroup in the matcher
 #define VISO_MATCH_THREADS 256
-#define VISO_KP_LDS_MAX 12288 // target keypoints staged in LDS (96 KiB) at most
+#define VISO_KPCAP 1024       // target-window keypoints staged in LDS per query tile
+#define VISO_NB 256           // column buckets of the per-image x index
+#define VISO_SORT_MAX 16384   // keypoints per image / queries per call (LDS bitonic sorts)
 
 void viso_set_error(const char* fmt, ...);
 
@@ -34,16 +36,21 @@ struct MatchParamsDev {          // viso_match_params, device copy (kernarg)
     double sampson_thresh, ratio;
 };
 
+struct ImageView {               // one image's keypoints + descriptors on the device
+    const float2* kp;            // [n] boundary order (x,y)
+    const float* frows;          // [n][dlen] boundary-layout descriptors (original order)
+    const int* n;                // keypoint count (device, ragged batches)
+    float2* skp;                 // [n] keypoints sorted by x (ties by index)
+    int* sidx;                   // [n] sorted position -> original index
+    int* rank;                   // [n] original index -> sorted position
+    int* bstart;                 // [VISO_NB+1] first sorted position of each column bucket
+    float* xinfo;                // [2] x0, scale of the bucket map
+    uint16_t* rows;              // [n][128] packed descriptor rows, x-sorted order
+};
+
 struct MatchProblem {            // one match_desc call (reference src/viso.cpp:669)
-    const float2* kp1;           // queries  n1 x (x,y)
-    const float2* kp2;           // targets  n2 x (x,y)
-    const uint16_t* d1;          // packed rows (fast path)
-    const uint16_t* d2;
-    const float* f1;             // boundary-layout rows (general path)
-    const float* f2;
-    const int* n1p;              // counts live in device memory (ragged batches)
-    const int* n2p;
-    int2* res;                   // per query: (accepted target or -1, (int)best SAD)
+    ImageView q, t;              // queries (kp1,d1) and targets (kp2,d2)
+    int2* res;                   // per ORIGINAL query index: (accepted target or -1, (int)best SAD)
     int* sorted;                 // out: M x 3 (i1,i2,dist) sorted by (dist,i1)
     int* pos;                    // out: per query, row in `sorted` or -1
     int* m_cnt;                  // out: M
@@ -71,12 +78,15 @@ int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
 viso_ctx* viso_default_ctx();
 
 // ---- launchers (host) -------------------------------------------------------
-// pack boundary-layout float descriptors into biased u16 rows; sets *bad to 1
-// when a value is not an integer in [-32768, 32767] or dlen > 128.
-int launch_pack(hipStream_t s, const float* src, uint16_t* dst, const int* n_rows_per_img,
-                int n_img, int cap, int dlen, int* bad);
-int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                 int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad);
+// x-sort every image's keypoints (+ inverse permutation and column index)
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max);
+// pack boundary-layout float descriptors into biased u16 rows in x-sorted order;
+// sets *bad to 1 when a value is not an integer in [-32768, 32767] or dlen > 128.
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad);
+int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
+                 const MatchParamsDev mp[2], const int* bad);
+int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
+                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1);
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);

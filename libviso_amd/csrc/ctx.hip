@@ -108,9 +108,14 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if (!c) return VISO_ERR_HIP;
     hipStream_t s = c->stream;
     float2 *dk1, *dk2; float *df1, *df2; uint16_t *du1, *du2; int2* dres; int *dsorted, *dpos, *dmisc;
+    unsigned char* daux;
     MatchProblem* dprob;
     int r;
     const size_t n2a = (size_t)(n2 > 0 ? n2 : 1);
+    if (n1 > VISO_SORT_MAX || n2 > VISO_SORT_MAX) {
+        viso_set_error("viso_match_desc: more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
+        return VISO_ERR_UNSUPPORTED;
+    }
     if ((r = ctx_scratch(c, 0, sizeof(float2) * n1, (void**)&dk1)) < 0) return r;
     if ((r = ctx_scratch(c, 1, sizeof(float2) * n2a, (void**)&dk2)) < 0) return r;
     if ((r = ctx_scratch(c, 2, sizeof(float) * (size_t)n1 * dlen, (void**)&df1)) < 0) return r;
@@ -121,7 +126,10 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if ((r = ctx_scratch(c, 7, sizeof(int) * 3 * (size_t)n1, (void**)&dsorted)) < 0) return r;
     if ((r = ctx_scratch(c, 8, sizeof(int) * n1, (void**)&dpos)) < 0) return r;
     if ((r = ctx_scratch(c, 9, sizeof(int) * 16, (void**)&dmisc)) < 0) return r;
-    if ((r = ctx_scratch(c, 10, sizeof(MatchProblem), (void**)&dprob)) < 0) return r;
+    if ((r = ctx_scratch(c, 10, sizeof(MatchProblem) + 2 * sizeof(ImageView), (void**)&dprob)) < 0) return r;
+    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (8), 16-B aligned pieces
+    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 8 + 15) / 16) * 16; };
+    if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(dk1, kp1, sizeof(float2) * n1, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(df1, d1, sizeof(float) * (size_t)n1 * dlen, hipMemcpyHostToDevice, s));
     if (n2) {
@@ -131,17 +139,33 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     // dmisc: [0]=n1 [1]=n2 [2]=bad [3]=m_cnt [4..5]=scored (u64)
     int hm[8] = {n1, n2, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, s));
-    if ((r = launch_pack(s, df1, du1, dmisc + 0, 1, n1, dlen, dmisc + 2)) < 0) return r;
-    if (n2 && (r = launch_pack(s, df2, du2, dmisc + 1, 1, n2, dlen, dmisc + 2)) < 0) return r;
+    auto view = [&](unsigned char* base, size_t n, const float2* kp, const float* f, const int* np, uint16_t* rows) {
+        ImageView v{};
+        v.kp = kp; v.frows = f; v.n = np; v.rows = rows;
+        v.skp = (float2*)base;
+        v.sidx = (int*)(base + 8 * n);
+        v.rank = (int*)(base + 12 * n);
+        unsigned char* tail = base + ((16 * n + 15) / 16) * 16;
+        v.bstart = (int*)tail;
+        v.xinfo = (float*)(tail + 4 * (VISO_NB + 1));
+        return v;
+    };
     MatchProblem P{};
-    P.kp1 = dk1; P.kp2 = dk2; P.d1 = du1; P.d2 = du2; P.f1 = df1; P.f2 = df2;
-    P.n1p = dmisc + 0; P.n2p = dmisc + 1; P.res = dres; P.sorted = dsorted; P.pos = dpos;
+    P.q = view(daux, (size_t)n1, dk1, df1, dmisc + 0, du1);
+    P.t = view(daux + aux_bytes((size_t)n1), n2a, dk2, df2, dmisc + 1, du2);
+    P.res = dres; P.sorted = dsorted; P.pos = dpos;
     P.m_cnt = dmisc + 3; P.scored = (unsigned long long*)(dmisc + 4); P.pidx = 0; P.cap = n1;
-    HIP_TRY(hipMemcpyAsync(dprob, &P, sizeof(P), hipMemcpyHostToDevice, s));
+    struct { MatchProblem p; ImageView v[2]; } up;
+    up.p = P; up.v[0] = P.q; up.v[1] = P.t;
+    HIP_TRY(hipMemcpyAsync(dprob, &up, sizeof(up), hipMemcpyHostToDevice, s));
+    const ImageView* dviews = reinterpret_cast<const ImageView*>(dprob + 1);
+    const int capmax = n1 > n2 ? n1 : (int)n2a;
+    if ((r = launch_sort_kp(s, dviews, 2, capmax)) < 0) return r;
+    if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2)) < 0) return r;
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];
-    if ((r = launch_match(s, dprob, 1, n1, n2, dlen, mpd, dmisc + 2)) < 0) return r;
+    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 2)) < 0) return r;
     if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
     int m = 0;
     HIP_TRY(hipMemcpyAsync(&m, dmisc + 3, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -2,41 +2,45 @@
 //
 // Replaces match_desc + radiusSearch + sampsonDistance of the reference
 // (src/viso.cpp:669-726, 170-203, 655-666).  Integer abs-diff work: no MFMA;
-// the levers are coalesced 256-B descriptor rows, wave64 DPP reductions and
-// keeping every problem's working set inside one XCD's L2.
+// the levers are x-sorted images (a query tile only scans the +-radius column
+// window of the target image), coalesced 256-B descriptor rows, wave64
+// ballot/DPP reductions and keeping a problem's working set inside one XCD's L2.
 //
 // Kernels
-//   pack_desc_kernel    f32 N x dlen (boundary layout)  ->  u16 N x 128 rows (+bias)
-//   match_u16_kernel    neighbour gate + epipolar gate + SAD + best/2nd-best  (hot)
-//   match_f32_kernel    same walk, double-accumulated SAD for non-integer data
-//   sort_matches_kernel (dist,i1)-ordered match list, inverse permutation, count
+//   sort_kp_kernel       per image: keypoints sorted by x (+ inverse permutation, bucket index)
+//   pack_desc_kernel     f32 N x dlen (boundary layout) -> u16 N x 128 rows (+bias), x-sorted order
+//   match_kernel<false>  neighbour gate + epipolar gate + SAD + best/2nd-best   (hot, u16)
+//   match_kernel<true>   same walk, double-accumulated SAD for non-integer data
+//   sort_matches_kernel  (dist,i1)-ordered match list, inverse permutation, count
 //
-// Equivalence with the reference's list walk (proved in DESIGN.md §3):
+// Equivalence with the reference's list walk:
 // cvflann returns in-radius targets ordered by key=(L1 distance, index), keeps
 // the first K, and match_desc walks them while index > 0 (Q1).  Hence the
 // scored set is { t : key(t) < min(key_K, key(target 0 if in radius)) } and,
 // because the best/second-best update is order independent except for ties
 // (`<=`: the LAST equal candidate wins, Q2), the winner is the candidate of
-// minimal SAD with the LARGEST key.  No neighbour list is materialised.
+// minimal SAD with the LARGEST key.  No neighbour list is materialised, and the
+// order in which candidates are visited (here: x-sorted) is irrelevant.
 #include "common.h"
 
 #include <math.h>
 
 // ------------------------------------------------------------------ helpers
-__device__ __forceinline__ int lane_id() { return __lane_id(); }
-
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// sum over each row of 16 lanes, result in every lane of the row
-__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
-    v += dpp_mov<0x128>(v);  // row_ror:8
-    v += dpp_mov<0x124>(v);  // row_ror:4
-    v += dpp_mov<0x122>(v);  // row_ror:2
-    v += dpp_mov<0x121>(v);  // row_ror:1
+// sum over each group of 8 consecutive lanes, result in every lane of the group
+__device__ __forceinline__ uint32_t row8_sum(uint32_t v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror (quads are uniform by now)
     return v;
+}
+
+__device__ __forceinline__ int mbcnt(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
 // cvflann::L1<float> over 2 elements: result = 0; result += |a0-b0|; result += |a1-b1|
@@ -67,13 +71,112 @@ __device__ __forceinline__ bool key_less(uint32_t ad, uint32_t ai, uint32_t bd, 
     return ad < bd || (ad == bd && ai < bi);
 }
 
+// ------------------------------------------------------------------ x-sort
+// One workgroup per image.  Keys (sortable(x) << 32 | index) in LDS, bitonic
+// network; NaN x sorts last.  Also builds a 256-bucket column index so that a
+// query tile finds its target window with two independent loads.
+#define VISO_IMG_THREADS 512
+
+__device__ __forceinline__ uint32_t sortable_f32(float x) {
+    if (x != x) return 0xffffffffu;
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ int bucket_of(float x, float x0, float scale) {
+    if (x != x) return VISO_NB - 1;
+    const float f = floorf((x - x0) * scale);
+    return f <= 0.f ? 0 : (f >= (float)(VISO_NB - 1) ? VISO_NB - 1 : (int)f);
+}
+
+__global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img,
+                                                                   int npad_alloc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    float* s_x = reinterpret_cast<float*>(keys + npad_alloc);   // [0]=x0 [1]=scale
+    if ((int)blockIdx.x >= n_img) return;
+    const ImageView I = imgs[blockIdx.x];
+    const int n = *I.n;
+    int npad = 64;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += VISO_IMG_THREADS) {
+        unsigned long long k = ~0ull;
+        if (i < n) k = ((unsigned long long)sortable_f32(I.kp[i].x) << 32) | (uint32_t)i;
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npad >> 1); t += VISO_IMG_THREADS) {
+                const int i = ((t / j) * 2 * j) + (t % j);
+                const int l = i + j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = keys[i], b = keys[l];
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < n; j += VISO_IMG_THREADS) {
+        const int idx = (int)(uint32_t)keys[j];
+        I.skp[j] = I.kp[idx];
+        I.sidx[j] = idx;
+        I.rank[idx] = j;
+    }
+    if (threadIdx.x == 0) {
+        float x0 = 0.f, scale = 0.f;
+        if (n > 0) {
+            x0 = I.kp[(int)(uint32_t)keys[0]].x;
+            int last = n - 1;   // last non-NaN x (NaNs sort to the end)
+            while (last > 0 && (uint32_t)(keys[last] >> 32) == 0xffffffffu) --last;
+            const float x1 = I.kp[(int)(uint32_t)keys[last]].x;
+            if (x1 > x0) scale = (float)VISO_NB / (x1 - x0);
+            if (!(scale > 0.f) || !(scale < 3.0e38f)) scale = 0.f;
+            if (x0 != x0) { x0 = 0.f; scale = 0.f; }
+        }
+        s_x[0] = x0; s_x[1] = scale;
+        I.xinfo[0] = x0; I.xinfo[1] = scale;
+    }
+    __syncthreads();
+    const float x0 = s_x[0], scale = s_x[1];
+    // replace each key by its bucket (monotone in j), then bstart[b] = first j with bucket >= b
+    for (int j = threadIdx.x; j < n; j += VISO_IMG_THREADS) {
+        const int idx = (int)(uint32_t)keys[j];
+        const int bk = bucket_of(I.kp[idx].x, x0, scale);
+        keys[j] = (unsigned long long)bk;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= VISO_NB; b += VISO_IMG_THREADS) {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)keys[mid] >= b) hi = mid; else lo = mid + 1;
+        }
+        I.bstart[b] = (b == VISO_NB) ? n : lo;
+    }
+}
+
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max) {
+    if (n_img <= 0) return VISO_OK;
+    if (cap_max > VISO_SORT_MAX) {
+        viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
+        return VISO_ERR_UNSUPPORTED;
+    }
+    int npad = 64;
+    while (npad < cap_max) npad <<= 1;
+    const size_t lds = (size_t)npad * sizeof(unsigned long long) + 16;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)sort_kp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, npad);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
 // ------------------------------------------------------------------ pack
-// One thread = 8 consecutive u16 of one row (a 16-B store).
-__global__ __launch_bounds__(256) void pack_desc_kernel(const float* __restrict__ src,
-                                                        uint16_t* __restrict__ dst,
-                                                        const int* __restrict__ n_rows,
-                                                        int n_img, int cap, int dlen,
-                                                        int* __restrict__ bad) {
+// One thread = 8 consecutive u16 of one row (a 16-B store).  Row j of the
+// packed image is the descriptor of keypoint sidx[j] (x-sorted order).
+__global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
+                                                        int cap, int dlen, int* __restrict__ bad) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)n_img * cap * (VISO_ROW / 8);
     if (gid >= total) return;
@@ -81,8 +184,9 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const float* __restrict_
     const long long row = gid / (VISO_ROW / 8);
     const int img = (int)(row / cap);
     const int r = (int)(row % cap);
-    if (r >= n_rows[img]) return;
-    const float* s = src + row * dlen;
+    const ImageView I = imgs[img];
+    if (r >= *I.n) return;
+    const float* s = I.frows + (size_t)I.sidx[r] * dlen;
     uint32_t w[4];
     bool isbad = false;
 #pragma unroll
@@ -102,12 +206,11 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const float* __restrict_
         }
         w[k] = pair;
     }
-    *reinterpret_cast<uint4*>(dst + row * VISO_ROW + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(I.rows + (size_t)r * VISO_ROW + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     if (isbad) atomicOr(bad, 1);
 }
 
-int launch_pack(hipStream_t s, const float* src, uint16_t* dst, const int* n_rows_per_img,
-                int n_img, int cap, int dlen, int* bad) {
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad) {
     if (dlen > VISO_ROW) {  // rows do not fit the packed format: force the general path
         int one = 1;
         HIP_TRY(hipMemcpyAsync(bad, &one, sizeof(int), hipMemcpyHostToDevice, s));
@@ -116,16 +219,17 @@ int launch_pack(hipStream_t s, const float* src, uint16_t* dst, const int* n_row
     const long long total = (long long)n_img * cap * (VISO_ROW / 8);
     if (total == 0) return VISO_OK;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n_rows_per_img,
-                       n_img, cap, dlen, bad);
+    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, cap, dlen, bad);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
 
-// ------------------------------------------------------------------ scorers
+// ------------------------------------------------------------------ trackers
 // Best / second-best bookkeeping (src/viso.cpp:703-709), order independent:
-// d1 = min SAD, d2 = second order statistic WITH multiplicity, key = largest
-// (distance,index) among the candidates whose SAD equals d1.
+// d1 = min SAD, d2 = second order statistic WITH multiplicity, winner = the
+// candidate with SAD == d1 and the largest key (distance bits, original index).
+
+// Exact tracker (keys compared on every update).
 struct TrackU {
     uint32_t d1, d2, kd, ki;
     __device__ __forceinline__ void init() { d1 = d2 = 0xffffffffu; kd = ki = 0; }
@@ -153,56 +257,102 @@ struct TrackU {
     }
 };
 
-// Fast path: 16 lanes per candidate, one 16-B load each (a 256-B row per
-// 16-lane DPP row), 4 x v_sad_u16, 4 DPP adds.  4 candidates per wave pass.
-struct ScorerU16 {
-    const uint16_t* d2;
-    uint4 q;        // this lane's 8 query elements
-    TrackU t;
-    int g, sub;
-    __device__ __forceinline__ void begin(const MatchProblem& P, int i, int lane) {
-        g = lane >> 4; sub = lane & 15;
-        d2 = P.d2;
-        q = *reinterpret_cast<const uint4*>(P.d1 + (size_t)i * VISO_ROW + sub * 8);
-        t.init();
+// Cheap tracker: remembers ANY position reaching d1 and whether d1 was reached
+// more than once; ties (rare) are resolved by re-scoring with TrackU.
+struct TrackT {
+    uint32_t d1, d2, bp, tie;
+    __device__ __forceinline__ void init() { d1 = d2 = 0xffffffffu; bp = 0; tie = 0; }
+    __device__ __forceinline__ void add(uint32_t s, uint32_t p) {   // s == 0xffffffff: invalid slot
+        const bool lt = s < d1;
+        const bool eq = (s == d1) && (s != 0xffffffffu);
+        d2 = (lt || eq) ? d1 : min(d2, s);
+        tie = lt ? 0u : (tie | (uint32_t)eq);
+        d1 = lt ? s : d1;
+        bp = lt ? p : bp;
     }
-    __device__ __forceinline__ void score(const uint2* queue, int n) {
-        for (int b = 0; b < n; b += 16) {
-            uint2 e[4];
-            uint4 r[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int j = min(b + p * 4 + g, n - 1);
-                e[p] = queue[j];
-                r[p] = *reinterpret_cast<const uint4*>(d2 + (size_t)e[p].x * VISO_ROW + sub * 8);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                uint32_t s = __builtin_amdgcn_sad_u16(r[p].x, q.x, 0u);
-                s = __builtin_amdgcn_sad_u16(r[p].y, q.y, s);
-                s = __builtin_amdgcn_sad_u16(r[p].z, q.z, s);
-                s = __builtin_amdgcn_sad_u16(r[p].w, q.w, s);
-                s = row16_sum(s);
-                const bool valid = (b + p * 4 + g) < n;
-                t.add(valid ? s : 0xffffffffu, e[p].y, e[p].x);
-            }
-        }
-    }
-    // combine the four 16-lane groups; every lane ends with the wave result
-    __device__ __forceinline__ void finish(int& idx, int& dist, double& bd1, double& bd2) {
-#pragma unroll
-        for (int m = 16; m <= 32; m <<= 1) {
-            const uint32_t od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
-            const uint32_t okd = __shfl_xor(t.kd, m), oki = __shfl_xor(t.ki, m);
-            t.merge(od1, od2, okd, oki);
-        }
-        const bool any = t.d1 != 0xffffffffu;
-        idx = any ? (int)t.ki : -1;
-        dist = (int)t.d1;
-        bd1 = (double)t.d1;
-        bd2 = (t.d2 == 0xffffffffu) ? 1.7976931348623157e308 : (double)t.d2;
+    __device__ __forceinline__ void merge(uint32_t od1, uint32_t od2, uint32_t obp, uint32_t otie) {
+        if (od1 < d1) { d2 = min(d1, od2); d1 = od1; bp = obp; tie = otie; }
+        else if (od1 == d1) { if (d1 != 0xffffffffu) { d2 = d1; tie = 1; } }
+        else d2 = min(d2, od1);
     }
 };
+
+// ------------------------------------------------------------------ scorers
+// Queue entries: (sorted target position p, float bits of the keypoint distance).
+//
+// Fast path: 8 lanes per candidate, two 16-B loads each (chunks sub and sub+8
+// of the 256-B row: every load instruction touches whole 128-B lines),
+// 8 x v_sad_u16, 3 DPP adds; 8 candidates per wave pass, two passes in flight.
+struct ScorerU16 {
+    const uint16_t* d2;
+    const int* sidx2;
+    uint4 q0, q1;   // this lane's 16 query elements
+    int g, sub;
+    __device__ __forceinline__ void begin(const MatchProblem& P, int j, int lane) {
+        g = lane >> 3; sub = lane & 7;
+        d2 = P.t.rows; sidx2 = P.t.sidx;
+        const uint16_t* qr = P.q.rows + (size_t)j * VISO_ROW + sub * 8;
+        q0 = *reinterpret_cast<const uint4*>(qr);
+        q1 = *reinterpret_cast<const uint4*>(qr + 64);
+    }
+    __device__ __forceinline__ uint32_t sad_row(const uint4& r0, const uint4& r1) const {
+        uint32_t s = __builtin_amdgcn_sad_u16(r0.x, q0.x, 0u);
+        s = __builtin_amdgcn_sad_u16(r0.y, q0.y, s);
+        s = __builtin_amdgcn_sad_u16(r0.z, q0.z, s);
+        s = __builtin_amdgcn_sad_u16(r0.w, q0.w, s);
+        s = __builtin_amdgcn_sad_u16(r1.x, q1.x, s);
+        s = __builtin_amdgcn_sad_u16(r1.y, q1.y, s);
+        s = __builtin_amdgcn_sad_u16(r1.z, q1.z, s);
+        s = __builtin_amdgcn_sad_u16(r1.w, q1.w, s);
+        return row8_sum(s);
+    }
+    __device__ __forceinline__ void score_fast(const uint2* queue, int n, TrackT& t) const {
+        for (int b = 0; b < n; b += 16) {
+            uint2 e[2];
+            uint4 r0[2], r1[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                e[p] = queue[min(b + p * 8 + g, n - 1)];
+                const uint16_t* row = d2 + (size_t)e[p].x * VISO_ROW + sub * 8;
+                r0[p] = *reinterpret_cast<const uint4*>(row);
+                r1[p] = *reinterpret_cast<const uint4*>(row + 64);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t s = sad_row(r0[p], r1[p]);
+                t.add((b + p * 8 + g) < n ? s : 0xffffffffu, e[p].x);
+            }
+        }
+    }
+    __device__ __forceinline__ void score_exact(const uint2* queue, int n, TrackU& t) const {
+        for (int b = 0; b < n; b += 8) {
+            const uint2 e = queue[min(b + g, n - 1)];
+            const uint16_t* row = d2 + (size_t)e.x * VISO_ROW + sub * 8;
+            const uint4 r0 = *reinterpret_cast<const uint4*>(row);
+            const uint4 r1 = *reinterpret_cast<const uint4*>(row + 64);
+            const uint32_t oi = (uint32_t)sidx2[e.x];
+            const uint32_t s = sad_row(r0, r1);
+            t.add((b + g) < n ? s : 0xffffffffu, e.y, oi);
+        }
+    }
+};
+
+__device__ __forceinline__ void merge_groups(TrackT& t) {
+#pragma unroll
+    for (int m = 8; m <= 32; m <<= 1) {
+        const uint32_t od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
+        const uint32_t obp = __shfl_xor(t.bp, m), ot = __shfl_xor(t.tie, m);
+        t.merge(od1, od2, obp, ot);
+    }
+}
+__device__ __forceinline__ void merge_groups(TrackU& t) {
+#pragma unroll
+    for (int m = 8; m <= 32; m <<= 1) {
+        const uint32_t od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
+        const uint32_t okd = __shfl_xor(t.kd, m), oki = __shfl_xor(t.ki, m);
+        t.merge(od1, od2, okd, oki);
+    }
+}
 
 // General path (descriptors that are not int16-valued, or dlen > 128): one
 // lane per candidate, |a-b| in float summed in double in index order — the
@@ -230,186 +380,217 @@ struct TrackD {
 struct ScorerF32 {
     const float* f1row;
     const float* f2;
+    const int* sidx2;
     int dlen, lane;
-    TrackD t;
-    __device__ __forceinline__ void begin(const MatchProblem& P, int i, int lane_, int dlen_) {
+    __device__ __forceinline__ void begin(const MatchProblem& P, int orig_q, int lane_, int dlen_) {
         dlen = dlen_; lane = lane_;
-        f1row = P.f1 + (size_t)i * dlen;
-        f2 = P.f2;
-        t.init();
+        f1row = P.q.frows + (size_t)orig_q * dlen;
+        f2 = P.t.frows; sidx2 = P.t.sidx;
     }
-    __device__ __forceinline__ void score(const uint2* queue, int n) {
+    __device__ __forceinline__ void score(const uint2* queue, int n, TrackD& t) const {
         for (int j = lane; j < n; j += VISO_WAVE) {
             const uint2 e = queue[j];
-            const float* a = f2 + (size_t)e.x * dlen;
+            const uint32_t oi = (uint32_t)sidx2[e.x];
+            const float* a = f2 + (size_t)oi * dlen;
             double s = 0;
             for (int c = 0; c < dlen; ++c) {
                 const float df = a[c] - f1row[c];
                 s += (double)fabsf(df);
             }
-            t.add(s, e.y, e.x);
+            t.add(s, e.y, oi);
         }
     }
-    __device__ __forceinline__ void finish(int& idx, int& dist, double& bd1, double& bd2) {
+};
+
+__device__ __forceinline__ void merge_lanes(TrackD& t) {
 #pragma unroll
-        for (int m = 1; m < VISO_WAVE; m <<= 1) {
-            const double od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
-            const uint32_t okd = __shfl_xor(t.kd, m), oki = __shfl_xor(t.ki, m);
-            const int oany = __shfl_xor((int)t.any, m);
-            t.merge(od1, od2, okd, oki, oany != 0);
-        }
-        idx = t.any ? (int)t.ki : -1;
-        // Vec3i(i, idx, double): conversion truncates; saturate instead of UB
-        double c = t.d1 > 2147483647.0 ? 2147483647.0 : t.d1;
-        dist = t.any ? (int)c : 0;
-        bd1 = t.d1; bd2 = t.d2;
+    for (int m = 1; m < VISO_WAVE; m <<= 1) {
+        const double od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
+        const uint32_t okd = __shfl_xor(t.kd, m), oki = __shfl_xor(t.ki, m);
+        const int oany = __shfl_xor((int)t.any, m);
+        t.merge(od1, od2, okd, oki, oany != 0);
     }
-};
-
-// ------------------------------------------------------------------ the walk
-// Target keypoints come either from LDS (staged once per workgroup) or global.
-template <bool STAGED>
-struct KpSrc {
-    const float2* g;
-    const float2* s;
-    __device__ __forceinline__ float2 at(int t) const { return STAGED ? s[t] : g[t]; }
-};
-
-// Count the targets whose key=(dist,idx) is < (kd,ki), among those in radius
-// and below the Q1 cut.  Wave-uniform result.
-template <bool STAGED>
-__device__ int count_below(const KpSrc<STAGED>& kp, int n2, float qx, float qy, float radius,
-                           float d0cut, uint32_t kd, uint32_t ki, int lane) {
-    int c = 0;
-    for (int base = 0; base < n2; base += VISO_WAVE) {
-        const int t = base + lane;
-        bool in = false;
-        if (t < n2) {
-            const float d = l1_kp(qx, qy, kp.at(t));
-            in = (d <= radius) && (d < d0cut) && key_less(__float_as_uint(d), (uint32_t)t, kd, ki);
-        }
-        c += __popcll(__ballot(in));
-    }
-    return c;
 }
 
-template <bool STAGED, class Scorer>
-__device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int i, int n2,
-                            const KpSrc<STAGED>& kp, uint2* queue, Scorer& sc, int lane,
-                            unsigned long long& scored) {
-    const float2 q = P.kp1[i];
+// ------------------------------------------------------------------ the walk
+// Window of the target image a query tile has to look at: sorted positions
+// [lo, lo+W).  The first `cap` entries are staged in LDS, the rest (dense
+// clusters only) is read from global memory.
+struct Window {
+    const float2* gkp; const int* gidx;   // global, sorted order
+    const float2* skp; const int* sidx;   // LDS copies of [lo, lo+cap)
+    int lo, W, cap;
+    __device__ __forceinline__ float2 kp(int w) const { return w < cap ? skp[w] : gkp[lo + w]; }
+    __device__ __forceinline__ int idx(int w) const { return w < cap ? sidx[w] : gidx[lo + w]; }
+};
+
+struct QueryResult { int idx; int dist; double bd1, bd2; };
+
+template <bool GENERAL>
+__device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int j, const Window& win,
+                            float2 kp0, bool has0, uint2* queue, int lane, int dlen,
+                            unsigned long long& scored, QueryResult& out) {
+    const float2 q = P.q.skp[j];
     const float qx = q.x, qy = q.y;
     const float radius = mp.radius;
-    // Q1 (src/viso.cpp:693): the walk stops at target index 0, i.e. everything
-    // at or behind key(0) = (d0, 0) is cut: dist < d0 strictly.
+    // Q1 (src/viso.cpp:693): the walk stops at target index 0: everything at or
+    // behind key(0) = (d0, 0) is cut, i.e. dist < d0 strictly.
     float d0cut = __builtin_huge_valf();
-    if (n2 > 0) {
-        const float d0 = l1_kp(qx, qy, P.kp2[0]);
+    if (has0) {
+        const float d0 = l1_kp(qx, qy, kp0);
         if (d0 <= radius) d0cut = d0;
     }
-    // ---- phase A: scan, queue the in-radius candidates
+    // ---- phase A: scan the window, queue the in-radius candidates
     int cnt = 0;
-    for (int base = 0; base < n2; base += VISO_WAVE) {
-        const int t = base + lane;
+    for (int base = 0; base < win.W; base += VISO_WAVE) {
+        const int w = base + lane;
         bool in = false;
         float d = 0.f;
-        if (t < n2) {
-            d = l1_kp(qx, qy, kp.at(t));
+        if (w < win.W) {
+            d = l1_kp(qx, qy, win.kp(w));
             in = (d <= radius) && (d < d0cut);
         }
         const unsigned long long m = __ballot(in);
         if (m) {
-            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in && pos < VISO_QCAP) queue[pos] = make_uint2((uint32_t)t, __float_as_uint(d));
+            const int pos = cnt + mbcnt(m);
+            if (in && pos < VISO_QCAP) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));
             cnt += __popcll(m);
         }
     }
     const int K = mp.K;
     const double* F = mp.F;
+    ScorerU16 su;
+    ScorerF32 sf;
+    TrackU tu;
+    TrackD td;
+    if constexpr (GENERAL) { sf.begin(P, P.q.sidx[j], lane, dlen); td.init(); }
+    else { su.begin(P, j, lane); tu.init(); }
+    bool exact_done = false;
     if (cnt <= K && cnt <= VISO_QCAP) {
-        // ---- fast path: whole candidate set is in the queue
+        // ---- fast path: the whole candidate set is in the queue
         int n = cnt;
         if (mp.epi) {
-            int w = 0;
+            int wr = 0;
             for (int b = 0; b < n; b += VISO_WAVE) {
-                const int j = b + lane;
+                const int k = b + lane;
                 bool pass = false;
                 uint2 e = make_uint2(0, 0);
-                if (j < n) {
-                    e = queue[j];
-                    const float2 t2 = kp.at((int)e.x);
+                if (k < n) {
+                    e = queue[k];
+                    const float2 t2 = win.kp((int)e.x - win.lo);
                     const double s = sampson_dev(F, qx, qy, t2.x, t2.y);
                     pass = isfinite(s) && !(s > mp.sampson_thresh);
                 }
                 const unsigned long long m = __ballot(pass);
-                const int pos = w + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const int pos = wr + mbcnt(m);
                 __builtin_amdgcn_wave_barrier();
-                if (pass) queue[pos] = e;   // pos <= j: in-place compaction is safe
-                w += __popcll(m);
+                if (pass) queue[pos] = e;   // pos <= k: in-place compaction is safe
+                wr += __popcll(m);
             }
-            n = w;
+            n = wr;
         }
         __builtin_amdgcn_wave_barrier();
-        if (n > 0) sc.score(queue, n);
         scored += (unsigned long long)n;
-        return;
-    }
-    // ---- slow path (dense clusters): apply the K cap, then stream in batches
-    uint32_t tkd = 0xffffffffu, tki = 0xffffffffu;   // threshold key (exclusive)
-    if (cnt > K) {
-        // key_K = largest v with |{key < v}| <= K, built bit by bit (64-bit key)
-        unsigned long long v = 0;
-        for (int bit = 63; bit >= 0; --bit) {
-            const unsigned long long trial = v | (1ull << bit);
-            const int c = count_below(kp, n2, qx, qy, radius, d0cut, (uint32_t)(trial >> 32),
-                                      (uint32_t)trial, lane);
-            if (c <= K) v = trial;
-        }
-        tkd = (uint32_t)(v >> 32); tki = (uint32_t)v;
-    }
-    int qn = 0;
-    for (int base = 0; base < n2; base += VISO_WAVE) {
-        const int t = base + lane;
-        bool in = false;
-        float d = 0.f;
-        if (t < n2) {
-            const float2 t2 = kp.at(t);
-            d = l1_kp(qx, qy, t2);
-            in = (d <= radius) && (d < d0cut) && key_less(__float_as_uint(d), (uint32_t)t, tkd, tki);
-            if (in && mp.epi) {
-                const double s = sampson_dev(F, qx, qy, t2.x, t2.y);
-                in = isfinite(s) && !(s > mp.sampson_thresh);
+        if constexpr (GENERAL) {
+            if (n > 0) sf.score(queue, n, td);
+        } else {
+            TrackT tt;
+            tt.init();
+            if (n > 0) su.score_fast(queue, n, tt);
+            merge_groups(tt);
+            if (tt.tie) {
+                su.score_exact(queue, n, tu);   // rare: equal minimal SADs -> largest key wins
+                exact_done = true;
+            } else {
+                out.idx = tt.d1 != 0xffffffffu ? P.t.sidx[tt.bp] : -1;
+                out.dist = (int)tt.d1;
+                out.bd1 = (double)tt.d1;
+                out.bd2 = tt.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tt.d2;
+                return;
             }
         }
-        const unsigned long long m = __ballot(in);
-        const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (in) queue[pos] = make_uint2((uint32_t)t, __float_as_uint(d));   // qn < 64 => pos < 128
-        qn += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= VISO_WAVE) {
-            sc.score(queue, VISO_WAVE);
-            scored += VISO_WAVE;
-            const int rest = qn - VISO_WAVE;
-            uint2 mv = make_uint2(0, 0);
-            if (lane < rest) mv = queue[VISO_WAVE + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < rest) queue[lane] = mv;
-            __builtin_amdgcn_wave_barrier();
-            qn = rest;
+    } else {
+        // ---- slow path (dense clusters): apply the K cap, then stream in batches
+        uint32_t tkd = 0xffffffffu, tki = 0xffffffffu;   // threshold key (exclusive)
+        if (cnt > K) {
+            // key_K = largest v with |{key < v}| <= K, built bit by bit (64-bit key)
+            unsigned long long v = 0;
+            for (int bit = 63; bit >= 0; --bit) {
+                const unsigned long long trial = v | (1ull << bit);
+                const uint32_t kd = (uint32_t)(trial >> 32), ki = (uint32_t)trial;
+                int c = 0;
+                for (int base = 0; base < win.W; base += VISO_WAVE) {
+                    const int w = base + lane;
+                    bool in = false;
+                    if (w < win.W) {
+                        const float d = l1_kp(qx, qy, win.kp(w));
+                        in = (d <= radius) && (d < d0cut) &&
+                             key_less(__float_as_uint(d), (uint32_t)win.idx(w), kd, ki);
+                    }
+                    c += __popcll(__ballot(in));
+                }
+                if (c <= K) v = trial;
+            }
+            tkd = (uint32_t)(v >> 32); tki = (uint32_t)v;
         }
+        int qn = 0;
+        for (int base = 0; base < win.W; base += VISO_WAVE) {
+            const int w = base + lane;
+            bool in = false;
+            float d = 0.f;
+            if (w < win.W) {
+                const float2 t2 = win.kp(w);
+                d = l1_kp(qx, qy, t2);
+                in = (d <= radius) && (d < d0cut) &&
+                     key_less(__float_as_uint(d), (uint32_t)win.idx(w), tkd, tki);
+                if (in && mp.epi) {
+                    const double s = sampson_dev(F, qx, qy, t2.x, t2.y);
+                    in = isfinite(s) && !(s > mp.sampson_thresh);
+                }
+            }
+            const unsigned long long m = __ballot(in);
+            const int pos = qn + mbcnt(m);
+            if (in) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));   // qn < 64 => pos < 128
+            qn += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= VISO_WAVE) {
+                if constexpr (GENERAL) sf.score(queue, VISO_WAVE, td); else su.score_exact(queue, VISO_WAVE, tu);
+                scored += VISO_WAVE;
+                const int rest = qn - VISO_WAVE;
+                uint2 mv = make_uint2(0, 0);
+                if (lane < rest) mv = queue[VISO_WAVE + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < rest) queue[lane] = mv;
+                __builtin_amdgcn_wave_barrier();
+                qn = rest;
+            }
+        }
+        if (qn > 0) {
+            if constexpr (GENERAL) sf.score(queue, qn, td); else su.score_exact(queue, qn, tu);
+            scored += (unsigned long long)qn;
+        }
+        exact_done = true;
     }
-    if (qn > 0) {
-        sc.score(queue, qn);
-        scored += (unsigned long long)qn;
+    if constexpr (GENERAL) {
+        merge_lanes(td);
+        out.idx = td.any ? (int)td.ki : -1;
+        // Vec3i(i, idx, double): conversion truncates; saturate instead of UB
+        const double c = td.d1 > 2147483647.0 ? 2147483647.0 : td.d1;
+        out.dist = td.any ? (int)c : 0;
+        out.bd1 = td.d1; out.bd2 = td.d2;
+    } else {
+        (void)exact_done;
+        merge_groups(tu);
+        out.idx = tu.d1 != 0xffffffffu ? (int)tu.ki : -1;
+        out.dist = (int)tu.d1;
+        out.bd1 = (double)tu.d1;
+        out.bd2 = tu.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tu.d2;
     }
 }
 
-// blockIdx -> (problem, query block).  Blocks b and b+8 share an XCD (round
-// robin dispatch; speed only), so problem = f(b % 8, b / 8): all query blocks of
-// one problem run on one XCD and re-read its target rows from that XCD's L2.
+// blockIdx -> (problem, query tile).  Blocks b and b+8 share an XCD (round
+// robin dispatch; speed only), so problem = f(b % 8, b / 8): all tiles of one
+// problem run on one XCD and re-read its target rows from that XCD's L2.
 __device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int& prob, int& qblk) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -420,14 +601,19 @@ __device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int& prob
 
 struct MatchArgs {
     const MatchProblem* probs;
-    int n_probs, bpp, dlen, kp_lds;   // kp_lds: target keypoints the LDS staging area holds
+    int n_probs, bpp, dlen, _pad;
     const int* bad;
     MatchParamsDev mp[2];
 };
 
+#define VISO_MATCH_WAVES (VISO_MATCH_THREADS / VISO_WAVE)
+
 template <bool GENERAL>
 __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
+    __shared__ float2 s_kp[VISO_KPCAP];
+    __shared__ int s_idx[VISO_KPCAP];
+    __shared__ float s_xr[2];
     // the pack kernel decides which variant does the work (no host round trip)
     const bool is_bad = *a.bad != 0;
     if (is_bad != GENERAL) return;
@@ -435,48 +621,64 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) 
     block_to_problem(a.n_probs, a.bpp, prob, qblk);
     if (prob < 0) return;
     const MatchProblem P = a.probs[prob];
-    const int n1 = *P.n1p, n2 = *P.n2p;
+    const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * VISO_QPB;
     if (q0 >= n1) return;
+    const int q1 = min(q0 + VISO_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint2* queue = reinterpret_cast<uint2*>(smem) + wave * VISO_QCAP;
-    float2* skp = reinterpret_cast<float2*>(smem + (VISO_MATCH_THREADS / VISO_WAVE) * VISO_QCAP * sizeof(uint2));
-    const bool staged = n2 <= a.kp_lds;
-    if (staged) {
-        for (int t = threadIdx.x; t < n2; t += VISO_MATCH_THREADS) skp[t] = P.kp2[t];
-        __syncthreads();
-    }
-    unsigned long long scored = 0;
-    const int q1 = min(q0 + VISO_QPB, n1);
-    for (int i = q0 + wave; i < q1; i += VISO_MATCH_THREADS / VISO_WAVE) {
-        int idx, dist;
-        double bd1, bd2;
-        if constexpr (GENERAL) {
-            ScorerF32 sc;
-            sc.begin(P, i, lane, a.dlen);
-            if (staged) { KpSrc<true> kp{P.kp2, skp}; match_query(P, mp, i, n2, kp, queue, sc, lane, scored); }
-            else { KpSrc<false> kp{P.kp2, skp}; match_query(P, mp, i, n2, kp, queue, sc, lane, scored); }
-            sc.finish(idx, dist, bd1, bd2);
-        } else {
-            ScorerU16 sc;
-            sc.begin(P, i, lane);
-            if (staged) { KpSrc<true> kp{P.kp2, skp}; match_query(P, mp, i, n2, kp, queue, sc, lane, scored); }
-            else { KpSrc<false> kp{P.kp2, skp}; match_query(P, mp, i, n2, kp, queue, sc, lane, scored); }
-            sc.finish(idx, dist, bd1, bd2);
+    // x range of the tile (queries are x-sorted; NaNs sort last and are ignored)
+    if (wave == 0) {
+        float x = (q0 + lane < q1) ? P.q.skp[q0 + lane].x : __builtin_nanf("");
+        float mn = x, mx = x;
+#pragma unroll
+        for (int m = 1; m < VISO_WAVE; m <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, m));
+            mx = fmaxf(mx, __shfl_xor(mx, m));
         }
+        if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
+    }
+    __syncthreads();
+    Window win;
+    win.gkp = P.t.skp; win.gidx = P.t.sidx; win.skp = s_kp; win.sidx = s_idx;
+    win.lo = 0; win.W = 0; win.cap = 0;
+    const float xa = s_xr[0], xb = s_xr[1];
+    if (n2 > 0 && xa == xa) {
+        const float r = mp.radius;
+        const float slack = (fabsf(xa) + fabsf(xb) + fabsf(r)) * 1e-6f + 1e-6f;
+        const float x0 = P.t.xinfo[0], scale = P.t.xinfo[1];
+        if (r >= 0.f) {
+            const int blo = bucket_of(xa - r - slack, x0, scale);
+            const int bhi = bucket_of(xb + r + slack, x0, scale);
+            win.lo = P.t.bstart[blo];
+            win.W = P.t.bstart[bhi + 1] - win.lo;
+        }
+    }
+    win.cap = min(win.W, VISO_KPCAP);
+    for (int w = threadIdx.x; w < win.cap; w += VISO_MATCH_THREADS) {
+        s_kp[w] = P.t.skp[win.lo + w];
+        s_idx[w] = P.t.sidx[win.lo + w];
+    }
+    float2 kp0 = make_float2(0.f, 0.f);
+    const bool has0 = n2 > 0;
+    if (has0) kp0 = P.t.skp[P.t.rank[0]];
+    __syncthreads();
+    unsigned long long scored = 0;
+    for (int j = q0 + wave; j < q1; j += VISO_MATCH_WAVES) {
+        QueryResult r;
+        match_query<GENERAL>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
         if (lane == 0) {
-            bool accept = idx >= 0;
+            bool accept = r.idx >= 0;
             // src/viso.cpp:713-716 — ratio test in double (Q3)
-            if (accept && mp.second) accept = bd1 < bd2 * mp.ratio;
-            P.res[i] = make_int2(accept ? idx : -1, dist);
+            if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
+            P.res[P.q.sidx[j]] = make_int2(accept ? r.idx : -1, r.dist);
         }
     }
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad,
+                       int dlen, const MatchParamsDev mp[2], const int* bad,
                        hipEvent_t e0, hipEvent_t e1) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
@@ -484,31 +686,25 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     a.n_probs = n_probs;
     a.bpp = (cap_max + VISO_QPB - 1) / VISO_QPB;
     a.dlen = dlen;
+    a._pad = 0;
     a.bad = bad;
     a.mp[0] = mp[0];
     a.mp[1] = mp[1];
     const int groups = (n_probs + 7) / 8;
     const long long blocks = (long long)groups * 8 * a.bpp;
     if (blocks > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
-    const int staged = n2_max <= VISO_KP_LDS_MAX ? n2_max : 0;
-    a.kp_lds = staged;
-    const size_t lds = (VISO_MATCH_THREADS / VISO_WAVE) * VISO_QCAP * sizeof(uint2) + (size_t)staged * sizeof(float2);
-    if (lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void*)match_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)match_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
     if (e0) HIP_TRY(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(match_kernel<false>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), lds, s, a);
+    hipLaunchKernelGGL(match_kernel<false>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, s));
-    hipLaunchKernelGGL(match_kernel<true>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), lds, s, a);
+    hipLaunchKernelGGL(match_kernel<true>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
 
-int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                 int n2_max, int dlen, const MatchParamsDev mp[2], const int* bad) {
-    return launch_match_timed(s, probs_dev, n_probs, cap_max, n2_max, dlen, mp, bad, nullptr, nullptr);
+int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
+                 const MatchParamsDev mp[2], const int* bad) {
+    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr);
 }
 
 extern "C" const char* viso_matcher_kernel_name(void) { return "match_kernel<false>"; }
@@ -520,7 +716,6 @@ extern "C" const char* viso_matcher_kernel_name(void) { return "match_kernel<fal
 // is also the compaction.  Also emits pos[i1] (row of query i1, or -1) for the
 // circle join, and the match count.
 #define VISO_SORT_THREADS 512
-#define VISO_SORT_MAX 16384
 
 __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const MatchProblem* probs,
                                                                          int n_probs, int npad_alloc) {
@@ -529,7 +724,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     const int prob = blockIdx.x;
     if (prob >= n_probs) return;
     const MatchProblem P = probs[prob];
-    const int n1 = *P.n1p;
+    const int n1 = *P.q.n;
     int npad = 64;
     while (npad < n1) npad <<= 1;
     for (int i = threadIdx.x; i < npad; i += VISO_SORT_THREADS) {
