@@ -23,7 +23,7 @@ struct viso_batch {
     float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
-    int2* res; int* sorted; int* pos; int* m_cnt; unsigned long long* scored;
+    int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored;
     double *x, *X, *x_c, *Xp_c;
     TriItem* tri; JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
@@ -57,7 +57,7 @@ extern "C" void viso_batch_destroy(viso_batch* b) {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+    void* ptrs[] = {b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
@@ -87,7 +87,7 @@ static int build_items(viso_batch* b) {
     }
     HIP_TRY(hipMemcpy(b->views, V.data(), sizeof(ImageView) * V.size(), hipMemcpyHostToDevice));
     std::vector<MatchProblem> P((size_t)b->n_probs);
-    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
+    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.ovf = b->pos; p.ovf_cnt = b->zero + 4; p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
     auto img_kp = [&](int t, int side) { return b->kp + ((size_t)t * 2 + side) * kpi; };
     for (int t = 0; t < nf; ++t) {
         for (int which = 0; which < 3; ++which) {
@@ -102,6 +102,7 @@ static int build_items(viso_batch* b) {
             const size_t o = (size_t)which * nf + t;
             p.res = b->res + o * cap; p.sorted = b->sorted + o * cap * 3; p.pos = b->pos + o * cap;
             p.m_cnt = b->m_cnt + o; p.scored = b->scored + o;
+            p.ovf = p.pos; p.ovf_cnt = b->ovf_cnt + o;   // pos is rewritten by the final sort
             p.pidx = which == 0 ? 0 : 1; p.cap = cap;
         }
     }
@@ -167,7 +168,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
-    A(dalloc(&b->m_cnt, 3 * nf)); A(dalloc(&b->scored, 3 * nf));
+    A(dalloc(&b->m_cnt, 3 * nf)); A(dalloc(&b->scored, 3 * nf)); A(dalloc(&b->ovf_cnt, 3 * nf));
     A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
     A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
@@ -242,6 +243,7 @@ extern "C" int viso_batch_run_matcher(viso_batch* b) {
     hipStream_t s = b->ctx->stream;
     HIP_TRY(hipMemsetAsync(b->bad, 0, sizeof(int), s));
     HIP_TRY(hipMemsetAsync(b->scored, 0, sizeof(unsigned long long) * 3 * (size_t)b->nf, s));
+    HIP_TRY(hipMemsetAsync(b->ovf_cnt, 0, sizeof(int) * 3 * (size_t)b->nf, s));
     int r;
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
     if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;

@@ -55,6 +55,8 @@ struct MatchProblem {            // one match_desc call (reference src/viso.cpp:
     int* pos;                    // out: per query, row in `sorted` or -1
     int* m_cnt;                  // out: M
     unsigned long long* scored;  // out: number of SAD evaluations (C of SURVEY 8(d))
+    int* ovf;                    // scratch: sorted positions of queries left to the overflow kernel
+    int* ovf_cnt;                // scratch: their count (zeroed before every run)
     int pidx;                    // 0 = stereo params, 1 = temporal params
     int cap;                     // row capacity of res/sorted/pos
 };

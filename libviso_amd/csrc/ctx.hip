@@ -155,6 +155,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     P.t = view(daux + aux_bytes((size_t)n1), n2a, dk2, df2, dmisc + 1, du2);
     P.res = dres; P.sorted = dsorted; P.pos = dpos;
     P.m_cnt = dmisc + 3; P.scored = (unsigned long long*)(dmisc + 4); P.pidx = 0; P.cap = n1;
+    P.ovf = dpos; P.ovf_cnt = dmisc + 6;   // pos is written by the final sort, after the overflow pass
     struct { MatchProblem p; ImageView v[2]; } up;
     up.p = P; up.v[0] = P.q; up.v[1] = P.t;
     HIP_TRY(hipMemcpyAsync(dprob, &up, sizeof(up), hipMemcpyHostToDevice, s));

@@ -426,8 +426,11 @@ struct Window {
 
 struct QueryResult { int idx; int dist; double bd1, bd2; };
 
-template <bool GENERAL>
-__device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int j, const Window& win,
+// SLOW = false: the tile kernel's path; returns false (nothing scored) when the
+// candidate set needs the K cap or does not fit the queue — the query is then
+// handed to the overflow kernel, which runs the SLOW = true instantiation.
+template <bool GENERAL, bool SLOW>
+__device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int j, const Window& win,
                             float2 kp0, bool has0, uint2* queue, int lane, int dlen,
                             unsigned long long& scored, QueryResult& out) {
     const float2 q = P.q.skp[j];
@@ -453,7 +456,7 @@ __device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int
         const unsigned long long m = __ballot(in);
         if (m) {
             const int pos = cnt + mbcnt(m);
-            if (in && pos < VISO_QCAP) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));
+            if (!SLOW && in && pos < VISO_QCAP) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));
             cnt += __popcll(m);
         }
     }
@@ -465,8 +468,8 @@ __device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int
     TrackD td;
     if constexpr (GENERAL) { sf.begin(P, P.q.sidx[j], lane, dlen); td.init(); }
     else { su.begin(P, j, lane); tu.init(); }
-    bool exact_done = false;
-    if (cnt <= K && cnt <= VISO_QCAP) {
+    if constexpr (!SLOW) {
+        if (cnt > K || cnt > VISO_QCAP) return false;
         // ---- fast path: the whole candidate set is in the queue
         int n = cnt;
         if (mp.epi) {
@@ -500,13 +503,12 @@ __device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int
             merge_groups(tt);
             if (tt.tie) {
                 su.score_exact(queue, n, tu);   // rare: equal minimal SADs -> largest key wins
-                exact_done = true;
             } else {
                 out.idx = tt.d1 != 0xffffffffu ? P.t.sidx[tt.bp] : -1;
                 out.dist = (int)tt.d1;
                 out.bd1 = (double)tt.d1;
                 out.bd2 = tt.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tt.d2;
-                return;
+                return true;
             }
         }
     } else {
@@ -569,7 +571,6 @@ __device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int
             if constexpr (GENERAL) sf.score(queue, qn, td); else su.score_exact(queue, qn, tu);
             scored += (unsigned long long)qn;
         }
-        exact_done = true;
     }
     if constexpr (GENERAL) {
         merge_lanes(td);
@@ -579,13 +580,13 @@ __device__ void match_query(const MatchProblem& P, const MatchParamsDev& mp, int
         out.dist = td.any ? (int)c : 0;
         out.bd1 = td.d1; out.bd2 = td.d2;
     } else {
-        (void)exact_done;
         merge_groups(tu);
         out.idx = tu.d1 != 0xffffffffu ? (int)tu.ki : -1;
         out.dist = (int)tu.d1;
         out.bd1 = (double)tu.d1;
         out.bd2 = tu.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tu.d2;
     }
+    return true;
 }
 
 // blockIdx -> (problem, query tile).  Blocks b and b+8 share an XCD (round
@@ -666,10 +667,52 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) 
     unsigned long long scored = 0;
     for (int j = q0 + wave; j < q1; j += VISO_MATCH_WAVES) {
         QueryResult r;
-        match_query<GENERAL>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
+        const bool done = match_query<GENERAL, false>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
+        if (lane == 0) {
+            if (done) {
+                bool accept = r.idx >= 0;
+                // src/viso.cpp:713-716 — ratio test in double (Q3)
+                if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
+                P.res[P.q.sidx[j]] = make_int2(accept ? r.idx : -1, r.dist);
+            } else {
+                P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // dense cluster: overflow kernel
+            }
+        }
+    }
+    if (lane == 0 && scored) atomicAdd(P.scored, scored);
+}
+
+// Queries whose in-radius set exceeds K or the LDS queue (dense keypoint
+// clusters): exact K-cap selection + streaming, reading the window from global
+// memory.  A few waves per problem; empty for ordinary data.
+#define VISO_OVF_BLOCKS 4
+
+template <bool GENERAL>
+__global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(MatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
+    const bool is_bad = *a.bad != 0;
+    if (is_bad != GENERAL) return;
+    const int prob = blockIdx.x / VISO_OVF_BLOCKS, sub = blockIdx.x % VISO_OVF_BLOCKS;
+    if (prob >= a.n_probs) return;
+    const MatchProblem P = a.probs[prob];
+    const int n_ovf = *P.ovf_cnt;
+    if (n_ovf == 0) return;
+    const int n2 = *P.t.n;
+    const MatchParamsDev& mp = a.mp[P.pidx];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 kp0 = make_float2(0.f, 0.f);
+    const bool has0 = n2 > 0;
+    if (has0) kp0 = P.t.skp[P.t.rank[0]];
+    unsigned long long scored = 0;
+    for (int k = sub * VISO_MATCH_WAVES + wave; k < n_ovf; k += VISO_OVF_BLOCKS * VISO_MATCH_WAVES) {
+        const int j = P.ovf[k];
+        Window win;
+        win.gkp = P.t.skp; win.gidx = P.t.sidx; win.skp = nullptr; win.sidx = nullptr;
+        win.lo = 0; win.W = n2; win.cap = 0;   // whole image, global reads
+        QueryResult r;
+        match_query<GENERAL, true>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
         if (lane == 0) {
             bool accept = r.idx >= 0;
-            // src/viso.cpp:713-716 — ratio test in double (Q3)
             if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
             P.res[P.q.sidx[j]] = make_int2(accept ? r.idx : -1, r.dist);
         }
@@ -698,6 +741,10 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, s));
     hipLaunchKernelGGL(match_kernel<true>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(match_overflow_kernel<true>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
