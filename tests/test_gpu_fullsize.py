@@ -1,0 +1,93 @@
+"""BASELINE.json sizes: configs[1]/[2] (1241x376, 2000 kp) and configs[4]
+(2048x1024, 8000 kp) against the oracle on a few frames, plus
+size-independent properties over a whole bench-sized batch."""
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_batch(seq, seed=3, full=True):
+    nf, _, cap, _ = seq["kp"].shape
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, cap)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.set_params(st, tm, seq["param"], seed=seed)
+    (b.run if full else b.run_matcher)()
+    return ctx, b, st, tm
+
+
+def _per_call(oracle, seq, which, t, st, tm):
+    n = seq["n"]
+    q = (0, t) if which < 2 else (1, t)
+    tg = (1, t) if which == 0 else ((0, t - 1) if which == 1 else (1, t - 1))
+    nq, nt = n[q[1], q[0]], n[tg[1], tg[0]]
+    return oracle.match_desc(seq["kp"][q[1], q[0], :nq], seq["kp"][tg[1], tg[0], :nt],
+                             seq["desc"][q[1], q[0], :nq], seq["desc"][tg[1], tg[0], :nt],
+                             st if which == 0 else tm, return_scored=True)
+
+
+def test_config2_3_full_size_vs_oracle(viso, oracle):
+    seq = synth.make_sequence(101, 3, n_kp=2000)              # 1241x376, 2000 features/image
+    ctx, b, st, tm = _run_batch(seq)
+    sc, mo = b.counters()
+    for t in range(3):
+        for which in range(3 if t else 1):
+            want, wsc = _per_call(oracle, seq, which, t, st, tm)
+            assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc
+    want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=3)
+    tr, ok, n_inl = b.poses()
+    assert np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"]) and ok[1:].all()
+    for t in (1, 2):
+        a, r = libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])
+        assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-5
+    # ~50 candidates per temporal query, ~3 per stereo query
+    assert 35 < sc[1, 1] / 2000 < 65 and 1.5 < sc[0, 1] / 2000 < 5
+    b.close(); ctx.close()
+
+
+def test_config5_stress_size_vs_oracle(viso, oracle):
+    seq = synth.make_sequence(102, 2, n_kp=8000, width=2048, height=1024)
+    ctx, b, st, tm = _run_batch(seq, full=False)
+    sc, _ = b.counters()
+    for which, t in ((0, 0), (0, 1), (1, 1), (2, 1)):
+        want, wsc = _per_call(oracle, seq, which, t, st, tm)
+        assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc
+    b.close(); ctx.close()
+
+
+def test_bench_sized_batch_properties(viso):
+    """64 frame pairs of the bench workload: properties that need no oracle."""
+    seq = synth.make_sequence(103, 65, n_kp=2000)
+    ctx, b, st, tm = _run_batch(seq, full=True)
+    tr1, ok1, ni1 = b.poses()
+    first = [b.matches(w, t) for t in (1, 17, 64) for w in range(3)]
+    b.run()                                                     # idempotent / deterministic
+    tr2, ok2, ni2 = b.poses()
+    assert np.array_equal(tr1, tr2) and np.array_equal(ok1, ok2) and np.array_equal(ni1, ni2)
+    again = [b.matches(w, t) for t in (1, 17, 64) for w in range(3)]
+    assert all(np.array_equal(x, y) for x, y in zip(first, again))
+    assert ok1[1:].all() and np.abs(tr1[1:] - seq["tr_gt"][1:]).max() < 3e-2
+    kp, desc, n = seq["kp"], seq["desc"], seq["n"]
+    for t in (1, 17, 64):
+        for which in range(3):
+            m = b.matches(which, t)
+            q = (0, t) if which < 2 else (1, t)
+            tg = (1, t) if which == 0 else ((0, t - 1) if which == 1 else (1, t - 1))
+            # sorted by (dist, i1); one match per query; indices in range; target 0 never matched (Q1)
+            key = m[:, 2].astype(np.int64) * 10000 + m[:, 0]
+            assert np.all(np.diff(key) > 0) and len(np.unique(m[:, 0])) == len(m)
+            assert m[:, 0].max() < n[q[1], q[0]] and 0 < m[:, 1].min() and m[:, 1].max() < n[tg[1], tg[0]]
+            # reported distance is the SAD of the reported pair, within the L1 radius
+            dq, dt = desc[q[1], q[0]][m[:, 0]], desc[tg[1], tg[0]][m[:, 1]]
+            assert np.array_equal(np.abs(dq - dt).sum(1).astype(np.int32), m[:, 2])
+            kq, kt = kp[q[1], q[0]][m[:, 0]], kp[tg[1], tg[0]][m[:, 1]]
+            assert np.abs(kq - kt).sum(1).max() <= 80
+            if which == 0:
+                assert np.abs(kq[:, 1] - kt[:, 1]).max() <= 1      # rectified epipolar gate == |dy| <= 1
+    b.close(); ctx.close()
