@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--matcher", type=int, default=0, help="0 = L2-gather kernel (default, faster), 1 = LDS tile kernel")
+    ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,6 +81,7 @@ def main():
     from libviso_amd import synth
     from libviso_amd.abi import MatchParams
 
+    libviso_amd.set_matcher_variant(args.matcher)
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
     seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
@@ -123,6 +126,23 @@ def main():
     scored, m_out = batch.counters()
     balg = b_alg_bytes(seq["n"], scored, m_out)
     achieved = balg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    ab = None
+    if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
+        rounds = {0: [], 1: []}
+        for _ in range(5):
+            for v in (0, 1):
+                libviso_amd.set_matcher_variant(v)
+                batch.kernel_timing(True)
+                for _ in range(4):
+                    batch.run_matcher()
+                rounds[v].append(batch.kernel_ms()[0])
+                batch.kernel_timing(False)
+        libviso_amd.set_matcher_variant(args.matcher)
+        ab = {"kernel_ms_median": {"match_kernel<false>": float(np.median(rounds[0])),
+                                   "match_tile_kernel": float(np.median(rounds[1]))},
+              "kernel_ms_min": {"match_kernel<false>": float(np.min(rounds[0])),
+                                "match_tile_kernel": float(np.min(rounds[1]))}}
 
     # ---- configs[2]: end to end (matcher + circle + RANSAC/GN) ---------------
     e2e = None
@@ -183,6 +203,7 @@ def main():
                                  "a tiled kernel serves most of them from L2/LDS, so this is effective bandwidth"},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "matcher_ab": ab,
         }
         print(json.dumps(line), flush=True)
     batch.close()

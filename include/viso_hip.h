@@ -209,6 +209,9 @@ int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out);
  * its average duration in ms over the launches since the last reset, measured
  * with hipEvents on the context's stream. */
 const char* viso_matcher_kernel_name(void);
+/* Tuning/debug: 0 (default) = L2-gather kernel, 1 = LDS-resident tile kernel.
+ * Identical results; lets bench.py time both in one process. */
+void viso_debug_set_matcher(int variant);
 int viso_batch_kernel_timing(viso_batch* b, int enable);
 int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches);
 

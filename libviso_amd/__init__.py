@@ -86,6 +86,8 @@ def load():
     L.viso_batch_get_counters.argtypes = [C.c_void_p, i64p, i64p]
     L.viso_batch_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.viso_batch_kernel_ms.argtypes = [C.c_void_p, f64p, intp]
+    L.viso_debug_set_matcher.argtypes = [C.c_int]
+    L.viso_debug_set_matcher.restype = None
     _lib = L
     return L
 
@@ -105,6 +107,11 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def set_matcher_variant(v):
+    """0 = L2-gather kernel (default), 1 = LDS-resident tile kernel; same results."""
+    load().viso_debug_set_matcher(int(v))
 
 
 # ------------------------------------------------------------ plain family

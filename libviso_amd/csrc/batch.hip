@@ -53,7 +53,7 @@ static void free_solver_bufs(viso_batch* b) {
     b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
 }
 
-extern "C" void viso_batch_destroy(viso_batch* b) {
+extern "C" void viso_batch_destroy(viso_batch* b) try {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -64,6 +64,7 @@ extern "C" void viso_batch_destroy(viso_batch* b) {
     for (void* p : ptrs) if (p) hipFree(p);
     free_solver_bufs(b);
     delete b;
+} catch (...) {   // the HIP runtime may already be gone at process exit
 }
 
 static int build_items(viso_batch* b) {

@@ -134,3 +134,5 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);
+int launch_match_tile(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
+                      const MatchParamsDev mp[2], const int* bad);

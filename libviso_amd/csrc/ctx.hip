@@ -42,12 +42,13 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     return c;
 }
 
-extern "C" void viso_ctx_destroy(viso_ctx* c) {
+extern "C" void viso_ctx_destroy(viso_ctx* c) try {
     if (!c) return;
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < 16; ++i) if (c->scratch[i]) hipFree(c->scratch[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
+} catch (...) {   // the HIP runtime may already be gone at process exit
 }
 
 extern "C" void* viso_ctx_stream(viso_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -22,6 +22,7 @@
 // minimal SAD with the LARGEST key.  No neighbour list is materialised, and the
 // order in which candidates are visited (here: x-sorted) is irrelevant.
 #include "common.h"
+#include "match_dev.h"
 
 #include <math.h>
 
@@ -39,38 +40,6 @@ __device__ __forceinline__ uint32_t row8_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ int mbcnt(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// cvflann::L1<float> over 2 elements: result = 0; result += |a0-b0|; result += |a1-b1|
-__device__ __forceinline__ float l1_kp(float qx, float qy, float2 t) {
-    float r = fabsf(qx - t.x);
-    r += fabsf(qy - t.y);
-    return r;
-}
-
-// sampsonDistance + algebricDistance, src/viso.cpp:655-666, 390-407 — same
-// operation order and the same float roundings (Q4).
-__device__ __forceinline__ double sampson_dev(const double* F, float p1x, float p1y, float p2x,
-                                              float p2y) {
-    double Fx0 = F[0] * p1x + F[1] * p1y + F[2];
-    double Fx1 = F[3] * p1x + F[4] * p1y + F[5];
-    double Ftx0 = F[0] * p2x + F[3] * p2y + F[6];
-    double Ftx1 = F[1] * p2x + F[4] * p2y + F[7];
-    float a0 = p1x, a1 = p1y, a2 = 1.f, b0 = p2x, b1 = p2y, b2 = 1.f;
-    double adv = b0 * F[0] * a0 + b0 * F[1] * a1 + b0 * F[2] * a2 + b1 * F[3] * a0 +
-                 b1 * F[4] * a1 + b1 * F[5] * a2 + b2 * F[6] * a0 + b2 * F[7] * a1 +
-                 b2 * F[8] * a2;
-    float ad = (float)adv;
-    float ad2 = ad * ad;
-    return ad2 / (Fx0 * Fx0 + Fx1 * Fx1 + Ftx0 * Ftx0 + Ftx1 * Ftx1);
-}
-
-__device__ __forceinline__ bool key_less(uint32_t ad, uint32_t ai, uint32_t bd, uint32_t bi) {
-    return ad < bd || (ad == bd && ai < bi);
-}
-
 // ------------------------------------------------------------------ x-sort
 // One workgroup per image.  Keys (sortable(x) << 32 | index) in LDS, bitonic
 // network; NaN x sorts last.  Also builds a 256-bucket column index so that a
@@ -81,12 +50,6 @@ __device__ __forceinline__ uint32_t sortable_f32(float x) {
     if (x != x) return 0xffffffffu;
     const uint32_t u = __float_as_uint(x);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__device__ __forceinline__ int bucket_of(float x, float x0, float scale) {
-    if (x != x) return VISO_NB - 1;
-    const float f = floorf((x - x0) * scale);
-    return f <= 0.f ? 0 : (f >= (float)(VISO_NB - 1) ? VISO_NB - 1 : (int)f);
 }
 
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img,
@@ -720,6 +683,16 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
+// 1 = match_tile_kernel (LDS-resident window, match_tile.hip), 0 = match_kernel<false> (L2 gathers).
+// Same results; kept switchable so the two can be timed against each other in one process.
+// Measured on MI355X (bench.py --ab, 769 problems/launch): gather kernel 1.385 ms, tile kernel
+// 1.77 ms — the gather kernel is the default; the tile kernel stays for dense-keypoint studies.
+static int g_matcher_variant = 0;
+extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = variant ? 1 : 0; }
+extern "C" const char* viso_matcher_kernel_name(void) {
+    return g_matcher_variant == 1 ? "match_tile_kernel" : "match_kernel<false>";
+}
+
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], const int* bad,
                        hipEvent_t e0, hipEvent_t e1) {
@@ -737,8 +710,13 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     const long long blocks = (long long)groups * 8 * a.bpp;
     if (blocks > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
     if (e0) HIP_TRY(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(match_kernel<false>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    if (g_matcher_variant == 1) {
+        const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
+        if (r < 0) return r;
+    } else {
+        hipLaunchKernelGGL(match_kernel<false>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     if (e1) HIP_TRY(hipEventRecord(e1, s));
     hipLaunchKernelGGL(match_kernel<true>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
@@ -754,7 +732,6 @@ int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int 
     return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr);
 }
 
-extern "C" const char* viso_matcher_kernel_name(void) { return "match_kernel<false>"; }
 
 // ------------------------------------------------------------------ sort
 // std::sort(match, by [2]) of src/viso.cpp:724 with the documented total order
