@@ -254,7 +254,7 @@ extern "C" int viso_batch_run_matcher(viso_batch* b) {
         HIP_TRY(hipEventCreate(&e1));
         b->events.push_back({e0, e1});
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad, e0, e1)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad, e0, e1, 1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     return VISO_OK;
 }

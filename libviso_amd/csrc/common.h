@@ -88,7 +88,7 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], const int* bad);
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1);
+                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1, int layout);
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);

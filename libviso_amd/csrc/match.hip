@@ -136,41 +136,50 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 }
 
 // ------------------------------------------------------------------ pack
-// One thread = 8 consecutive u16 of one row (a 16-B store).  Row j of the
-// packed image is the descriptor of keypoint sidx[j] (x-sorted order).
+// One wave = VISO_PACK_RPW consecutive ORIGINAL rows: lane l converts floats
+// 2l, 2l+1 of a boundary-layout row (one 8-B load; the wave streams the rows'
+// bytes linearly) into one packed dword and the wave writes the whole 256-B
+// row to its x-sorted position rank[i] (two full cache lines).  All loads of a
+// wave are independent and in flight together.
+#define VISO_PACK_RPW 8   // rows per wave
+
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
                                                         int cap, int dlen, int* __restrict__ bad) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)n_img * cap * (VISO_ROW / 8);
-    if (gid >= total) return;
-    const int chunk = (int)(gid % (VISO_ROW / 8));
-    const long long row = gid / (VISO_ROW / 8);
-    const int img = (int)(row / cap);
-    const int r = (int)(row % cap);
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long row0 = wave * VISO_PACK_RPW;
+    if (row0 >= (long long)n_img * cap) return;
+    const int img = (int)(row0 / cap);      // cap is a multiple of VISO_PACK_RPW: a wave never straddles images
     const ImageView I = imgs[img];
-    if (r >= *I.n) return;
-    const float* s = I.frows + (size_t)I.sidx[r] * dlen;
-    uint32_t w[4];
+    const int n = *I.n;
+    const int r0 = (int)(row0 % cap);
+    if (r0 >= n) return;
+    float2 v[VISO_PACK_RPW];
+    int dst[VISO_PACK_RPW];
+    const int c = 2 * lane;
+#pragma unroll
+    for (int k = 0; k < VISO_PACK_RPW; ++k) {
+        const int r = r0 + k;
+        v[k] = make_float2(0.f, 0.f);
+        dst[k] = -1;
+        if (r < n) {
+            dst[k] = I.rank[r];
+            const float* s = I.frows + (size_t)r * dlen;
+            if (c + 1 < dlen) { v[k].x = s[c]; v[k].y = s[c + 1]; }
+            else if (c < dlen) v[k].x = s[c];
+        }
+    }
     bool isbad = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t pair = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = chunk * 8 + 2 * k + h;
-            uint32_t u = VISO_BIAS;
-            if (c < dlen) {
-                const float v = s[c];
-                const float vr = rintf(v);
-                if (!(v == vr) || v < -32768.f || v > 32767.f) isbad = true;
-                else u = (uint32_t)((int)vr + VISO_BIAS);
-            }
-            pair |= (u & 0xffffu) << (16 * h);
-        }
-        w[k] = pair;
+    for (int k = 0; k < VISO_PACK_RPW; ++k) {
+        if (dst[k] < 0) continue;
+        const float a = v[k].x, b = v[k].y;
+        const float ar = rintf(a), br = rintf(b);
+        if (!(a == ar) || a < -32768.f || a > 32767.f || !(b == br) || b < -32768.f || b > 32767.f) isbad = true;
+        const uint32_t ua = (uint32_t)((int)ar + VISO_BIAS) & 0xffffu, ub = (uint32_t)((int)br + VISO_BIAS) & 0xffffu;
+        reinterpret_cast<uint32_t*>(I.rows + (size_t)dst[k] * VISO_ROW)[lane] = ua | (ub << 16);
     }
-    *reinterpret_cast<uint4*>(I.rows + (size_t)r * VISO_ROW + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-    if (isbad) atomicOr(bad, 1);
+    if (__any(isbad) && lane == 0) atomicOr(bad, 1);
 }
 
 int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad) {
@@ -179,10 +188,13 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
         HIP_TRY(hipMemcpyAsync(bad, &one, sizeof(int), hipMemcpyHostToDevice, s));
         return VISO_OK;
     }
-    const long long total = (long long)n_img * cap * (VISO_ROW / 8);
-    if (total == 0) return VISO_OK;
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, cap, dlen, bad);
+    // the kernel addresses rows as img * capp + r with capp a multiple of the rows per wave,
+    // so that a wave never straddles two images
+    const int capp = (cap + VISO_PACK_RPW - 1) / VISO_PACK_RPW * VISO_PACK_RPW;
+    const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
+    if (waves == 0) return VISO_OK;
+    const int blocks = (int)((waves + 3) / 4);
+    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -392,7 +404,7 @@ struct QueryResult { int idx; int dist; double bd1, bd2; };
 // SLOW = false: the tile kernel's path; returns false (nothing scored) when the
 // candidate set needs the K cap or does not fit the queue — the query is then
 // handed to the overflow kernel, which runs the SLOW = true instantiation.
-template <bool GENERAL, bool SLOW>
+template <bool GENERAL, bool SLOW, int EPI>
 __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int j, const Window& win,
                             float2 kp0, bool has0, uint2* queue, int lane, int dlen,
                             unsigned long long& scored, QueryResult& out) {
@@ -435,7 +447,7 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
         if (cnt > K || cnt > VISO_QCAP) return false;
         // ---- fast path: the whole candidate set is in the queue
         int n = cnt;
-        if (mp.epi) {
+        if (EPI < 0 ? (mp.epi != 0) : (EPI != 0)) {
             int wr = 0;
             for (int b = 0; b < n; b += VISO_WAVE) {
                 const int k = b + lane;
@@ -467,7 +479,7 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
             if (tt.tie) {
                 su.score_exact(queue, n, tu);   // rare: equal minimal SADs -> largest key wins
             } else {
-                out.idx = tt.d1 != 0xffffffffu ? P.t.sidx[tt.bp] : -1;
+                out.idx = tt.d1 != 0xffffffffu ? win.idx((int)tt.bp - win.lo) : -1;
                 out.dist = (int)tt.d1;
                 out.bd1 = (double)tt.d1;
                 out.bd2 = tt.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tt.d2;
@@ -555,25 +567,33 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
 // blockIdx -> (problem, query tile).  Blocks b and b+8 share an XCD (round
 // robin dispatch; speed only), so problem = f(b % 8, b / 8): all tiles of one
 // problem run on one XCD and re-read its target rows from that XCD's L2.
-__device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int& prob, int& qblk) {
+// Groups of 8 problems can be strided so that a launch only enumerates the
+// problems of one kind: group = (g / gc) * gs + gf + g % gc  (batches lay the
+// problems out as [8 stereo][8 temporal-left][8 temporal-right] per 8 frames).
+__device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int gs, int gf, int gc, int& prob, int& qblk) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    prob = (slot / bpp) * 8 + xcd;
+    const int g = slot / bpp;
+    prob = ((g / gc) * gs + gf + g % gc) * 8 + xcd;
     qblk = slot % bpp;
     if (prob >= n_probs) prob = -1;
 }
 
 struct MatchArgs {
     const MatchProblem* probs;
-    int n_probs, bpp, dlen, _pad;
+    int n_probs, bpp, dlen, gs, gf, gc;
     const int* bad;
     MatchParamsDev mp[2];
 };
 
 #define VISO_MATCH_WAVES (VISO_MATCH_THREADS / VISO_WAVE)
 
-template <bool GENERAL>
-__global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
+// EPI is a compile-time copy of MatchParams::enforce_epipolar: the temporal
+// instantiation carries no fp64 Sampson code and needs fewer registers (more
+// waves per SIMD to hide the L2 gather latency); each instantiation skips the
+// problems of the other kind.
+template <bool GENERAL, int EPI>
+__global__ __attribute__((amdgpu_waves_per_eu(7, 7))) __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
     __shared__ float2 s_kp[VISO_KPCAP];
     __shared__ int s_idx[VISO_KPCAP];
@@ -582,7 +602,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) 
     const bool is_bad = *a.bad != 0;
     if (is_bad != GENERAL) return;
     int prob, qblk;
-    block_to_problem(a.n_probs, a.bpp, prob, qblk);
+    block_to_problem(a.n_probs, a.bpp, a.gs, a.gf, a.gc, prob, qblk);
     if (prob < 0) return;
     const MatchProblem P = a.probs[prob];
     const int n1 = *P.q.n, n2 = *P.t.n;
@@ -590,6 +610,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) 
     if (q0 >= n1) return;
     const int q1 = min(q0 + VISO_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
+    if ((mp.epi != 0) != (EPI != 0)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // x range of the tile (queries are x-sorted; NaNs sort last and are ignored)
     if (wave == 0) {
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) 
     unsigned long long scored = 0;
     for (int j = q0 + wave; j < q1; j += VISO_MATCH_WAVES) {
         QueryResult r;
-        const bool done = match_query<GENERAL, false>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
+        const bool done = match_query<GENERAL, false, EPI>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
         if (lane == 0) {
             if (done) {
                 bool accept = r.idx >= 0;
@@ -673,7 +694,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
         win.gkp = P.t.skp; win.gidx = P.t.sidx; win.skp = nullptr; win.sidx = nullptr;
         win.lo = 0; win.W = n2; win.cap = 0;   // whole image, global reads
         QueryResult r;
-        match_query<GENERAL, true>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
+        match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
         if (lane == 0) {
             bool accept = r.idx >= 0;
             if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
@@ -690,19 +711,21 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 static int g_matcher_variant = 0;
 extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = variant ? 1 : 0; }
 extern "C" const char* viso_matcher_kernel_name(void) {
-    return g_matcher_variant == 1 ? "match_tile_kernel" : "match_kernel<false>";
+    return g_matcher_variant == 1 ? "match_tile_kernel" : "match_kernel<false, 0>";
 }
 
+// layout 0: problems in any order (both instantiations enumerate all of them);
+// layout 1: the batch order [8 stereo][8 temporal-left][8 temporal-right] per 8 frames.
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], const int* bad,
-                       hipEvent_t e0, hipEvent_t e1) {
+                       hipEvent_t e0, hipEvent_t e1, int layout) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
     a.bpp = (cap_max + VISO_QPB - 1) / VISO_QPB;
     a.dlen = dlen;
-    a._pad = 0;
+    a.gs = 1; a.gf = 0; a.gc = 1;
     a.bad = bad;
     a.mp[0] = mp[0];
     a.mp[1] = mp[1];
@@ -714,11 +737,25 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
         if (r < 0) return r;
     } else {
-        hipLaunchKernelGGL(match_kernel<false>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+        // the events bracket the temporal instantiation only: the dominant kernel
+        // (2/3 of the problems, ~97 % of the scored pairs)
+        MatchArgs at = a, as = a;   // temporal / stereo enumerations
+        long long bt = blocks, bs = blocks;
+        if (layout == 1) {
+            const int g3 = (groups + 2) / 3;
+            at.gs = 3; at.gf = 1; at.gc = 2; bt = (long long)g3 * 2 * 8 * a.bpp;
+            as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
+        }
+        hipLaunchKernelGGL((match_kernel<false, 0>), dim3((unsigned)bt), dim3(VISO_MATCH_THREADS), 0, s, at);
+        HIP_TRY(hipGetLastError());
+        if (e1) { HIP_TRY(hipEventRecord(e1, s)); e1 = nullptr; }
+        hipLaunchKernelGGL((match_kernel<false, 1>), dim3((unsigned)bs), dim3(VISO_MATCH_THREADS), 0, s, as);
         HIP_TRY(hipGetLastError());
     }
     if (e1) HIP_TRY(hipEventRecord(e1, s));
-    hipLaunchKernelGGL(match_kernel<true>, dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+    hipLaunchKernelGGL((match_kernel<true, 0>), dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((match_kernel<true, 1>), dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(match_overflow_kernel<false>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
@@ -729,7 +766,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
 
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], const int* bad) {
-    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr);
+    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0);
 }
 
 

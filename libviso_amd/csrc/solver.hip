@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
         bool valid = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
-        if (valid) ok = gn_serial(S.X, S.obs, S.ld, sample, 3, tr, a.sp);
+        if (valid) ok = gn_serial<3>(S.X, S.obs, S.ld, sample, tr, a.sp);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];

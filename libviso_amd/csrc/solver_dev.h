@@ -22,8 +22,10 @@ struct RotDev {
 __device__ __forceinline__ void make_rot(const double* tr, RotDev& R) {
     const double rx = tr[0], ry = tr[1], rz = tr[2];
     R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
-    const double sx = sin(rx), cx = cos(rx), sy = sin(ry);
-    const double cy = cos(ry), sz = sin(rz), cz = cos(rz);
+    double sx, cx, sy, cy, sz, cz;   // sincos shares the argument reduction of sin and cos
+    sincos(rx, &sx, &cx);
+    sincos(ry, &sy, &cy);
+    sincos(rz, &sz, &cz);
     R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
     R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
     R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
@@ -171,8 +173,9 @@ __device__ __forceinline__ void symmetrize(double A[6][6]) {
 // One thread runs the whole Gauss-Newton loop over `n` active points in the
 // reference's summation order (used for the 3-point RANSAC hypotheses: one
 // lane per hypothesis).  Returns 1 (converged) / 0; tr is in/out.
-__device__ inline int gn_serial(const double* X, const double* obs, int ld, const int* active,
-                                int n, double tr[6], const SolverParamsDev& sp) {
+template <int N>
+__device__ inline int gn_serial(const double* X, const double* obs, int ld, const int (&active)[N],
+                                double tr[6], const SolverParamsDev& sp) {
     for (int it = 0; it < 100; ++it) {
         RotDev R;
         make_rot(tr, R);
@@ -183,7 +186,8 @@ __device__ inline int gn_serial(const double* X, const double* obs, int ld, cons
 #pragma unroll
             for (int q = 0; q < 6; ++q) A[p][q] = 0;
         }
-        for (int i = 0; i < n; ++i) accumulate_point(R, sp, X, obs, ld, active[i], i, A, B);
+#pragma unroll
+        for (int i = 0; i < N; ++i) accumulate_point(R, sp, X, obs, ld, active[i], i, A, B);
         symmetrize(A);
         if (!lu_solve6(A, B)) return 0;           // src/viso.cpp:1602-1606
         bool converged = true;

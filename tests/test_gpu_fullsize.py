@@ -91,3 +91,28 @@ def test_bench_sized_batch_properties(viso):
             if which == 0:
                 assert np.abs(kq[:, 1] - kt[:, 1]).max() <= 1      # rectified epipolar gate == |dy| <= 1
     b.close(); ctx.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
+    """The L2-gather kernel (default) and the LDS-resident tile kernel must both
+    be bit-exact: ragged counts, duplicated patches (exact SAD ties -> overflow
+    kernel), dense clusters (K cap), and the 8000-keypoint chunked window."""
+    libviso_amd.set_matcher_variant(variant)
+    try:
+        seq = synth.make_sequence(104, 4, n_kp=900, width=300, height=120, ragged=True, dup_frac=0.1)
+        ctx, b, st, tm = _run_batch(seq, full=False)
+        sc, _ = b.counters()
+        for t in range(4):
+            for which in range(3 if t else 1):
+                want, wsc = _per_call(oracle, seq, which, t, st, tm)     # 900 kp in 300x120: > K in radius
+                assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc, (variant, which, t)
+        b.close(); ctx.close()
+        seq = synth.make_sequence(105, 2, n_kp=8000, width=2048, height=1024)
+        ctx, b, st, tm = _run_batch(seq, full=False)
+        for which, t in ((0, 1), (1, 1), (2, 1)):
+            want, _ = _per_call(oracle, seq, which, t, st, tm)
+            assert np.array_equal(b.matches(which, t), want), (variant, which, t)
+        b.close(); ctx.close()
+    finally:
+        libviso_amd.set_matcher_variant(0)
