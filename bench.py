@@ -132,6 +132,16 @@ def main():
     balg = balg_temporal if "match_kernel" in kname else balg_stereo + balg_temporal
     pairs = int(scored[1:].sum()) if "match_kernel" in kname else int(scored.sum())
     achieved = balg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the figure
+    # comes from the committed rocprofv3 --pmc passes of this same command (profiles/), and is only
+    # reported when the workload is the one those passes ran (bench.py defaults).
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_final.json")
+    if os.path.exists(pmc_path) and args.frames == 256 and args.kp == 2000 and args.width == 1241:
+        pmc = json.load(open(pmc_path))
+        if kname in pmc.get("kernel", ""):
+            traffic = pmc["hbm_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
 
     ab = None
     if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
@@ -200,7 +210,7 @@ def main():
                                    f"{args.kp} features/image, SAD matcher only (pack + 3 match_desc/frame + sort)",
                        "frames_per_step_per_gpu": args.frames, "parallelism": f"frames sharded over {world} rank(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname,
                          "kernel_ms_avg": kern_ms, "kernel_launches": kern_n,
                          "algorithmic_bytes_per_launch": balg,
