@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--matcher", type=int, default=0, help="0 = L2-gather kernel (default, faster), 1 = LDS tile kernel")
+    ap.add_argument("--images", action="store_true",
+                    help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
     args = ap.parse_args()
 
@@ -177,6 +179,22 @@ def main():
                "poses_ok": int(ok[1:].sum()), "frames": int(args.frames),
                "max_abs_tr_err_vs_ground_truth": err}
 
+    # ---- image-in pipeline: uint8 images + keypoints resident in HBM ---------
+    e2e_img = None
+    if args.images:
+        nfi = min(nf, 65)
+        iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
+        ib = libviso_amd.Batch(ctx, nfi, args.kp)
+        ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
+        ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+        dt3 = timed(lambda: ib.run_images(False), max(1, args.steps // 2), 1)
+        tri, oki, _ = ib.poses()
+        e2e_img = {"fps": (nfi - 1) * max(1, args.steps // 2) * world / dt3, "frames": nfi - 1,
+                   "workload": "uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
+                   "poses_ok": int(oki[1:].sum()),
+                   "max_abs_tr_err_vs_ground_truth": float(np.abs(tri[1:][oki[1:] == 1] - iseq["tr_gt"][1:][oki[1:] == 1]).max()) if oki[1:].any() else None}
+        ib.close()
+
     # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -220,6 +238,7 @@ def main():
                                  "a tiled kernel serves most of them from L2/LDS, so this is effective bandwidth"},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "end_to_end_from_images": e2e_img,
             "matcher_ab": ab,
         }
         print(json.dumps(line), flush=True)

@@ -191,6 +191,15 @@ int viso_batch_run_matcher(viso_batch* b);
  * join + RANSAC/GN.  Asynchronous on the context's stream. */
 int viso_batch_run(viso_batch* b);
 
+/* Image-in mode: upload uint8 images [nf][2][rows][cols]
+ * and keypoints; viso_batch_run_images extracts the 11x11 Sobel-x descriptor
+ * windows on the device (MyFeatureExtractor, src/viso.cpp:1004-1024) straight
+ * into the matcher's row format and then runs like viso_batch_run_matcher
+ * (matcher_only != 0) or viso_batch_run.  Needs dlen == 121. */
+int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
+                             const float* kp, const int32_t* n);
+int viso_batch_run_images(viso_batch* b, int matcher_only);
+
 /* Results (host copies; they synchronise the stream).
  * which: 0 = stereo L->R of frame t, 1 = temporal left (t vs t-1), 2 = temporal right. */
 int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* out_match, int* out_n);

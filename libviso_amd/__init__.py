@@ -86,6 +86,9 @@ def load():
     L.viso_batch_get_counters.argtypes = [C.c_void_p, i64p, i64p]
     L.viso_batch_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.viso_batch_kernel_ms.argtypes = [C.c_void_p, f64p, intp]
+    L.viso_batch_upload_images.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                           f32p, i32p]
+    L.viso_batch_run_images.argtypes = [C.c_void_p, C.c_int]
     L.viso_debug_set_matcher.argtypes = [C.c_int]
     L.viso_debug_set_matcher.restype = None
     _lib = L
@@ -295,6 +298,18 @@ class Batch:
         assert kp.shape == (nf, 2, self.cap, 2) and desc.shape == (nf, 2, self.cap, self.dlen)
         self._chk("viso_batch_upload", self.L.viso_batch_upload(self.h, f0, nf, ptr(kp, C.c_float),
                                                                  ptr(desc, C.c_float), ptr(n, C.c_int32)))
+
+    def upload_images(self, images, kp, n, f0=0):
+        """Image-in mode: uint8 images [nf][2][rows][cols] + keypoints (descriptors are extracted on the device)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        kp, n = _f32(kp), _i32(n)
+        nf, _, rows, cols = images.shape
+        assert kp.shape == (nf, 2, self.cap, 2)
+        self._chk("viso_batch_upload_images", self.L.viso_batch_upload_images(
+            self.h, f0, nf, ptr(images, C.c_uint8), rows, cols, ptr(kp, C.c_float), ptr(n, C.c_int32)))
+
+    def run_images(self, matcher_only=False):
+        self._chk("viso_batch_run_images", self.L.viso_batch_run_images(self.h, int(matcher_only)))
 
     def set_params(self, stereo, temporal, param, seed=0, first_frame=0):
         self._chk("viso_batch_set_params", self.L.viso_batch_set_params(

@@ -21,6 +21,7 @@ struct viso_batch {
     int n_probs;               // padded problem count (multiple of 24)
     float2* kp; float* desc; int* n; uint16_t* packed; int* bad; int* zero;
     float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
+    uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
     int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored;
@@ -57,7 +58,7 @@ extern "C" void viso_batch_destroy(viso_batch* b) try {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+    void* ptrs[] = {b->images, b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
@@ -159,6 +160,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
     b->n_probs = ((n_frames + 7) / 8) * 24;
     b->params_set = false; b->timing = false;
+    b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
     const size_t nf = (size_t)n_frames, c = (size_t)cap;
     int r = VISO_OK;
@@ -239,15 +241,23 @@ extern "C" int viso_batch_kernel_timing(viso_batch* b, int enable) {
     return VISO_OK;
 }
 
-extern "C" int viso_batch_run_matcher(viso_batch* b) {
-    if (!b || !b->params_set) { viso_set_error("viso_batch_run_matcher: parameters not set"); return VISO_ERR_ARG; }
+static int run_matcher_impl(viso_batch* b, bool from_images) {
+    if (!b || !b->params_set) { viso_set_error("viso_batch_run: parameters not set"); return VISO_ERR_ARG; }
+    if (from_images && (!b->images || b->dlen != VISO_DESC_LEN)) {
+        viso_set_error("viso_batch_run_images: no images uploaded (or descriptor length is not 121)");
+        return VISO_ERR_ARG;
+    }
     hipStream_t s = b->ctx->stream;
     HIP_TRY(hipMemsetAsync(b->bad, 0, sizeof(int), s));
     HIP_TRY(hipMemsetAsync(b->scored, 0, sizeof(unsigned long long) * 3 * (size_t)b->nf, s));
     HIP_TRY(hipMemsetAsync(b->ovf_cnt, 0, sizeof(int) * 3 * (size_t)b->nf, s));
     int r;
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
-    if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
+    if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
+        if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols)) < 0) return r;
+    } else {
+        if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {
         HIP_TRY(hipEventCreate(&e0));
@@ -259,9 +269,50 @@ extern "C" int viso_batch_run_matcher(viso_batch* b) {
     return VISO_OK;
 }
 
+extern "C" int viso_batch_run_matcher(viso_batch* b) { return run_matcher_impl(b, false); }
+
+static int run_rest(viso_batch* b);
+
 extern "C" int viso_batch_run(viso_batch* b) {
-    int r = viso_batch_run_matcher(b);
+    int r = run_matcher_impl(b, false);
     if (r < 0) return r;
+    return run_rest(b);
+}
+
+extern "C" int viso_batch_run_images(viso_batch* b, int matcher_only) {
+    int r = run_matcher_impl(b, true);
+    if (r < 0 || matcher_only) return r;
+    return run_rest(b);
+}
+
+extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
+                                        const float* kp, const int32_t* n) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && (!images || !kp || !n))) {
+        viso_set_error("viso_batch_upload_images: bad argument");
+        return VISO_ERR_ARG;
+    }
+    for (int i = 0; i < 2 * nf; ++i)
+        if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_images: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
+    if (b->images && (rows != b->img_rows || cols != b->img_cols)) {
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        HIP_TRY(hipFree(b->images));
+        b->images = nullptr;
+    }
+    const size_t per = (size_t)rows * cols;
+    if (!b->images) {
+        HIP_TRY(hipMalloc((void**)&b->images, per * 2 * (size_t)b->nf));
+        b->img_rows = rows; b->img_cols = cols;
+    }
+    if (nf == 0) return VISO_OK;
+    const size_t c = (size_t)b->cap;
+    HIP_TRY(hipMemcpy(b->images + (size_t)f0 * 2 * per, images, per * 2 * (size_t)nf, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice));
+    return VISO_OK;
+}
+
+static int run_rest(viso_batch* b) {
+    int r;
     hipStream_t s = b->ctx->stream;
     HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, s));            // vector<double> tr(6,0), :1312
     if ((r = launch_collect_triangulate(s, b->tri, b->nf, b->sp, b->cap)) < 0) return r;   // :1245-1247

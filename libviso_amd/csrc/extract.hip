@@ -70,3 +70,62 @@ extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VISO_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Fused extract + pack for the batch pipeline: the
+// 11x11 Sobel-x window of every keypoint goes straight from the uint8 image
+// into the matcher's biased-u16 row (x-sorted order); the N x 121 float
+// descriptor matrix of the reference (src/viso.cpp:1008) is never materialised.
+// Sobel of uint8 is an integer in [-1020, 1020], so the u16 path is always exact.
+// One wave = one keypoint at a time: lane l produces elements 2l and 2l+1.
+#define VISO_EXT_KPW 4   // keypoints per wave
+
+__global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __restrict__ imgs, int n_img, int cap,
+                                                           const uint8_t* __restrict__ images, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long k0 = wave * VISO_EXT_KPW;
+    if (k0 >= (long long)n_img * cap) return;
+    const int img = (int)(k0 / cap);           // cap is a multiple of VISO_EXT_KPW
+    const ImageView I = imgs[img];
+    const int n = *I.n;
+    const int j0 = (int)(k0 % cap);
+    const uint8_t* im = images + (size_t)img * rows * cols;
+#pragma unroll
+    for (int k = 0; k < VISO_EXT_KPW; ++k) {
+        const int j = j0 + k;
+        if (j >= n) return;
+        const float2 p = I.skp[j];
+        const int px = (int)rintf(p.x), py = (int)rintf(p.y);   // Point2i p = kp.pt, src/viso.cpp:1013
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * lane + h;
+            int v = 0;
+            if (c < 121) {
+                const int y = py + c / 11 - 5, x = px + c % 11 - 5;
+                if (y > 0 && y < rows && x > 0 && x < cols) {   // strict > 0, src/viso.cpp:1018
+                    const int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows);
+                    const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+                    const uint8_t* r0 = im + (size_t)ym * cols;
+                    const uint8_t* r1 = im + (size_t)y * cols;
+                    const uint8_t* r2 = im + (size_t)yp * cols;
+                    v = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+                }
+            }
+            packed |= ((uint32_t)(v + VISO_BIAS) & 0xffffu) << (16 * h);
+        }
+        reinterpret_cast<uint32_t*>(I.rows + (size_t)j * VISO_ROW)[lane] = packed;
+    }
+}
+
+int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
+                        int rows, int cols) {
+    const int capp = (cap + VISO_EXT_KPW - 1) / VISO_EXT_KPW * VISO_EXT_KPW;
+    const long long waves = (long long)n_img * capp / VISO_EXT_KPW;
+    if (waves == 0) return VISO_OK;
+    hipLaunchKernelGGL(extract_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp,
+                       images, rows, cols);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}

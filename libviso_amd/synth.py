@@ -158,3 +158,77 @@ def make_solver_case(seed, m=200, outlier_frac=0.25, tr=None, noise=0.3):
         obs[:, bad] += rng.uniform(-40, 40, (4, k_out))
     param = Param.default(base=base, f=f, cu=cu, cv=cv)
     return np.ascontiguousarray(Xp.T), np.ascontiguousarray(obs), tr, param
+
+
+def make_image_sequence(seed, n_frames, n_kp=2000, width=1241, height=376, outlier_frac=0.2,
+                        noise_sigma=2.0, cap=None, zmin=4.0, zmax=60.0):
+    """Image-in variant of make_sequence for the device-side descriptor
+    extractor (reference MyFeatureExtractor, src/viso.cpp:981-1025): returns
+    uint8 images [n_frames][2][height][width] plus keypoints.  Every world point
+    owns a 13x13 texture patch that is painted (with a little per-view noise)
+    around its projection in every view, so the 11x11 Sobel windows of
+    corresponding keypoints are similar and the rest of the pipeline sees real
+    matches; outlier keypoints sit on background noise."""
+    rng = np.random.default_rng(seed)
+    cap = cap or n_kp
+    f, cu, cv, base = KITTI_F, KITTI_CU, KITTI_CV, KITTI_BASE
+    n_in = int(round(n_kp * (1.0 - outlier_frac)))
+    R = 6                                                   # patch radius (13x13 covers the 11x11 window + Sobel)
+    images = np.zeros((n_frames, 2, height, width), np.uint8)
+    kp = np.zeros((n_frames, 2, cap, 2), np.float32)
+    n = np.zeros((n_frames, 2), np.int32)
+    tr_gt = np.zeros((n_frames, 6))
+
+    def new_patches(k):
+        p = rng.normal(128.0, 45.0, (k, 2 * R + 1, 2 * R + 1))
+        return np.clip(p, 0, 255)
+
+    P = _new_points(rng, n_in, width, height, zmin, zmax, f, cu, cv)
+    T = new_patches(n_in)
+    for t in range(n_frames):
+        if t > 0:
+            tr = np.concatenate([rng.uniform(-0.02, 0.02, 3), rng.uniform(-0.05, 0.05, 2),
+                                 -rng.uniform(0.5, 1.5, 1)])
+            tr_gt[t] = tr
+            Rm, tt = rot_from_tr(tr)
+            P = P @ Rm.T + tt
+            u = f * P[:, 0] / P[:, 2] + cu
+            v = f * P[:, 1] / P[:, 2] + cv
+            keep = (P[:, 2] > 2.0) & (u >= 0) & (u <= width - 1) & (v >= 0) & (v <= height - 1)
+            P, T = P[keep], T[keep]
+            k_new = n_in - len(P)
+            if k_new > 0:
+                P = np.concatenate([P, _new_points(rng, k_new, width, height, zmin, zmax, f, cu, cv)])
+                T = np.concatenate([T, new_patches(k_new)])
+        uL = np.rint(f * P[:, 0] / P[:, 2] + cu).astype(int)
+        vL = np.rint(f * P[:, 1] / P[:, 2] + cv).astype(int)
+        uR = np.rint(f * (P[:, 0] - base) / P[:, 2] + cu).astype(int)
+        order = rng.permutation(len(P))                      # same paint order in both views
+        for side in (0, 1):
+            img = rng.normal(128.0, 6.0, (height, width))
+            uu = uL if side == 0 else uR
+            vis = np.ones(len(P), bool) if side == 0 else ((uR >= 0) & (uR <= width - 1))
+            for j in order:
+                if not vis[j]:
+                    continue
+                x, y = uu[j], vL[j]
+                x0, x1, y0, y1 = max(0, x - R), min(width, x + R + 1), max(0, y - R), min(height, y + R + 1)
+                img[y0:y1, x0:x1] = T[j][y0 - (y - R):y1 - (y - R), x0 - (x - R):x1 - (x - R)]
+            img = img + rng.normal(0.0, noise_sigma, img.shape)
+            images[t, side] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+            idx = np.nonzero(vis)[0][:n_kp]
+            k_real = len(idx)
+            k_out = n_kp - k_real
+            xy = np.empty((n_kp, 2), np.float32)
+            xy[:k_real, 0] = uu[idx]
+            xy[:k_real, 1] = vL[idx]
+            xy[k_real:, 0] = rng.integers(0, width, k_out)
+            xy[k_real:, 1] = rng.integers(0, height, k_out)
+            perm = rng.permutation(n_kp)
+            kp[t, side, :n_kp] = xy[perm]
+            n[t, side] = n_kp
+    from . import hostmath
+    F = hostmath.F_from_P(KITTI_P1, KITTI_P2)
+    param = Param.default(base=base, f=f, cu=cu, cv=cv)
+    return dict(images=images, kp=kp, n=n, tr_gt=tr_gt, param=param, F=F, P1=KITTI_P1, P2=KITTI_P2,
+                width=width, height=height)
