@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--matcher", type=int, default=0, help="0 = L2-gather kernel (default, faster), 1 = LDS tile kernel")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true",
                     help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
@@ -75,10 +76,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a 1-GPU box: VISO_BENCH_SAME_DEVICE=1 puts every rank on device 0 (use --backend gloo)
+    dev_index = 0 if os.environ.get("VISO_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     import libviso_amd
     from libviso_amd import synth
@@ -88,7 +95,7 @@ def main():
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
     seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
-    ctx = libviso_amd.Context(local_rank)
+    ctx = libviso_amd.Context(dev_index)
     batch = libviso_amd.Batch(ctx, nf, args.kp)
     batch.upload(seq["kp"], seq["desc"], seq["n"])
     batch.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
@@ -110,7 +117,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -170,7 +177,7 @@ def main():
         dt2 = timed(full, max(1, args.steps // 2), 1)
         tr, ok, n_inl = batch.poses()
         if world > 1:   # the one exchange step: gather per-frame transforms (RCCL over xGMI)
-            rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64)], 1), device="cuda")
+            rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64)], 1), device=coll_dev)
             out = [torch.empty_like(rec) for _ in range(world)]
             dist.all_gather(out, rec)
         err = float(np.abs(tr[1:][ok[1:] == 1] - seq["tr_gt"][1:][ok[1:] == 1]).max()) if ok[1:].any() else None

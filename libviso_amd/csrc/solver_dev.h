@@ -79,6 +79,7 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
     double pred[4], X1c, Y1c, Z1c, X2c;
     predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
     const double weight = 1.0 / (fabs(obs[0 * ld + pos] - sp.cu) / fabs(sp.cu) + 0.05);
+    const double wf = weight * sp.f, iz2 = 1.0 / (Z1c * Z1c);
     double Jr[3][6];   // rows u_left, v_left, u_right
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -100,9 +101,12 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
         case 4: X1cd = 0; Y1cd = 1; Z1cd = 0; break;
         default: X1cd = 0; Y1cd = 0; Z1cd = 1; break;
         }
-        Jr[0][j] = weight * sp.f * (X1cd * Z1c - X1c * Z1cd) / (Z1c * Z1c);
-        Jr[1][j] = weight * sp.f * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
-        Jr[2][j] = weight * sp.f * (X1cd * Z1c - X2c * Z1cd) / (Z1c * Z1c);
+        // reference: weight*f*(..)/(Z1c*Z1c) (src/viso.cpp:1478-1481).  The 18 divisions per point are
+        // replaced by one reciprocal (<= 1 ulp per entry; J only steers the Gauss-Newton step, the
+        // inlier decisions use predict_point's exact divisions).
+        Jr[0][j] = wf * (X1cd * Z1c - X1c * Z1cd) * iz2;
+        Jr[1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) * iz2;
+        Jr[2][j] = wf * (X1cd * Z1c - X2c * Z1cd) * iz2;
     }
     double res[4];
     res[0] = weight * (obs[0 * ld + a] - pred[0]);
