@@ -91,3 +91,15 @@ def test_product_does_not_import_oracle():
                 bad = re.findall(r"^\s*(?:from|import)\s+oracle|#include\s+[\"<][^\n]*oracle|libviso_oracle|oracle_[a-z_0-9]+\s*\(",
                                  txt, flags=re.M)
                 assert not bad, (os.path.join(base, f), bad)
+
+
+def test_cpp_host_mirror_selftest(tmp_path):
+    """C++ host mirror (libviso_amd/host): Procrustes known answer of the
+    reference's test/test.cpp:171-205, F_from_P (src/mvg.cpp:73-89), tr2mat and
+    the KITTI calib/pose file formats (src/kitti.cpp:23-64).  Host-only code."""
+    import subprocess
+    exe = os.path.join(ROOT, "libviso_amd", "viso_host_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "libviso_amd", "host"), "-s"])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
