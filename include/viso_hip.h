@@ -156,6 +156,14 @@ void viso_F_from_P(const double P1[12], const double P2[12], double F[9]);
 int viso_extract_descriptors(const uint8_t* img, int rows, int cols,
                              const float* kp, int n, int radius, float* desc);
 
+/* cv::cornerHarris(img, R, 3, 5, k, BORDER_DEFAULT) restated; resp: rows x cols float. */
+int viso_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp);
+/* HarrisBinnedFeatureDetector::detectImpl, src/viso.cpp:926-975 (reference defaults:
+ * n_features 1200, nbinx 24, nbiny 5).  kp: up to n_features x 2 (x,y);
+ * resp_out (may be NULL): |response| per keypoint. */
+int viso_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_features, int nbinx, int nbiny,
+                              double k, float* kp, float* resp_out, int* n_out);
+
 /* ------------------------------------------- batched, device-resident family
  *
  * A frame set holds `n_frames` stereo frames resident in HBM:
@@ -199,6 +207,14 @@ int viso_batch_run(viso_batch* b);
 int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
                              const float* kp, const int32_t* n);
 int viso_batch_run_images(viso_batch* b, int matcher_only);
+/* HarrisBinnedFeatureDetector::detectImpl (src/viso.cpp:926-975) on every
+ * uploaded image (pass kp = n = NULL to viso_batch_upload_images): fills the
+ * batch's keypoints on the device.  cv::cornerHarris(blockSize 3, ksize 5, k)
+ * restated; the reference leaves k uninitialised (:915-919,978) — its intended
+ * default is 0.04f — and the order inside a bin unspecified (:963); here:
+ * (|response| desc, push order asc).  n_features/(nbinx*nbiny) corners per bin. */
+int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int nbiny, double k);
+int viso_batch_get_keypoints(viso_batch* b, int t, int side, float* kp, int* n_out);
 
 /* Results (host copies; they synchronise the stream).
  * which: 0 = stereo L->R of frame t, 1 = temporal left (t vs t-1), 2 = temporal right. */

@@ -89,6 +89,11 @@ def load():
     L.viso_batch_upload_images.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
                                            f32p, i32p]
     L.viso_batch_run_images.argtypes = [C.c_void_p, C.c_int]
+    L.viso_batch_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.viso_batch_get_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, intp]
+    L.viso_harris_response.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
+    L.viso_detect_harris_binned.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_double, f32p, f32p, intp]
     L.viso_debug_set_matcher.argtypes = [C.c_int]
     L.viso_debug_set_matcher.restype = None
     _lib = L
@@ -253,6 +258,34 @@ def extract_descriptors(img, kp, radius=5):
     return d
 
 
+HARRIS_K = float(np.float32(0.04))   # the reference's intended default (float k = .04, src/viso.cpp:915)
+
+
+def harris_response(img, k=HARRIS_K):
+    """cv::cornerHarris(img, R, 3, 5, k, BORDER_DEFAULT) restated (reference src/viso.cpp:930)."""
+    L = load()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    r = np.empty(img.shape, np.float32)
+    rc = L.viso_harris_response(ptr(img, C.c_uint8), img.shape[0], img.shape[1], k, ptr(r, C.c_float))
+    if rc != 1:
+        _err("viso_harris_response", rc)
+    return r
+
+
+def detect_harris_binned(img, n_features=1200, nbinx=24, nbiny=5, k=HARRIS_K):
+    """HarrisBinnedFeatureDetector::detectImpl, reference src/viso.cpp:926-975."""
+    L = load()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    kp = np.empty((max(1, n_features), 2), np.float32)
+    resp = np.empty(max(1, n_features), np.float32)
+    n = C.c_int(0)
+    rc = L.viso_detect_harris_binned(ptr(img, C.c_uint8), img.shape[0], img.shape[1], n_features, nbinx, nbiny, k,
+                                     ptr(kp, C.c_float), ptr(resp, C.c_float), C.byref(n))
+    if rc != 1:
+        _err("viso_detect_harris_binned", rc)
+    return kp[:n.value].copy(), resp[:n.value].copy()
+
+
 # ------------------------------------------------------------ batched family
 class Context:
     def __init__(self, device=0, stream=None):
@@ -307,6 +340,22 @@ class Batch:
         assert kp.shape == (nf, 2, self.cap, 2)
         self._chk("viso_batch_upload_images", self.L.viso_batch_upload_images(
             self.h, f0, nf, ptr(images, C.c_uint8), rows, cols, ptr(kp, C.c_float), ptr(n, C.c_int32)))
+
+    def upload_images_only(self, images, f0=0):
+        """Images without keypoints: follow with detect()."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        nf, _, rows, cols = images.shape
+        self._chk("viso_batch_upload_images", self.L.viso_batch_upload_images(
+            self.h, f0, nf, ptr(images, C.c_uint8), rows, cols, None, None))
+
+    def detect(self, n_features=1200, nbinx=24, nbiny=5, k=HARRIS_K):
+        self._chk("viso_batch_detect", self.L.viso_batch_detect(self.h, n_features, nbinx, nbiny, k))
+
+    def keypoints(self, t, side):
+        kp = np.empty((self.cap, 2), np.float32)
+        n = C.c_int(0)
+        self._chk("viso_batch_get_keypoints", self.L.viso_batch_get_keypoints(self.h, t, side, ptr(kp, C.c_float), C.byref(n)))
+        return kp[:n.value].copy()
 
     def run_images(self, matcher_only=False):
         self._chk("viso_batch_run_images", self.L.viso_batch_run_images(self.h, int(matcher_only)))

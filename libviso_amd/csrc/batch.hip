@@ -22,6 +22,7 @@ struct viso_batch {
     float2* kp; float* desc; int* n; uint16_t* packed; int* bad; int* zero;
     float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
+    float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
     int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored;
@@ -58,7 +59,7 @@ extern "C" void viso_batch_destroy(viso_batch* b) try {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {b->images, b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+    void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
@@ -161,6 +162,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->n_probs = ((n_frames + 7) / 8) * 24;
     b->params_set = false; b->timing = false;
     b->images = nullptr; b->img_rows = b->img_cols = 0;
+    b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
     b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
     const size_t nf = (size_t)n_frames, c = (size_t)cap;
     int r = VISO_OK;
@@ -287,11 +289,11 @@ extern "C" int viso_batch_run_images(viso_batch* b, int matcher_only) {
 
 extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
                                         const float* kp, const int32_t* n) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && (!images || !kp || !n))) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
         viso_set_error("viso_batch_upload_images: bad argument");
         return VISO_ERR_ARG;
     }
-    for (int i = 0; i < 2 * nf; ++i)
+    for (int i = 0; n && i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_images: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
     if (b->images && (rows != b->img_rows || cols != b->img_cols)) {
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -306,8 +308,54 @@ extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uin
     if (nf == 0) return VISO_OK;
     const size_t c = (size_t)b->cap;
     HIP_TRY(hipMemcpy(b->images + (size_t)f0 * 2 * per, images, per * 2 * (size_t)nf, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice));
+    if (kp) {   // keypoints may instead come from viso_batch_detect
+        HIP_TRY(hipMemcpy(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice));
+    }
+    return VISO_OK;
+}
+
+// HarrisBinnedFeatureDetector on every uploaded image (src/viso.cpp:1226-1227): fills the batch's
+// keypoint arrays and counts on the device; viso_batch_run_images then extracts descriptors there too.
+extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int nbiny, double k) {
+    if (!b || !b->images) { viso_set_error("viso_batch_detect: no images uploaded"); return VISO_ERR_ARG; }
+    if (n_features < 0 || nbinx <= 0 || nbiny <= 0 || b->img_cols / nbinx <= 0 || b->img_rows / nbiny <= 0 ||
+        (long long)nbinx * nbiny > 16384) {
+        viso_set_error("viso_batch_detect: bad bin geometry");
+        return VISO_ERR_ARG;
+    }
+    const int nbins = nbinx * nbiny, per = n_features / nbins;
+    if ((long long)nbins * per > b->cap) { viso_set_error("viso_batch_detect: %d features exceed the batch capacity %d", nbins * per, b->cap); return VISO_ERR_ARG; }
+    const int n_img = b->nf * 2;
+    hipStream_t s = b->ctx->stream;
+    if (!b->h_resp) HIP_TRY(hipMalloc((void**)&b->h_resp, sizeof(float) * (size_t)n_img * b->img_rows * b->img_cols));
+    const size_t slots = (size_t)nbins * (per > 0 ? per : 1);
+    if (slots > b->h_slots) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (b->h_tmp_kp) HIP_TRY(hipFree(b->h_tmp_kp));
+        if (b->h_tmp_resp) HIP_TRY(hipFree(b->h_tmp_resp));
+        if (b->h_cnt) HIP_TRY(hipFree(b->h_cnt));
+        b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr;
+        HIP_TRY(hipMalloc((void**)&b->h_tmp_kp, sizeof(float2) * slots * n_img));
+        HIP_TRY(hipMalloc((void**)&b->h_tmp_resp, sizeof(float) * slots * n_img));
+        HIP_TRY(hipMalloc((void**)&b->h_cnt, sizeof(int) * (size_t)16384 * n_img));
+        b->h_slots = slots;
+    }
+    int r;
+    if ((r = launch_harris_response(s, b->images, n_img, b->img_rows, b->img_cols, k, b->h_resp)) < 0) return r;
+    if (per == 0) { HIP_TRY(hipMemsetAsync(b->n, 0, sizeof(int) * (size_t)n_img, s)); return VISO_OK; }
+    return launch_harris_bins(s, b->h_resp, n_img, b->img_rows, b->img_cols, n_features, nbinx, nbiny, b->h_tmp_kp,
+                              b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap);
+}
+
+// Keypoints of frame t, image side (after viso_batch_detect or an upload).
+extern "C" int viso_batch_get_keypoints(viso_batch* b, int t, int side, float* kp, int* n_out) {
+    if (!b || t < 0 || t >= b->nf || side < 0 || side > 1 || !n_out) { viso_set_error("viso_batch_get_keypoints: bad argument"); return VISO_ERR_ARG; }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, b->n + (size_t)t * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > 0 && kp) HIP_TRY(hipMemcpy(kp, b->kp + ((size_t)t * 2 + side) * b->cap, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
+    *n_out = n;
     return VISO_OK;
 }
 

@@ -138,3 +138,7 @@ int launch_match_tile(hipStream_t s, const MatchProblem* probs_dev, int n_probs,
                       const MatchParamsDev mp[2], const int* bad);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols);
+int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
+int launch_harris_bins(hipStream_t s, const float* resp, int n_img, int rows, int cols, int n_features, int nbinx,
+                       int nbiny, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
+                       int* n_out, int cap, size_t kp_stride);

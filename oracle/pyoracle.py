@@ -45,6 +45,11 @@ def lib():
         L.oracle_minimize_reproj.argtypes = [f64p, f64p, C.c_int, f64p, PP, i32p, C.c_int, intp]
         L.oracle_lu_solve6.restype = C.c_int
         L.oracle_lu_solve6.argtypes = [f64p, f64p]
+        L.oracle_harris_response.restype = C.c_int
+        L.oracle_harris_response.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
+        L.oracle_detect_harris_binned.restype = C.c_int
+        L.oracle_detect_harris_binned.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_double, f32p, f32p, intp]
         L.oracle_sequence.restype = C.c_int
         L.oracle_sequence.argtypes = [f32p, f32p, i32p, C.c_int, C.c_int, C.c_int, MP, MP, PP,
                                       C.c_uint64, C.c_uint64, C.c_int, f64p, i32p, i32p, i64p, i64p,
@@ -209,6 +214,27 @@ def extract_descriptors(img, kp, radius=5):
                                          ptr(kp, C.c_float), len(kp), radius, ptr(d, C.c_float))
     assert r == 1
     return d
+
+
+HARRIS_K = float(np.float32(0.04))   # the reference's intended default (float k = .04, src/viso.cpp:915)
+
+
+def harris_response(img, k=HARRIS_K):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    r = np.empty(img.shape, np.float32)
+    assert lib().oracle_harris_response(ptr(img, C.c_uint8), img.shape[0], img.shape[1], k, ptr(r, C.c_float)) == 1
+    return r
+
+
+def detect_harris_binned(img, n_features=1200, nbinx=24, nbiny=5, k=HARRIS_K):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    kp = np.empty((max(1, n_features), 2), np.float32)
+    resp = np.empty(max(1, n_features), np.float32)
+    n = C.c_int(0)
+    r = lib().oracle_detect_harris_binned(ptr(img, C.c_uint8), img.shape[0], img.shape[1], n_features, nbinx, nbiny,
+                                          k, ptr(kp, C.c_float), ptr(resp, C.c_float), C.byref(n))
+    assert r == 1, r
+    return kp[:n.value].copy(), resp[:n.value].copy()
 
 
 def sequence(kp, desc, n, stereo, temporal, param, seed=0, first_frame=0, matcher_only=False):

@@ -593,6 +593,111 @@ int oracle_extract_descriptors(const uint8_t* img, int rows, int cols,
     return VISO_OK;
 }
 
+/* ------------------------------------------------------- Harris (binned) */
+/* HarrisBinnedFeatureDetector::detectImpl, reference src/viso.cpp:926-975, with
+ * cv::cornerHarris(image, R, blockSize=3, ksize=5, k, BORDER_DEFAULT) restated
+ * (OpenCV imgproc corner.cpp, un-vendored): Dx, Dy = 5x5 Sobel (deriv
+ * [-1,-2,0,2,1] x smooth [1,4,6,4,1], BORDER_REFLECT_101) scaled by
+ * 1/(2^(ksize-1) * blockSize * 255); cov = (dx*dx, dx*dy, dy*dy) in float;
+ * unnormalised 3x3 box sum of cov with BORDER_REFLECT_101 on the cov image;
+ * R = (float)(a*c - b*b - k*(a+c)*(a+c)) with k double.  The reference never
+ * initialises its k (src/viso.cpp:915-919,978): k is an explicit input here.
+ * Evaluation order (this restatement's definition, shared with the HIP kernel):
+ * integer Sobel sums are exact, dx = (float)Dx * (float)scale, box sums add the
+ * nine taps row-major in float. */
+static void harris_cov(const uint8_t* img, int rows, int cols, float* cov /* rows*cols*3 */) {
+    static const int d[5] = {-1, -2, 0, 2, 1}, sm[5] = {1, 4, 6, 4, 1};
+    const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            int Dx = 0, Dy = 0;
+            for (int i = -2; i <= 2; ++i) {
+                const uint8_t* r = img + (size_t)reflect101(y + i, rows) * cols;
+                int hd = 0, hs = 0;
+                for (int j = -2; j <= 2; ++j) {
+                    const int p = r[reflect101(x + j, cols)];
+                    hd += d[j + 2] * p;
+                    hs += sm[j + 2] * p;
+                }
+                Dx += sm[i + 2] * hd;
+                Dy += d[i + 2] * hs;
+            }
+            const float dx = (float)Dx * scale, dy = (float)Dy * scale;
+            float* c = cov + ((size_t)y * cols + x) * 3;
+            c[0] = dx * dx; c[1] = dx * dy; c[2] = dy * dy;
+        }
+}
+
+int oracle_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp) {
+    if (rows <= 0 || cols <= 0) return VISO_ERR_ARG;
+    float* cov = (float*)malloc(sizeof(float) * (size_t)rows * cols * 3);
+    if (!cov) return VISO_ERR_NOMEM;
+    harris_cov(img, rows, cols, cov);
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            float a = 0.f, b = 0.f, c = 0.f;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    const float* q = cov + ((size_t)reflect101(y + i, rows) * cols + reflect101(x + j, cols)) * 3;
+                    a += q[0]; b += q[1]; c += q[2];
+                }
+            const float t1 = a * c, t2 = b * b;
+            const float t3 = t1 - t2;
+            const float tr = a + c;
+            resp[(size_t)y * cols + x] = (float)((double)t3 - k * (double)tr * (double)tr);
+        }
+    free(cov);
+    return VISO_OK;
+}
+
+typedef struct { float v; int pos; int x, y; } harris_elem;
+static int cmp_harris(const void* pa, const void* pb) {
+    const harris_elem* a = (const harris_elem*)pa;
+    const harris_elem* b = (const harris_elem*)pb;
+    if (a->v != b->v) return a->v > b->v ? -1 : 1;   /* |response| descending */
+    return (a->pos > b->pos) - (a->pos < b->pos);    /* then the reference's push order (x outer, y inner) */
+}
+
+/* src/viso.cpp:931-975.  kp: up to n_features x 2 (x,y); resp_out (may be NULL): |response| per keypoint.
+ * Bins in (binx outer, biny inner) order; within a bin the corners_per_block largest
+ * |response| != 0, ordered by (|response| desc, push order asc) — the reference's
+ * nth_element leaves that order unspecified (:963). */
+int oracle_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_features, int nbinx, int nbiny,
+                                double k, float* kp, float* resp_out, int* n_out) {
+    if (rows <= 0 || cols <= 0 || nbinx <= 0 || nbiny <= 0 || n_features < 0) return VISO_ERR_ARG;
+    const int stridex = cols / nbinx, stridey = rows / nbiny;
+    if (stridex <= 0 || stridey <= 0) return VISO_ERR_ARG;       /* assert(stridex>0 && stridey>0), :934 */
+    const int per = n_features / (nbinx * nbiny);                /* corners_per_block, :943 */
+    float* resp = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    harris_elem* v = (harris_elem*)malloc(sizeof(harris_elem) * (size_t)stridex * stridey);
+    if (!resp || !v) { free(resp); free(v); return VISO_ERR_NOMEM; }
+    oracle_harris_response(img, rows, cols, k, resp);
+    int n = 0;
+    for (int bx = 0; bx < nbinx; ++bx)
+        for (int by = 0; by < nbiny; ++by) {
+            int cnt = 0;
+            for (int x = bx * stridex; x < (bx + 1) * stridex && x < cols; ++x)
+                for (int y = by * stridey; y < (by + 1) * stridey && y < rows; ++y) {
+                    const float r = fabsf(resp[(size_t)y * cols + x]);
+                    if (fabsf(r - 0.f) <= 1e-6f * fabsf(r)) continue;          /* isEqual(response, .0f), src/misc.cpp:10-14 */
+                    v[cnt].v = r; v[cnt].pos = cnt; v[cnt].x = x; v[cnt].y = y;
+                    ++cnt;
+                }
+            /* pos must be the push index among ALL pixels of the bin (not only the kept ones) to
+             * be reproducible on the device: recompute it from coordinates */
+            for (int i = 0; i < cnt; ++i) v[i].pos = (v[i].x - bx * stridex) * stridey + (v[i].y - by * stridey);
+            qsort(v, (size_t)cnt, sizeof(harris_elem), cmp_harris);
+            for (int i = 0; i < cnt && i < per; ++i) {
+                kp[2 * n] = (float)v[i].x; kp[2 * n + 1] = (float)v[i].y;
+                if (resp_out) resp_out[n] = v[i].v;
+                ++n;
+            }
+        }
+    *n_out = n;
+    free(resp); free(v);
+    return VISO_OK;
+}
+
 /* ---------------------------------------------- sequence_odometry loop body */
 static double now_s(void) {
     struct timespec ts;

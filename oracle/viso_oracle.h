@@ -84,6 +84,12 @@ void oracle_F_from_P(const double P1[12], const double P2[12], double F[9]);
 int oracle_extract_descriptors(const uint8_t* img, int rows, int cols,
                                const float* kp, int n, int radius, float* desc);
 
+/* cv::cornerHarris(blockSize 3, ksize 5, k, BORDER_DEFAULT) restated; resp: rows x cols float. */
+int oracle_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp);
+/* HarrisBinnedFeatureDetector::detectImpl, src/viso.cpp:926-975 (k explicit). */
+int oracle_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_features, int nbinx, int nbiny,
+                                double k, float* kp, float* resp_out, int* n_out);
+
 /* One sequence_odometry loop body over in-memory frames (src/viso.cpp:1205-1327),
  * without the front-end: frames laid out as viso_batch (kp [nf][2][cap][2],
  * desc [nf][2][cap][dlen], n [nf][2]).  Outputs per frame t: tr [nf][6],

@@ -1,0 +1,69 @@
+"""Binned Harris detector on device against the oracle's
+restatement of HarrisBinnedFeatureDetector::detectImpl (reference
+src/viso.cpp:926-975; k explicit, per-bin order defined), and the complete
+image -> keypoints -> descriptors -> matches -> pose path without any host
+round trip."""
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(60, 96), (37, 131), (376, 1241)])
+def test_harris_response_bit_exact(viso, oracle, shape):
+    img = synth.make_images(shape[0], shape[0], shape[1])
+    a, b = libviso_amd.harris_response(img), oracle.harris_response(img)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 0
+
+
+def test_detect_binned_bit_exact(viso, oracle):
+    img = synth.make_image_sequence(3, 1, n_kp=1500)["images"][0, 0]          # 376 x 1241
+    for nf, bx, by in ((1200, 24, 5), (120, 6, 3), (64, 2, 2)):
+        k0, r0 = oracle.detect_harris_binned(img, nf, bx, by)
+        k1, r1 = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        assert np.array_equal(k0, k1) and np.array_equal(r0, r1)
+        assert len(k0) == (nf // (bx * by)) * bx * by
+    flat = np.full((40, 60), 7, np.uint8)                                      # zero response everywhere: no corners
+    assert len(libviso_amd.detect_harris_binned(flat, 120, 6, 2)[0]) == 0 == len(oracle.detect_harris_binned(flat, 120, 6, 2)[0])
+
+
+def test_image_to_pose_pipeline(viso, oracle):
+    seq = synth.make_image_sequence(9, 4, n_kp=1500)
+    nf = 4
+    # oracle: detect -> extract -> sequence, all on the CPU
+    cap = 1200
+    kp = np.zeros((nf, 2, cap, 2), np.float32)
+    n = np.zeros((nf, 2), np.int32)
+    desc = np.zeros((nf, 2, cap, 121), np.float32)
+    for t in range(nf):
+        for side in range(2):
+            k, _ = oracle.detect_harris_binned(seq["images"][t, side])
+            n[t, side] = len(k)
+            kp[t, side, :len(k)] = k
+            desc[t, side, :len(k)] = oracle.extract_descriptors(seq["images"][t, side], k)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    want = oracle.sequence(kp, desc, n, st, tm, seq["param"], seed=6)
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, cap)
+    b.upload_images_only(seq["images"])
+    b.set_params(st, tm, seq["param"], seed=6)
+    b.detect()
+    b.run_images()
+    for t in range(nf):
+        for side in range(2):
+            assert np.array_equal(b.keypoints(t, side), kp[t, side, :n[t, side]])
+    tr, ok, n_inl = b.poses()
+    sc, mo = b.counters()
+    assert np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"])
+    assert np.array_equal(sc, want["scored"]) and np.array_equal(mo, want["m_out"])
+    assert ok[1:].all() and n_inl[1:].min() > 30
+    for t in range(1, nf):
+        a, r = libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])
+        assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-5
+        assert np.abs(tr[t] - seq["tr_gt"][t]).max() < 5e-2
+    b.close(); ctx.close()

@@ -301,3 +301,37 @@ def test_sequence_driver_runs_and_recovers_motion(oracle):
     assert out["ok"][0] == 0 and np.all(out["ok"][1:] == 1)
     assert np.abs(out["tr"][1:] - seq["tr_gt"][1:]).max() < 2e-2
     assert out["scored"][1, 1:].min() > 400 and out["m_out"][0].min() > 50
+
+
+def test_harris_response_vs_scipy(oracle):
+    # cv::cornerHarris(blockSize 3, ksize 5, k) restated: Sobel 5x5 (deriv x smooth, reflect-101) scaled by
+    # 1/(2^4*3*255), unnormalised 3x3 box of (dx^2, dxdy, dy^2) with reflect-101, det - k*trace^2
+    from scipy import ndimage
+    img = synth.make_images(3, 60, 96)
+    r = oracle.harris_response(img)
+    d = np.array([-1, -2, 0, 2, 1.0]); s = np.array([1, 4, 6, 4, 1.0])
+    I = img.astype(np.float64)
+    Dx = ndimage.correlate1d(ndimage.correlate1d(I, d, axis=1, mode="mirror"), s, axis=0, mode="mirror") / 12240
+    Dy = ndimage.correlate1d(ndimage.correlate1d(I, s, axis=1, mode="mirror"), d, axis=0, mode="mirror") / 12240
+    box = lambda A: ndimage.uniform_filter(A, 3, mode="mirror") * 9
+    a, b, c = box(Dx * Dx), box(Dx * Dy), box(Dy * Dy)
+    R = a * c - b * b - oracle.HARRIS_K * (a + c) ** 2
+    assert np.abs(r - R).max() <= 2e-6 * np.abs(R).max()
+
+
+def test_harris_binned_selection(oracle):
+    img = synth.make_images(5, 80, 120)
+    kp, resp = oracle.detect_harris_binned(img, 120, 6, 4)        # 5 per bin, 24 bins
+    R = np.abs(oracle.harris_response(img))
+    assert len(kp) == 120 and np.all(resp > 0)
+    sx, sy = 120 // 6, 80 // 4
+    for b in range(24):
+        bx, by = b // 4, b % 4                                     # binx outer, biny inner (:949-951)
+        blk = R[by * sy:(by + 1) * sy, bx * sx:(bx + 1) * sx]
+        top = np.sort(blk.reshape(-1))[::-1][:5]
+        assert np.array_equal(resp[5 * b:5 * b + 5], top)          # the 5 largest |response|, descending
+        for (x, y), v in zip(kp[5 * b:5 * b + 5].astype(int), resp[5 * b:5 * b + 5]):
+            assert bx * sx <= x < (bx + 1) * sx and by * sy <= y < (by + 1) * sy and R[y, x] == v
+    # reference defaults: 1200 features, 24 x 5 bins, 10 per bin (src/viso.cpp:1171-1172, 915)
+    big = synth.make_image_sequence(1, 1, n_kp=300, width=480, height=200)["images"][0, 0]
+    assert len(oracle.detect_harris_binned(big)[0]) == 1200
