@@ -200,6 +200,22 @@ def main():
                    "workload": "uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
                    "poses_ok": int(oki[1:].sum()),
                    "max_abs_tr_err_vs_ground_truth": float(np.abs(tri[1:][oki[1:] == 1] - iseq["tr_gt"][1:][oki[1:] == 1]).max()) if oki[1:].any() else None}
+        # complete front-end on device too: binned Harris -> descriptors -> matcher -> solver
+        db = libviso_amd.Batch(ctx, nfi, 1200)
+        db.upload_images_only(iseq["images"])
+        db.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+
+        def detect_and_run():
+            db.detect()
+            db.run_images(False)
+        dt4 = timed(detect_and_run, max(1, args.steps // 2), 1)
+        trd, okd, _ = db.poses()
+        e2e_img["with_harris_detection"] = {
+            "fps": (nfi - 1) * max(1, args.steps // 2) * world / dt4,
+            "workload": "uint8 images only -> binned Harris (1200 corners/image, 24x5 bins) -> descriptors -> matcher + circle + RANSAC/GN",
+            "poses_ok": int(okd[1:].sum()),
+            "max_abs_tr_err_vs_ground_truth": float(np.abs(trd[1:][okd[1:] == 1] - iseq["tr_gt"][1:][okd[1:] == 1]).max()) if okd[1:].any() else None}
+        db.close()
         ib.close()
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload ----

@@ -90,8 +90,21 @@ struct BinArgs {
     int* cnt;               // [n_img][nbins]
 };
 
-// One wave per (image, bin): `per` rounds of "largest key below the previous
-// pick"; key = (|response| bits, ~push position), so ties go to the earlier push.
+// One wave per (image, bin).  key = (|response| bits, ~push position): larger is
+// better and ties go to the earlier push.  Fast path: ONE pass over the bin in
+// which every lane keeps its three largest keys, then `per` rounds of wave-max
+// over the lanes' heads.  That is exact unless some lane's third-best key is
+// still above the last pick (a fourth could hide behind it); such bins (a few
+// percent) are redone by the exact multi-pass loop.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o = __shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -102,32 +115,78 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
     const int x0 = bx * a.stridex, y0 = by * a.stridey;
     const int P = a.stridex * a.stridey;
     const float* r = a.resp + (size_t)img * a.rows * a.cols;
-    unsigned long long prev = ~0ull;
+    const size_t obase = ((size_t)img * nbins + bin) * a.per;
+    // ---- pass 1: per-lane top 3
+    unsigned long long k0 = 0, k1 = 0, k2 = 0;             // k0 >= k1 >= k2
+    {
+        // lanes walk the bin in MEMORY order (x fastest: coalesced rows); the key carries the
+        // reference's push position pos = xo * stridey + yo (x outer, y inner, :953-955)
+        int yo = lane / a.stridex, xo = lane % a.stridex;
+        for (int idx = lane; idx < P; idx += 64) {
+            const int x = x0 + xo, y = y0 + yo;
+            const int pos = xo * a.stridey + yo;
+            if (x < a.cols && y < a.rows) {
+                const float v = fabsf(r[(size_t)y * a.cols + x]);
+                if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {   // isEqual(response, .0f), src/misc.cpp:10-14
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
+                    if (key > k2) {
+                        if (key > k1) { k2 = k1; if (key > k0) { k1 = k0; k0 = key; } else k1 = key; }
+                        else k2 = key;
+                    }
+                }
+            }
+            xo += 64;
+            while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
+        }
+    }
+    // ---- merge: `per` rounds over the lanes' heads
+    const unsigned long long third = k2;                   // what this lane might be hiding behind
+    unsigned long long last = 0;
     int n = 0;
     for (int round = 0; round < a.per; ++round) {
-        unsigned long long best = 0;
-        for (int pos = lane; pos < P; pos += 64) {
-            const int x = x0 + pos / a.stridey, y = y0 + pos % a.stridey;
-            if (x >= a.cols || y >= a.rows) continue;
-            const float v = fabsf(r[(size_t)y * a.cols + x]);
-            if (fabsf(v - 0.f) <= 1e-6f * fabsf(v)) continue;            // isEqual(response, .0f), src/misc.cpp:10-14 (NaN stays)
-            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
-            if (key < prev && key > best) best = key;
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const unsigned long long o = __shfl_xor(best, m);
-            best = o > best ? o : best;
-        }
+        const unsigned long long best = wave_max_u64(k0);
         if (best == 0) break;
-        prev = best;
+        if (k0 == best) { k0 = k1; k1 = k2; k2 = 0; }      // keys are unique: exactly one lane pops
+        last = best;
         if (lane == 0) {
             const int pos = (int)(0xffffffffu - (uint32_t)best);
-            const size_t o = ((size_t)img * nbins + bin) * a.per + n;
-            a.tmp_kp[o] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
-            a.tmp_resp[o] = __uint_as_float((uint32_t)(best >> 32));
+            a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
+            a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
         }
         ++n;
+    }
+    // exact iff no lane used up all three of its keys while more picks could lie below them
+    const bool suspicious = (n == a.per) ? (third > last) : (third != 0 && k0 == 0 && n < a.per);
+    if (__any(suspicious)) {
+        // ---- exact path: `per` rounds of "largest key below the previous pick"
+        unsigned long long prev = ~0ull;
+        n = 0;
+        for (int round = 0; round < a.per; ++round) {
+            unsigned long long best = 0;
+            int yo = lane / a.stridex, xo = lane % a.stridex;
+            for (int idx = lane; idx < P; idx += 64) {
+                const int x = x0 + xo, y = y0 + yo;
+                const int pos = xo * a.stridey + yo;
+                if (x < a.cols && y < a.rows) {
+                    const float v = fabsf(r[(size_t)y * a.cols + x]);
+                    if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
+                        if (key < prev && key > best) best = key;
+                    }
+                }
+                xo += 64;
+                while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
+            }
+            best = wave_max_u64(best);
+            if (best == 0) break;
+            prev = best;
+            if (lane == 0) {
+                const int pos = (int)(0xffffffffu - (uint32_t)best);
+                a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
+                a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
+            }
+            ++n;
+        }
     }
     if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
 }
