@@ -128,3 +128,65 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
                                  int chunk = 64, uint64_t ransac_seed = 0);
 
 }  // namespace viso
+
+// ---------------------------------------------------------------------------
+// Front-end mirror: the reference's detector /
+// extractor classes and the image-driven sequence_odometry, on the GPU.
+namespace viso {
+
+// Grayscale image (what cv::imread(name, CV_LOAD_IMAGE_GRAYSCALE) returns, src/viso.h:92-93).
+struct Image {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+    bool empty() const { return data.empty(); }
+};
+// Binary PGM (P5, maxval <= 255).  KITTI ships PNG; convert once (e.g. `mogrify -format pgm`):
+// this build has no PNG decoder and the reference's cv::imread is out of scope.
+Image imread_pgm(const std::string& file_name);
+
+// HarrisBinnedFeatureDetector, src/viso.cpp:911-979.  `k` is stored (the
+// reference forgets to, :915-919); block_size 3 / aperture_size 5 are what the
+// device kernel implements.
+class HarrisBinnedFeatureDetector {
+public:
+    HarrisBinnedFeatureDetector(int radius, int n, int nbinx = 24, int nbiny = 5, float k = .04f,
+                                int block_size = 3, int aperture_size = 5);
+    void detect(const Image& image, KeyPoints& kp) const;
+    int n() const { return m_n; }
+    int nbinx() const { return m_nbinx; }
+    int nbiny() const { return m_nbiny; }
+    float k() const { return m_k; }
+private:
+    int m_radius, m_nbinx, m_nbiny, m_block_size, m_aperture_size, m_n;
+    float m_k;
+};
+
+// MyFeatureExtractor, src/viso.cpp:981-1025.
+class MyFeatureExtractor {
+public:
+    explicit MyFeatureExtractor(int descriptor_radius) : m_descriptor_radius(descriptor_radius) {}
+    int descriptorSize() const { return (2 * m_descriptor_radius + 1) * (2 * m_descriptor_radius + 1); }
+    void compute(const Image& image, KeyPoints& kp, Descriptors& d) const;
+private:
+    int m_descriptor_radius;
+};
+
+// StereoImageGenerator, src/viso.h:81-100: printf-style masks, begin/end frame, stops at the first unreadable pair.
+class StereoImageGenerator {
+public:
+    typedef std::optional<std::pair<Image, Image>> result_type;
+    StereoImageGenerator(const std::pair<std::string, std::string>& mask, int begin = 0, int end = 2147483647)
+        : m_mask(mask), m_index(begin), m_end(end) {}
+    result_type operator()();
+private:
+    std::pair<std::string, std::string> m_mask;
+    int m_index, m_end;
+};
+
+// sequence_odometry(P1, P2, images, dbg_dir), src/viso.h:138-139 / src/viso.cpp:1167-1330, without the
+// debug dumps: detection (MAX_FEATURE_NUM 1200, radius 5, :1171-1174), description, matching and the
+// solver all run on the device, `chunk` frames per batch.
+OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images,
+                                 int chunk = 64, uint64_t ransac_seed = 0);
+
+}  // namespace viso

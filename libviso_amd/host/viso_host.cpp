@@ -322,3 +322,156 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
 }
 
 }  // namespace viso
+
+// ---------------------------------------------------------------------------
+// Front-end mirror
+#include <cstdio>
+
+namespace viso {
+
+Image imread_pgm(const std::string& file_name) {
+    Image im;
+    FILE* fp = std::fopen(file_name.c_str(), "rb");
+    if (!fp) return im;
+    auto token = [&](int& v) {   // next integer, skipping whitespace and '#' comments
+        int c = std::fgetc(fp);
+        for (;;) {
+            while (c == ' ' || c == '\n' || c == '\r' || c == '\t') c = std::fgetc(fp);
+            if (c == '#') { while (c != '\n' && c != EOF) c = std::fgetc(fp); continue; }
+            break;
+        }
+        if (c < '0' || c > '9') return false;
+        v = 0;
+        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = std::fgetc(fp); }
+        return true;   // the single whitespace after the token has been consumed
+    };
+    int w = 0, h = 0, maxv = 0;
+    const bool magic = std::fgetc(fp) == 'P' && std::fgetc(fp) == '5';
+    if (magic && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv > 0 && maxv <= 255) {
+        im.data.resize((size_t)w * h);
+        if (std::fread(im.data.data(), 1, im.data.size(), fp) == im.data.size()) { im.rows = h; im.cols = w; }
+        else im.data.clear();
+    }
+    std::fclose(fp);
+    return im;
+}
+
+HarrisBinnedFeatureDetector::HarrisBinnedFeatureDetector(int radius, int n, int nbinx, int nbiny, float k,
+                                                         int block_size, int aperture_size)
+    : m_radius(radius), m_nbinx(nbinx), m_nbiny(nbiny), m_block_size(block_size),
+      m_aperture_size(aperture_size), m_n(n), m_k(k) {
+    if (nbinx <= 0 || nbiny <= 0) throw std::invalid_argument("HarrisBinnedFeatureDetector: nbinx>0 && nbiny>0");   // :920
+    if (block_size != 3 || aperture_size != 5) throw std::invalid_argument("HarrisBinnedFeatureDetector: only block_size 3 / aperture_size 5 (the reference's values, :915-916)");
+}
+
+void HarrisBinnedFeatureDetector::detect(const Image& image, KeyPoints& kp) const {
+    if (image.empty()) throw std::invalid_argument("detect: empty image");
+    std::vector<float> xy((size_t)std::max(1, m_n) * 2), resp((size_t)std::max(1, m_n));
+    int n = 0;
+    int r = viso_detect_harris_binned(image.data.data(), image.rows, image.cols, m_n, m_nbinx, m_nbiny, (double)m_k,
+                                      xy.data(), resp.data(), &n);
+    if (r == VISO_ERR_ARG) throw std::invalid_argument("detect: stridex>0 && stridey>0");   // :934
+    hip_check(r, "detect");
+    for (int i = 0; i < n; ++i) {   // :964-971 (the reference appends)
+        KeyPoint k;
+        k.pt.x = xy[(size_t)2 * i]; k.pt.y = xy[(size_t)2 * i + 1];
+        k.response = resp[(size_t)i];
+        k.size = (float)(2 * m_radius + 1);
+        kp.push_back(k);
+    }
+}
+
+void MyFeatureExtractor::compute(const Image& image, KeyPoints& kp, Descriptors& d) const {
+    if (image.empty()) throw std::invalid_argument("compute: empty image");
+    d.create((int)kp.size(), descriptorSize());
+    if (kp.empty()) return;
+    std::vector<float> xy = kp2mat(kp);
+    hip_check(viso_extract_descriptors(image.data.data(), image.rows, image.cols, xy.data(), (int)kp.size(),
+                                       m_descriptor_radius, d.ptr()), "compute");
+}
+
+static std::string format_mask(const std::string& mask, int index) {
+    char buf[4096];
+    std::snprintf(buf, sizeof(buf), mask.c_str(), index);   // boost::format(mask) % index, src/viso.h:90-91
+    return buf;
+}
+
+StereoImageGenerator::result_type StereoImageGenerator::operator()() {
+    if (m_index > m_end) return std::nullopt;
+    Image a = imread_pgm(format_mask(m_mask.first, m_index)), b = imread_pgm(format_mask(m_mask.second, m_index));
+    m_index++;
+    if (a.empty() || b.empty()) return std::nullopt;
+    return std::make_pair(std::move(a), std::move(b));
+}
+
+OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images, int chunk,
+                                 uint64_t ransac_seed) {
+    if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("sequence_odometry: P1,P2 must be 3x4");
+    if (chunk < 1) chunk = 1;
+    const int MAX_FEATURE_NUM = 1200;                                   // :1171
+    HarrisBinnedFeatureDetector detector(5, MAX_FEATURE_NUM);           // :1172
+    Matd F = F_from_P(P1, P2);
+    param prm;
+    prm.base = std::fabs(P2.at(0, 3) / P2.at(0, 0));
+    prm.calib.f = P1.at(0, 0); prm.calib.cu = P1.at(0, 2); prm.calib.cv = P1.at(1, 2);
+    viso_match_params st = to_abi(MatchParams(F)), tm = to_abi(MatchParams());
+    viso_param vp = to_abi(prm);
+    OdometryResult out;
+    out.poses.push_back(Matd::eye(4));
+    out.frame_of_pose.push_back(0);
+    Ctx ctx;
+    std::vector<std::pair<Image, Image>> buf;
+    int global0 = 0;
+    bool eos = false;
+    double pose[16];
+    std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
+    while (!eos) {
+        while ((int)buf.size() < chunk + 1) {
+            StereoImageGenerator::result_type f = images();
+            if (!f) { eos = true; break; }
+            buf.push_back(std::move(*f));
+        }
+        const int nf = (int)buf.size();
+        if (nf == 0 || (nf == 1 && global0 > 0)) break;
+        const int rows = buf[0].first.rows, cols = buf[0].first.cols;
+        std::vector<uint8_t> img((size_t)nf * 2 * rows * cols);
+        for (int t = 0; t < nf; ++t)
+            for (int side = 0; side < 2; ++side) {
+                const Image& im = side ? buf[(size_t)t].second : buf[(size_t)t].first;
+                if (im.rows != rows || im.cols != cols) throw std::invalid_argument("sequence_odometry: image size changes inside a sequence");
+                std::memcpy(img.data() + ((size_t)t * 2 + side) * rows * cols, im.data.data(), (size_t)rows * cols);
+            }
+        viso_batch* b = viso_batch_create(ctx.c, nf, MAX_FEATURE_NUM, VISO_DESC_LEN);
+        if (!b) throw std::runtime_error(std::string("viso_batch_create: ") + viso_last_error());
+        std::vector<double> tr((size_t)nf * 6);
+        std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        int r = viso_batch_upload_images(b, 0, nf, img.data(), rows, cols, nullptr, nullptr);
+        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
+        if (r >= 0) r = viso_batch_detect(b, detector.n(), detector.nbinx(), detector.nbiny(), (double)detector.k());   // :1226-1227
+        if (r >= 0) r = viso_batch_run_images(b, 0);                                                                    // :1230-1313
+        if (r >= 0) r = viso_batch_get_poses(b, tr.data(), ok.data(), ninl.data());
+        viso_batch_destroy(b);
+        hip_check(r, "sequence_odometry");
+        for (int t = (global0 == 0 ? 0 : 1); t < nf; ++t) {
+            out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
+            out.n_inliers.push_back(t == 0 ? 0 : ninl[(size_t)t]);
+            std::array<double, 6> a{};
+            if (t > 0) for (int j = 0; j < 6; ++j) a[(size_t)j] = tr[(size_t)t * 6 + j];
+            out.tr.push_back(a);
+            if (t > 0 && ok[(size_t)t]) {
+                viso_pose_update(pose, a.data(), pose);
+                Matd Pm(4, 4);
+                std::memcpy(Pm.ptr(), pose, sizeof(pose));
+                out.poses.push_back(Pm);
+                out.frame_of_pose.push_back(global0 + t);
+            }
+        }
+        std::pair<Image, Image> last = std::move(buf.back());
+        buf.clear();
+        buf.push_back(std::move(last));
+        global0 += nf - 1;
+    }
+    return out;
+}
+
+}  // namespace viso

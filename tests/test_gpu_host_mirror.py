@@ -52,3 +52,44 @@ def test_demo_pose_file_matches_oracle_chain(oracle, tmp_path):
             assert np.abs(g - p[:3].reshape(-1)).max() < 2e-6 + 1e-5 * np.abs(p).max()   # "%lf" = 6 decimals
         results.append(got)
     assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+
+
+def test_kitti_driver_on_images(oracle, tmp_path):
+    """viso_kitti = the reference's `kitti` executable (src/kitti.cpp:79-118) on the GPU pipeline:
+    $KITTI_HOME/sequences/<seq>/{calib.txt,image_0,image_1} (PGM) in, results/<seq>/<sha>/data/<seq>.txt out.
+    Expected poses: oracle detector + extractor + loop body, chained on the host."""
+    exe = os.path.join(os.path.dirname(libviso_amd.SO_PATH), "viso_kitti")
+    if not os.path.exists(exe):
+        pytest.fail("libviso_amd/viso_kitti is missing: run __graft_entry__.build()")
+    seq = synth.make_image_sequence(12, 6, n_kp=1500, width=720, height=240)
+    home = str(tmp_path)
+    base = os.path.join(home, "sequences", "07")
+    for side in (0, 1):
+        os.makedirs(os.path.join(base, f"image_{side}"))
+        for t in range(6):
+            with open(os.path.join(base, f"image_{side}", "%06d.pgm" % t), "wb") as f:
+                f.write(b"P5\n# synthetic\n720 240\n255\n" + seq["images"][t, side].tobytes())
+    with open(os.path.join(base, "calib.txt"), "w") as f:
+        for name, P in (("P0", seq["P1"]), ("P1", seq["P2"]), ("P2", seq["P1"]), ("P3", seq["P2"])):
+            f.write(name + ": " + " ".join("%.12e" % v for v in P.reshape(-1)) + "\n")
+    nf, cap = 6, 1200
+    kp = np.zeros((nf, 2, cap, 2), np.float32); n = np.zeros((nf, 2), np.int32); desc = np.zeros((nf, 2, cap, 121), np.float32)
+    for t in range(nf):
+        for side in range(2):
+            k, _ = oracle.detect_harris_binned(seq["images"][t, side])
+            n[t, side] = len(k); kp[t, side, :len(k)] = k
+            desc[t, side, :len(k)] = oracle.extract_descriptors(seq["images"][t, side], k)
+    st, tm = MatchParams.stereo(oracle.F_from_P(seq["P1"], seq["P2"])), MatchParams.temporal()
+    want = oracle.sequence(kp, desc, n, st, tm, seq["param"], seed=0)
+    poses, valid = hostmath.chain_poses(want["tr"], want["ok"])
+    env = dict(os.environ, KITTI_HOME=home)
+    r = subprocess.run([exe, "abc123", "07"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(os.path.join(home, "results", "07", "abc123", "data", "07.txt")).reshape(-1, 12)
+    assert got.shape[0] == len(poses) == 6
+    for g, p in zip(got, poses):
+        assert np.abs(g - p[:3].reshape(-1)).max() < 2e-6 + 1e-5 * np.abs(p).max()
+    # begin/end arguments (src/kitti.cpp:86-94): frames 2..4 only -> identity + 2 poses
+    r = subprocess.run([exe, "sub", "07", "2", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert np.loadtxt(os.path.join(home, "results", "07", "sub", "data", "07.txt")).reshape(-1, 12).shape[0] == 3
