@@ -12,7 +12,7 @@
 #define VISO_QCAP 256         // per-wave candidate queue entries
 #define VISO_QPB 32           // queries per workgroup in the matcher
 #define VISO_MATCH_THREADS 256
-#define VISO_KPCAP 1024       // target-window keypoints staged in LDS per query tile
+#define VISO_KPCAP 768        // target-window keypoints staged in LDS per query tile
 #define VISO_NB 256           // column buckets of the per-image x index
 #define VISO_SORT_MAX 16384   // keypoints per image / queries per call (LDS bitonic sorts)
 

@@ -593,7 +593,7 @@ struct MatchArgs {
 // waves per SIMD to hide the L2 gather latency); each instantiation skips the
 // problems of the other kind.
 template <bool GENERAL, int EPI>
-__global__ __attribute__((amdgpu_waves_per_eu(7, 7))) __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
     __shared__ float2 s_kp[VISO_KPCAP];
     __shared__ int s_idx[VISO_KPCAP];
