@@ -32,14 +32,6 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// sum over each group of 8 consecutive lanes, result in every lane of the group
-__device__ __forceinline__ uint32_t row8_sum(uint32_t v) {
-    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);  // row_half_mirror (quads are uniform by now)
-    return v;
-}
-
 // ------------------------------------------------------------------ x-sort
 // One workgroup per image.  Keys (sortable(x) << 32 | index) in LDS, bitonic
 // network; NaN x sorts last.  Also builds a 256-bucket column index so that a
@@ -255,58 +247,79 @@ struct TrackT {
 // ------------------------------------------------------------------ scorers
 // Queue entries: (sorted target position p, float bits of the keypoint distance).
 //
-// Fast path: 8 lanes per candidate, two 16-B loads each (chunks sub and sub+8
-// of the 256-B row: every load instruction touches whole 128-B lines),
-// 8 x v_sad_u16, 3 DPP adds; 8 candidates per wave pass, two passes in flight.
+// Fast path: VISO_LPC lanes per candidate, 16 / VISO_LPC 16-B loads each (load k of
+// lane `sub` fetches chunk k * VISO_LPC + sub of the 256-B row, so the lanes of a
+// candidate read VISO_LPC * 16 contiguous bytes per instruction), v_sad_u16 chain,
+// log2(VISO_LPC) DPP adds; 64 / VISO_LPC candidates per wave pass.
+// Measured (MI355X, bench.py defaults): 8 lanes -> 0.90 ms per launch, 4 lanes -> 1.24 ms although it
+// issues fewer instructions: every load then touches 16 rows and only half of each 128-B line.
+#ifndef VISO_LPC
+#define VISO_LPC 8
+#endif
+#define VISO_CPP (64 / VISO_LPC)                 // candidates per wave pass
+#define VISO_NQ (16 / VISO_LPC)                  // 16-B chunks per lane
+#define VISO_NPASS (VISO_LPC == 8 ? 2 : 1)       // passes whose loads are in flight together (16 candidates)
+
+__device__ __forceinline__ uint32_t lpc_sum(uint32_t v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+#if VISO_LPC == 8
+    v += dpp_mov<0x141>(v);  // row_half_mirror (quads are uniform by now)
+#endif
+    return v;
+}
+
 struct ScorerU16 {
     const uint16_t* d2;
     const int* sidx2;
-    uint4 q0, q1;   // this lane's 16 query elements
+    uint4 q[VISO_NQ];   // this lane's query elements
     int g, sub;
     __device__ __forceinline__ void begin(const MatchProblem& P, int j, int lane) {
-        g = lane >> 3; sub = lane & 7;
+        g = lane / VISO_LPC; sub = lane % VISO_LPC;
         d2 = P.t.rows; sidx2 = P.t.sidx;
         const uint16_t* qr = P.q.rows + (size_t)j * VISO_ROW + sub * 8;
-        q0 = *reinterpret_cast<const uint4*>(qr);
-        q1 = *reinterpret_cast<const uint4*>(qr + 64);
+#pragma unroll
+        for (int k = 0; k < VISO_NQ; ++k) q[k] = *reinterpret_cast<const uint4*>(qr + k * VISO_LPC * 8);
     }
-    __device__ __forceinline__ uint32_t sad_row(const uint4& r0, const uint4& r1) const {
-        uint32_t s = __builtin_amdgcn_sad_u16(r0.x, q0.x, 0u);
-        s = __builtin_amdgcn_sad_u16(r0.y, q0.y, s);
-        s = __builtin_amdgcn_sad_u16(r0.z, q0.z, s);
-        s = __builtin_amdgcn_sad_u16(r0.w, q0.w, s);
-        s = __builtin_amdgcn_sad_u16(r1.x, q1.x, s);
-        s = __builtin_amdgcn_sad_u16(r1.y, q1.y, s);
-        s = __builtin_amdgcn_sad_u16(r1.z, q1.z, s);
-        s = __builtin_amdgcn_sad_u16(r1.w, q1.w, s);
-        return row8_sum(s);
+    __device__ __forceinline__ void load_row(uint32_t p, uint4 (&r)[VISO_NQ]) const {
+        const uint16_t* row = d2 + (size_t)p * VISO_ROW + sub * 8;
+#pragma unroll
+        for (int k = 0; k < VISO_NQ; ++k) r[k] = *reinterpret_cast<const uint4*>(row + k * VISO_LPC * 8);
+    }
+    __device__ __forceinline__ uint32_t sad_row(const uint4 (&r)[VISO_NQ]) const {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < VISO_NQ; ++k) {
+            s = __builtin_amdgcn_sad_u16(r[k].x, q[k].x, s);
+            s = __builtin_amdgcn_sad_u16(r[k].y, q[k].y, s);
+            s = __builtin_amdgcn_sad_u16(r[k].z, q[k].z, s);
+            s = __builtin_amdgcn_sad_u16(r[k].w, q[k].w, s);
+        }
+        return lpc_sum(s);
     }
     __device__ __forceinline__ void score_fast(const uint2* queue, int n, TrackT& t) const {
-        for (int b = 0; b < n; b += 16) {
-            uint2 e[2];
-            uint4 r0[2], r1[2];
+        for (int b = 0; b < n; b += VISO_CPP * VISO_NPASS) {
+            uint2 e[VISO_NPASS];
+            uint4 r[VISO_NPASS][VISO_NQ];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                e[p] = queue[min(b + p * 8 + g, n - 1)];
-                const uint16_t* row = d2 + (size_t)e[p].x * VISO_ROW + sub * 8;
-                r0[p] = *reinterpret_cast<const uint4*>(row);
-                r1[p] = *reinterpret_cast<const uint4*>(row + 64);
+            for (int p = 0; p < VISO_NPASS; ++p) {
+                e[p] = queue[min(b + p * VISO_CPP + g, n - 1)];
+                load_row(e[p].x, r[p]);
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const uint32_t s = sad_row(r0[p], r1[p]);
-                t.add((b + p * 8 + g) < n ? s : 0xffffffffu, e[p].x);
+            for (int p = 0; p < VISO_NPASS; ++p) {
+                const uint32_t s = sad_row(r[p]);
+                t.add((b + p * VISO_CPP + g) < n ? s : 0xffffffffu, e[p].x);
             }
         }
     }
     __device__ __forceinline__ void score_exact(const uint2* queue, int n, TrackU& t) const {
-        for (int b = 0; b < n; b += 8) {
+        for (int b = 0; b < n; b += VISO_CPP) {
             const uint2 e = queue[min(b + g, n - 1)];
-            const uint16_t* row = d2 + (size_t)e.x * VISO_ROW + sub * 8;
-            const uint4 r0 = *reinterpret_cast<const uint4*>(row);
-            const uint4 r1 = *reinterpret_cast<const uint4*>(row + 64);
+            uint4 r[VISO_NQ];
+            load_row(e.x, r);
             const uint32_t oi = (uint32_t)sidx2[e.x];
-            const uint32_t s = sad_row(r0, r1);
+            const uint32_t s = sad_row(r);
             t.add((b + g) < n ? s : 0xffffffffu, e.y, oi);
         }
     }
@@ -314,7 +327,7 @@ struct ScorerU16 {
 
 __device__ __forceinline__ void merge_groups(TrackT& t) {
 #pragma unroll
-    for (int m = 8; m <= 32; m <<= 1) {
+    for (int m = VISO_LPC; m <= 32; m <<= 1) {
         const uint32_t od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
         const uint32_t obp = __shfl_xor(t.bp, m), ot = __shfl_xor(t.tie, m);
         t.merge(od1, od2, obp, ot);
@@ -322,7 +335,7 @@ __device__ __forceinline__ void merge_groups(TrackT& t) {
 }
 __device__ __forceinline__ void merge_groups(TrackU& t) {
 #pragma unroll
-    for (int m = 8; m <= 32; m <<= 1) {
+    for (int m = VISO_LPC; m <= 32; m <<= 1) {
         const uint32_t od1 = __shfl_xor(t.d1, m), od2 = __shfl_xor(t.d2, m);
         const uint32_t okd = __shfl_xor(t.kd, m), oki = __shfl_xor(t.ki, m);
         t.merge(od1, od2, okd, oki);
