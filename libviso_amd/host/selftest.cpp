@@ -93,6 +93,11 @@ int main(int argc, char** argv) {
         CHECK(std::fgets(line, sizeof line, fp) && std::string(line).substr(0, 37) == "1.000000 0.000000 0.000000 1.234568 0");
         std::fclose(fp);
     }
+    for (int i = 2; i + 1 < argc; i += 2) {   // pairs (png, pgm) that must decode to the same pixels
+        Image a = imread_gray(argv[i]), b = imread_gray(argv[i + 1]);
+        CHECK(!a.empty() && !b.empty() && a.rows == b.rows && a.cols == b.cols && a.data == b.data);
+    }
+    CHECK(imread_gray("/nonexistent/file.png").empty());
     std::printf(fails ? "selftest: %d failure(s)\n" : "selftest ok\n", fails);
     return fails ? 1 : 0;
 }

@@ -140,9 +140,11 @@ struct Image {
     std::vector<uint8_t> data;
     bool empty() const { return data.empty(); }
 };
-// Binary PGM (P5, maxval <= 255).  KITTI ships PNG; convert once (e.g. `mogrify -format pgm`):
-// this build has no PNG decoder and the reference's cv::imread is out of scope.
+// Binary PGM (P5, maxval <= 255).
 Image imread_pgm(const std::string& file_name);
+// cv::imread(name, CV_LOAD_IMAGE_GRAYSCALE) for the formats the path meets: 8-bit non-interlaced PNG
+// (KITTI's image_0/%06d.png; own decoder in png_read.hpp) by extension, otherwise binary PGM.
+Image imread_gray(const std::string& file_name);
 
 // HarrisBinnedFeatureDetector, src/viso.cpp:911-979.  `k` is stored (the
 // reference forgets to, :915-919); block_size 3 / aperture_size 5 are what the

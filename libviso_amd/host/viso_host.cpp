@@ -327,6 +327,8 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
 // Front-end mirror
 #include <cstdio>
 
+#include "png_read.hpp"
+
 namespace viso {
 
 Image imread_pgm(const std::string& file_name) {
@@ -354,6 +356,16 @@ Image imread_pgm(const std::string& file_name) {
     }
     std::fclose(fp);
     return im;
+}
+
+Image imread_gray(const std::string& file_name) {
+    const size_t n = file_name.size();
+    if (n >= 4 && (file_name.compare(n - 4, 4, ".png") == 0 || file_name.compare(n - 4, 4, ".PNG") == 0)) {
+        Image im;
+        if (!read_png_gray(file_name, im.rows, im.cols, im.data)) { im.rows = im.cols = 0; im.data.clear(); }
+        return im;
+    }
+    return imread_pgm(file_name);
 }
 
 HarrisBinnedFeatureDetector::HarrisBinnedFeatureDetector(int radius, int n, int nbinx, int nbiny, float k,
@@ -398,7 +410,7 @@ static std::string format_mask(const std::string& mask, int index) {
 
 StereoImageGenerator::result_type StereoImageGenerator::operator()() {
     if (m_index > m_end) return std::nullopt;
-    Image a = imread_pgm(format_mask(m_mask.first, m_index)), b = imread_pgm(format_mask(m_mask.second, m_index));
+    Image a = imread_gray(format_mask(m_mask.first, m_index)), b = imread_gray(format_mask(m_mask.second, m_index));
     m_index++;
     if (a.empty() || b.empty()) return std::nullopt;
     return std::make_pair(std::move(a), std::move(b));

@@ -1,7 +1,7 @@
 // viso_kitti — the reference's `kitti` driver (src/kitti.cpp:79-118) on the GPU
-// pipeline: $KITTI_HOME/sequences/<seq>/{calib.txt,image_0/%06d.pgm,image_1/%06d.pgm}
-// in, $KITTI_HOME/results/<seq>/<result_sha>/data/<seq>.txt out.  Images are
-// binary PGM (KITTI's PNGs converted once; no PNG decoder in this build).
+// pipeline: $KITTI_HOME/sequences/<seq>/{calib.txt,image_0/%06d.png,image_1/%06d.png}
+// in, $KITTI_HOME/results/<seq>/<result_sha>/data/<seq>.txt out.  Images: KITTI's 8-bit
+// grayscale PNGs (image_0/%06d.png, own decoder) or binary PGM (image_0/%06d.pgm).
 //
 //   KITTI_HOME=... viso_kitti result_sha seq_name [begin [end]]
 #include <climits>
@@ -31,7 +31,13 @@ int main(int argc, char** argv) {
     const std::string result_dir = std::string(home) + "/results/" + seq_name + "/" + result_sha;   // :100
     viso::Matd P1, P2;
     if (!viso::loadCalib(seq_base + "/calib.txt", P1, P2)) { std::fprintf(stderr, "cannot read %s/calib.txt\n", seq_base.c_str()); return 2; }
-    viso::StereoImageGenerator images({seq_base + "/image_0/%06d.pgm", seq_base + "/image_1/%06d.pgm"}, begin, end);   // :108-110
+    // image_0/%06d.png like the reference (:108-110); .pgm if the sequence was converted
+    char first[4096];
+    std::snprintf(first, sizeof first, (seq_base + "/image_0/%06d.png").c_str(), begin);
+    FILE* probe = std::fopen(first, "rb");
+    const std::string ext = probe ? ".png" : ".pgm";
+    if (probe) std::fclose(probe);
+    viso::StereoImageGenerator images({seq_base + "/image_0/%06d" + ext, seq_base + "/image_1/%06d" + ext}, begin, end);
     try {
         viso::OdometryResult res = viso::sequence_odometry(P1, P2, images);                    // :111
         mkdirs(result_dir + "/data");                                                          // :112-113

@@ -101,5 +101,57 @@ def test_cpp_host_mirror_selftest(tmp_path):
     exe = os.path.join(ROOT, "libviso_amd", "viso_host_selftest")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "libviso_amd", "host"), "-s"])
-    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    # PNG decoder (KITTI images are 8-bit grayscale PNG, src/kitti.cpp:108-110): every filter type,
+    # stored / fixed / dynamic deflate blocks, and an RGB image, each against the same pixels as PGM
+    import struct
+    import zlib
+    rng = np.random.default_rng(0)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    def write_png(path, img, level, ftypes):
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        flat = img.reshape(h, w * ch).astype(np.int32)
+        raw = bytearray()
+        for y in range(h):
+            ft = ftypes[y % len(ftypes)]
+            cur, up = flat[y], (flat[y - 1] if y else np.zeros(w * ch, np.int32))
+            a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+            c = np.concatenate([np.zeros(ch, np.int32), up[:-ch]])
+            if ft == 0: f = cur
+            elif ft == 1: f = cur - a
+            elif ft == 2: f = cur - up
+            elif ft == 3: f = cur - ((a + up) >> 1)
+            else:
+                pp = a + up - c
+                pa, pb, pc = np.abs(pp - a), np.abs(pp - up), np.abs(pp - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, up, c))
+                f = cur - pred
+            raw += bytes([ft]) + (f & 255).astype(np.uint8).tobytes()
+        comp = zlib.compressobj(level, zlib.DEFLATED, 15, 9, zlib.Z_FIXED if level == 1 else zlib.Z_DEFAULT_STRATEGY)
+        z = comp.compress(bytes(raw)) + comp.flush()
+        ihdr = struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2}[ch], 0, 0, 0)
+        half = len(z) // 2                                     # two IDAT chunks
+        with open(path, "wb") as fo:
+            fo.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b""))
+
+    def write_pgm(path, gray):
+        with open(path, "wb") as fo:
+            fo.write(b"P5\n%d %d\n255\n" % (gray.shape[1], gray.shape[0]) + gray.tobytes())
+
+    args = []
+    smooth = np.clip(np.cumsum(rng.normal(0, 3, (61, 97)), 1) + 128, 0, 255).astype(np.uint8)
+    for i, (level, ft) in enumerate(((0, [0]), (1, [1, 2]), (6, [0, 1, 2, 3, 4]), (9, [4]), (6, [3]))):
+        write_png(str(tmp_path / f"g{i}.png"), smooth, level, ft)
+        write_pgm(str(tmp_path / f"g{i}.pgm"), smooth)
+        args += [str(tmp_path / f"g{i}.png"), str(tmp_path / f"g{i}.pgm")]
+    rgb = rng.integers(0, 256, (20, 33, 3)).astype(np.uint8)
+    write_png(str(tmp_path / "c.png"), rgb, 6, [0, 4])
+    r64 = rgb.astype(np.int64)
+    g = ((r64[..., 0] * 4899 + r64[..., 1] * 9617 + r64[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    write_pgm(str(tmp_path / "c.pgm"), g)
+    args += [str(tmp_path / "c.png"), str(tmp_path / "c.pgm")]
+    r = subprocess.run([exe, str(tmp_path)] + args, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import libviso_amd
+import pngutil
 from libviso_amd import hostmath, synth
 from libviso_amd.abi import MatchParams
 
@@ -56,7 +57,7 @@ def test_demo_pose_file_matches_oracle_chain(oracle, tmp_path):
 
 def test_kitti_driver_on_images(oracle, tmp_path):
     """viso_kitti = the reference's `kitti` executable (src/kitti.cpp:79-118) on the GPU pipeline:
-    $KITTI_HOME/sequences/<seq>/{calib.txt,image_0,image_1} (PGM) in, results/<seq>/<sha>/data/<seq>.txt out.
+    $KITTI_HOME/sequences/<seq>/{calib.txt,image_0/%06d.png,image_1/%06d.png} in, results/<seq>/<sha>/data/<seq>.txt out.
     Expected poses: oracle detector + extractor + loop body, chained on the host."""
     exe = os.path.join(os.path.dirname(libviso_amd.SO_PATH), "viso_kitti")
     if not os.path.exists(exe):
@@ -67,8 +68,8 @@ def test_kitti_driver_on_images(oracle, tmp_path):
     for side in (0, 1):
         os.makedirs(os.path.join(base, f"image_{side}"))
         for t in range(6):
-            with open(os.path.join(base, f"image_{side}", "%06d.pgm" % t), "wb") as f:
-                f.write(b"P5\n# synthetic\n720 240\n255\n" + seq["images"][t, side].tobytes())
+            # KITTI's own layout: image_0/%06d.png, 8-bit grayscale (src/kitti.cpp:108-110)
+            pngutil.write_gray_png(os.path.join(base, f"image_{side}", "%06d.png" % t), seq["images"][t, side])
     with open(os.path.join(base, "calib.txt"), "w") as f:
         for name, P in (("P0", seq["P1"]), ("P1", seq["P2"]), ("P2", seq["P1"]), ("P3", seq["P2"])):
             f.write(name + ": " + " ".join("%.12e" % v for v in P.reshape(-1)) + "\n")
