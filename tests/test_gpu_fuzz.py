@@ -1,0 +1,68 @@
+"""Randomised differential test of viso_match_desc against the oracle: many
+small problems with adversarial structure (duplicated keypoints and patches,
+negative / fractional / huge coordinates, NaN and inf keypoints, radius 0 and
+very large radii, K from 1 to beyond n, both gates on and off, odd descriptor
+lengths, non-integer descriptors)."""
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng, F):
+    n1, n2 = int(rng.integers(1, 140)), int(rng.integers(0, 140))
+    span = float(rng.choice([8, 40, 200, 2000]))
+    kind = rng.integers(0, 5)
+    kp1 = rng.integers(0, span, (n1, 2)).astype(np.float32)
+    kp2 = rng.integers(0, span, (n2, 2)).astype(np.float32)
+    if kind == 1:                                   # fractional and negative coordinates
+        kp1 = (kp1 - span / 2 + rng.uniform(-0.5, 0.5, kp1.shape)).astype(np.float32)
+        kp2 = (kp2 - span / 2 + rng.uniform(-0.5, 0.5, kp2.shape)).astype(np.float32)
+    elif kind == 2 and n2 > 3:                      # heavy duplication of keypoints
+        kp2[:] = kp2[rng.integers(0, 3, n2)]
+        kp1[:] = kp2[rng.integers(0, n2, n1)]
+    elif kind == 3:                                 # NaN / inf / huge values sprinkled in
+        for a in (kp1, kp2):
+            if len(a):
+                a[rng.integers(0, len(a), max(1, len(a) // 10)), rng.integers(0, 2)] = rng.choice([np.nan, np.inf, -np.inf, 3e38, -1e30])
+    dlen = int(rng.choice([121, 121, 121, 1, 7, 64, 128, 130]))
+    lo, hi = (-3, 4) if rng.random() < 0.4 else (-1020, 1021)          # tiny range => many exact SAD ties
+    d1 = rng.integers(lo, hi, (n1, dlen)).astype(np.float32)
+    d2 = rng.integers(lo, hi, (n2, dlen)).astype(np.float32)
+    if n2 and rng.random() < 0.5:                   # planted matches and duplicated patches
+        k = rng.integers(0, n2, n1)
+        d1[:] = d2[k] + rng.integers(-2, 3, (n1, dlen))
+        if rng.random() < 0.5:
+            d2[rng.integers(0, n2, max(1, n2 // 4))] = d2[rng.integers(0, n2, max(1, n2 // 4))]
+    if rng.random() < 0.15:
+        d1 = (d1 * 0.5).astype(np.float32); d2 = (d2 * 0.5).astype(np.float32)   # non-integers: general path
+    mp = MatchParams.stereo(F) if rng.random() < 0.4 else MatchParams.temporal()
+    mp.enforce_2nd_best = int(rng.random() < 0.5)
+    mp.ratio_2nd_best = float(rng.choice([0.5, 0.8, 0.9, 1.0, 1.5]))
+    mp.max_neighbors = int(rng.choice([1, 2, 5, 50, 200, 250, 1000]))
+    mp.radius = float(rng.choice([0, 1, 7.5, 80, 80, 500, 1e6]))
+    mp.sampson_thresh = float(rng.choice([1.0, 1.0, 0.3, 4.0]))
+    return kp1, kp2, d1, d2, mp
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_match_desc_randomised(viso, oracle, variant):
+    F = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+    rng = np.random.default_rng(20260 + variant)
+    libviso_amd.set_matcher_variant(variant)
+    try:
+        n_nonempty = 0
+        for it in range(220):
+            kp1, kp2, d1, d2, mp = _case(rng, F)
+            want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+            got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+            assert np.array_equal(got, want), (variant, it, len(kp1), len(kp2), d1.shape[1], mp.max_neighbors, mp.radius,
+                                               mp.enforce_epipolar, mp.enforce_2nd_best)
+            n_nonempty += len(want) > 0
+        assert n_nonempty > 100
+    finally:
+        libviso_amd.set_matcher_variant(0)
