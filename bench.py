@@ -60,10 +60,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--matcher", type=int, default=0, help="0 = L2-gather kernel (default, faster), 1 = LDS tile kernel")
+    ap.add_argument("--matcher", type=int, default=0, help="0 = L2-gather kernel (default), 1 = LDS tile kernel, 2 = wave-batched gather kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true",
                     help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
+    ap.add_argument("--ab-variants", default="0,1,2", help="matcher variants timed by --ab")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
     args = ap.parse_args()
 
@@ -154,20 +155,23 @@ def main():
 
     ab = None
     if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
-        rounds = {0: [], 1: []}
+        known = {0: "match_kernel<false, 0>", 1: "match_tile_kernel", 2: "match_batch_kernel<0>"}
+        names = {int(v): known.get(int(v), "variant %s" % v) for v in args.ab_variants.split(",")}
+        rounds = {v: [] for v in names}
+        walls = {v: [] for v in names}
         for _ in range(5):
-            for v in (0, 1):
+            for v in names:
                 libviso_amd.set_matcher_variant(v)
                 batch.kernel_timing(True)
                 for _ in range(4):
                     batch.run_matcher()
                 rounds[v].append(batch.kernel_ms()[0])
                 batch.kernel_timing(False)
+                walls[v].append(timed(batch.run_matcher, 4, 0) * 1e3 / 4)
         libviso_amd.set_matcher_variant(args.matcher)
-        ab = {"kernel_ms_median": {"match_kernel<false>": float(np.median(rounds[0])),
-                                   "match_tile_kernel": float(np.median(rounds[1]))},
-              "kernel_ms_min": {"match_kernel<false>": float(np.min(rounds[0])),
-                                "match_tile_kernel": float(np.min(rounds[1]))}}
+        ab = {"timed_kernel_ms_median": {names[v]: float(np.median(rounds[v])) for v in names},
+              "run_matcher_ms_median": {names[v]: float(np.median(walls[v])) for v in names},
+              "note": "timed kernel = temporal instantiation only for variants 0 and 2, the whole u16 kernel for 1"}
 
     # ---- configs[2]: end to end (matcher + circle + RANSAC/GN) ---------------
     e2e = None

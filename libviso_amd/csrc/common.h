@@ -136,6 +136,8 @@ int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_it
                                const SolverParamsDev& sp, int cap);
 int launch_match_tile(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                       const MatchParamsDev mp[2], const int* bad);
+int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);

@@ -722,9 +722,9 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 // Measured on MI355X (bench.py --ab, 769 problems/launch): gather kernel 1.385 ms, tile kernel
 // 1.77 ms — the gather kernel is the default; the tile kernel stays for dense-keypoint studies.
 static int g_matcher_variant = 0;
-extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = variant ? 1 : 0; }
+extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = (variant >= 0 && variant <= 2) ? variant : 0; }
 extern "C" const char* viso_matcher_kernel_name(void) {
-    return g_matcher_variant == 1 ? "match_tile_kernel" : "match_kernel<false, 0>";
+    return g_matcher_variant == 1 ? "match_tile_kernel" : g_matcher_variant == 2 ? "match_batch_kernel<0>" : "match_kernel<false, 0>";
 }
 
 // layout 0: problems in any order (both instantiations enumerate all of them);
@@ -749,6 +749,10 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     if (g_matcher_variant == 1) {
         const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
         if (r < 0) return r;
+    } else if (g_matcher_variant == 2) {
+        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1);
+        if (r < 0) return r;
+        e1 = nullptr;
     } else {
         // the events bracket the temporal instantiation only: the dominant kernel
         // (2/3 of the problems, ~97 % of the scored pairs)

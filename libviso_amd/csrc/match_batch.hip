@@ -1,0 +1,359 @@
+// match_batch.hip — third implementation of the u16 matcher: same tile / window
+// / L2-gather data path as match_kernel<false, EPI> (match.hip), but every wave
+// batches the work of FOUR queries:
+//
+//   phase 1  per query: scan the tile's target window (LDS), (stereo) Sampson
+//            gate, append the surviving candidates to the wave's pair list in LDS
+//   phase 2  one uniform loop over ALL pairs of the four queries: 8 lanes per
+//            pair, two 16-B global loads of the target row + two LDS reads of
+//            the (staged) query row, 8 x v_sad_u16, 3 DPP adds, SAD -> LDS.
+//            Passes are always full and independent of each other (no per-query
+//            tracker, no tail passes, loads of consecutive passes overlap)
+//   phase 3  per query: wave-wide min / second-min / count over its SAD segment
+//
+// Same results as the other two kernels.  Irregular queries (more than K or 255
+// in-radius candidates, no room in the pair list, an exact SAD tie) go to
+// match_overflow_kernel.
+#include "common.h"
+#include "match_dev.h"
+
+#define MB_THREADS 256
+#define MB_WAVES 4
+#define MB_QPB 32          // queries per tile (same tiles as match_kernel)
+#define MB_G 4             // queries batched per wave round
+#define MB_SEG 128         // pair-list entries per query (more in-radius candidates: overflow kernel)
+#define MB_KPCAP 512       // window keypoints staged in LDS
+
+struct BatchMatchArgs {
+    const MatchProblem* probs;
+    int n_probs, bpp, gs, gf, gc, _pad;
+    const int* bad;
+    MatchParamsDev mp[2];
+};
+
+__device__ __forceinline__ uint32_t mb_wave_min(uint32_t v) {
+    const int ident = -1;
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t mb_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+template <int EPI>
+__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREADS) void match_batch_kernel(BatchMatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pairs[MB_WAVES][MB_G * MB_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_sads[MB_WAVES][MB_G * MB_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MB_WAVES][MB_G][64];
+    __shared__ float2 s_kp[MB_KPCAP];
+    __shared__ int s_idx[MB_KPCAP];
+    __shared__ float s_xr[2];
+    if (*a.bad != 0) return;
+    int prob, qblk;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        const int g = slot / a.bpp;
+        prob = ((g / a.gc) * a.gs + a.gf + g % a.gc) * 8 + xcd;
+        qblk = slot % a.bpp;
+        if (prob >= a.n_probs) return;
+    }
+    const MatchProblem P = a.probs[prob];
+    const int n1 = *P.q.n, n2 = *P.t.n;
+    const int q0 = qblk * MB_QPB;
+    if (q0 >= n1) return;
+    const int q1 = min(q0 + MB_QPB, n1);
+    const MatchParamsDev& mp = a.mp[P.pidx];
+    if ((mp.epi != 0) != (EPI != 0)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // ---- tile window (identical to match_kernel)
+    if (wave == 0) {
+        float x = (q0 + lane < q1) ? P.q.skp[q0 + lane].x : __builtin_nanf("");
+        float mn = x, mx = x;
+#pragma unroll
+        for (int m = 1; m < VISO_WAVE; m <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, m));
+            mx = fmaxf(mx, __shfl_xor(mx, m));
+        }
+        if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
+    }
+    __syncthreads();
+    int lo = 0, W = 0;
+    {
+        const float xa = s_xr[0], xb = s_xr[1];
+        const float r = mp.radius;
+        if (n2 > 0 && xa == xa && r >= 0.f) {
+            const float slack = (fabsf(xa) + fabsf(xb) + fabsf(r)) * 1e-6f + 1e-6f;
+            const float x0 = P.t.xinfo[0], scale = P.t.xinfo[1];
+            lo = P.t.bstart[bucket_of(xa - r - slack, x0, scale)];
+            W = P.t.bstart[bucket_of(xb + r + slack, x0, scale) + 1] - lo;
+        }
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);   // wave uniform by construction; tell the compiler
+    W = __builtin_amdgcn_readfirstlane(W);
+    const int wcap = min(W, MB_KPCAP);
+    // staged window, padded with NaN keypoints (never in radius) to a multiple of 128 so the scan needs no bounds test
+    const int wpad = (wcap + 127) & ~127;
+    for (int w = threadIdx.x; w < wpad; w += MB_THREADS) {
+        float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        if (w < wcap) { t2 = P.t.skp[lo + w]; s_idx[w] = P.t.sidx[lo + w]; }
+        s_kp[w] = t2;
+    }
+    float2 kp0 = make_float2(0.f, 0.f);
+    const bool has0 = n2 > 0;
+    if (has0) kp0 = P.t.skp[P.t.rank[0]];
+    __syncthreads();
+    const float radius = mp.radius;
+    const int K = mp.K;
+    // the row gathers are the hot loads: pin their address space (global_load, not flat_load)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* grow_t;
+    const grow_t trows = (grow_t)reinterpret_cast<const u32x4*>(P.t.rows);
+    uint32_t* pairs = s_pairs[wave];
+    uint32_t* sads = s_sads[wave];
+    const int g8 = lane >> 3, sub = lane & 7;
+    unsigned long long scored = 0;
+
+    // query data of the next round, loaded one round ahead (the loads land during phases 2 and 3): lane l
+    // carries keypoint and original index of query (l & 3) of the round, every lane one word of each row
+    float2 pq;
+    int po;
+    uint32_t prow[MB_G];
+#define MB_PREFETCH(JG)                                                                                   \
+    do {                                                                                                  \
+        const int j_ = (JG) + (lane & (MB_G - 1)) * MB_WAVES;                                             \
+        const int jc_ = min(j_, q1 - 1);                                                                  \
+        pq = P.q.skp[jc_];                                                                                \
+        po = j_ < q1 ? P.q.sidx[jc_] : -1;                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < MB_G; ++k_)                                               \
+            prow[k_] = reinterpret_cast<const uint32_t*>(P.q.rows + (size_t)min((JG) + k_ * MB_WAVES, q1 - 1) * VISO_ROW)[lane]; \
+    } while (0)
+    MB_PREFETCH(q0 + wave);
+
+    for (int jg = q0 + wave; jg < q1; jg += MB_WAVES * MB_G) {
+        // ---------------- phase 1: one scan of the window for the round's MB_G queries
+        float2 qk[MB_G];      // wave uniform (scalar registers)
+        int orig[MB_G], cnt[MB_G], seg_n[MB_G];
+        uint32_t thr[MB_G];
+#pragma unroll
+        for (int k = 0; k < MB_G; ++k) {
+            qk[k].x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), k));
+            qk[k].y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), k));
+            orig[k] = __builtin_amdgcn_readlane(po, k);
+            s_qrow[wave][k][lane] = prow[k];
+            cnt[k] = 0;
+            // d = |dx| + |dy| is +0, positive or NaN, so its bit pattern orders like the value and every NaN is
+            // above +inf: (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in
+            // radius: Q1, src/viso.cpp:693) or bits(radius) + 1.  Dead slots (past the tile) get 0: nothing passes.
+            uint32_t t = __float_as_uint(radius) + 1u;
+            if (has0) {
+                const float d0 = l1_kp(qk[k].x, qk[k].y, kp0);
+                if (d0 <= radius) t = __float_as_uint(d0);
+            }
+            thr[k] = orig[k] >= 0 ? t : 0u;
+        }
+        if (jg + MB_WAVES * MB_G < q1) MB_PREFETCH(jg + MB_WAVES * MB_G);
+        for (int base = 0; base < wpad; base += 2 * VISO_WAVE) {   // LDS-resident (NaN padded) part of the window
+            const float2 ta = s_kp[base + lane], tb = s_kp[base + VISO_WAVE + lane];
+            const uint32_t ea = (uint32_t)(base + lane), eb = ea + VISO_WAVE;
+#pragma unroll
+            for (int k = 0; k < MB_G; ++k) {
+                const bool ina = __float_as_uint(l1_kp(qk[k].x, qk[k].y, ta)) < thr[k];
+                const bool inb = __float_as_uint(l1_kp(qk[k].x, qk[k].y, tb)) < thr[k];
+                const unsigned long long ma = __ballot(ina), mb = __ballot(inb);
+                const int ca = __popcll(ma);
+                // a segment holds MB_SEG entries; a query that needs more is flagged below, its clamped writes are ignored
+                uint32_t* dst = pairs + k * MB_SEG;
+                if (ina) dst[min(cnt[k] + mbcnt(ma), MB_SEG - 1)] = ea;
+                if (inb) dst[min(cnt[k] + ca + mbcnt(mb), MB_SEG - 1)] = eb;
+                cnt[k] += ca + __popcll(mb);
+            }
+        }
+        if (W > wcap) {   // windows wider than MB_KPCAP (dense data only): the rest from global memory
+#pragma unroll
+            for (int k = 0; k < MB_G; ++k) {
+                for (int base = wcap; base < W; base += VISO_WAVE) {
+                    const int w = base + lane;
+                    bool in = false;
+                    if (w < W) in = __float_as_uint(l1_kp(qk[k].x, qk[k].y, P.t.skp[lo + w])) < thr[k];
+                    const unsigned long long m = __ballot(in);
+                    if (in) pairs[k * MB_SEG + min(cnt[k] + mbcnt(m), MB_SEG - 1)] = (uint32_t)w;
+                    cnt[k] += __popcll(m);
+                }
+            }
+        }
+        int flags = 0, npass = 0;
+#pragma unroll
+        for (int k = 0; k < MB_G; ++k) {
+            const bool fits = cnt[k] <= K && cnt[k] <= MB_SEG;
+            if (!fits && orig[k] >= 0) flags |= 1 << k;   // left to the overflow kernel
+            int n = fits ? cnt[k] : 0;
+            if (EPI && n > 0) {   // Sampson gate, one candidate per lane, in-place compaction of the segment
+                uint32_t* seg = pairs + k * MB_SEG;
+                int wr = 0;
+                for (int b = 0; b < n; b += VISO_WAVE) {
+                    const int i = b + lane;
+                    bool pass = false;
+                    uint32_t e = 0;
+                    if (i < n) {
+                        e = seg[i];
+                        float2 t2;
+                        if ((int)e < wcap) t2 = s_kp[e]; else t2 = P.t.skp[lo + (int)e];
+                        const double s = sampson_dev(mp.F, qk[k].x, qk[k].y, t2.x, t2.y);
+                        pass = isfinite(s) && !(s > mp.sampson_thresh);
+                    }
+                    const unsigned long long m = __ballot(pass);
+                    const int pos = wr + mbcnt(m);
+                    __builtin_amdgcn_wave_barrier();
+                    if (pass) seg[pos] = e;
+                    wr += __popcll(m);
+                }
+                n = wr;
+            }
+            seg_n[k] = n;
+            npass += (n + 7) >> 3;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase 2: score every pair of the round; one pass = 8 pairs of ONE query (segments are
+        // walked in passes of 8, the last pass of a segment re-scores its last pair in the spare lane groups),
+        {
+            static_assert(MB_G == 4, "pass -> (query, pass) mapping below is written out for 4 segments");
+            const int n0 = seg_n[0], n1s = seg_n[1], n2s = seg_n[2], n3 = seg_n[3];
+            const int P1 = (n0 + 7) >> 3, P2 = P1 + ((n1s + 7) >> 3), P3 = P2 + ((n2s + 7) >> 3);
+            // rolling pipeline: the row loads of MB_NP passes (8 pairs each) are in flight while one pass is reduced
+            constexpr int MB_NP = EPI ? 2 : 4;   // the stereo kernel scores ~3 pairs per query and needs its registers for fp64
+            u32x4 r0[MB_NP], r1[MB_NP];
+            int dst[MB_NP], qoff[MB_NP];
+#define MB_ISSUE(SLOT, T)                                                                                  \
+            do {                                                                                           \
+                const int tt_ = min((T), npass - 1);   /* passes past the end repeat the last one, store nothing */ \
+                const int kk_ = (tt_ >= P1) + (tt_ >= P2) + (tt_ >= P3);                                   \
+                const int ps_ = kk_ == 0 ? 0 : kk_ == 1 ? P1 : kk_ == 2 ? P2 : P3;                         \
+                const int nk_ = kk_ == 0 ? n0 : kk_ == 1 ? n1s : kk_ == 2 ? n2s : n3;                     \
+                const int i_ = (tt_ - ps_) * 8 + g8;                                                       \
+                const uint32_t e_ = pairs[kk_ * MB_SEG + min(i_, nk_ - 1)];                                \
+                dst[SLOT] = ((T) < npass && i_ < nk_ && sub == 0) ? kk_ * MB_SEG + i_ : -1;                \
+                qoff[SLOT] = kk_;                                                                          \
+                const grow_t row_ = trows + (size_t)(lo + (int)e_) * (VISO_ROW / 8) + sub;   /* 16 uint4 per row */ \
+                r0[SLOT] = row_[0];                                                                        \
+                r1[SLOT] = row_[8];                                                                        \
+            } while (0)
+            if (npass > 0) {
+#pragma unroll
+                for (int p = 0; p < MB_NP; ++p) MB_ISSUE(p, p);
+            }
+#define MB_REDUCE(SLOT)                                                                                   \
+            do {                                                                                           \
+                const uint32_t* qr_ = &s_qrow[wave][qoff[SLOT]][sub * 4];                                  \
+                const uint4 c0_ = *reinterpret_cast<const uint4*>(qr_);                                    \
+                const uint4 c1_ = *reinterpret_cast<const uint4*>(qr_ + 32);                               \
+                uint32_t s_ = __builtin_amdgcn_sad_u16(r0[SLOT].x, c0_.x, 0u);                             \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].y, c0_.y, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].z, c0_.z, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].w, c0_.w, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].x, c1_.x, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].y, c1_.y, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].z, c1_.z, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, c1_.w, s_);                                      \
+                s_ += mb_dpp<0xB1>(s_);                                                                    \
+                s_ += mb_dpp<0x4E>(s_);                                                                    \
+                s_ += mb_dpp<0x141>(s_);                                                                   \
+                if (dst[SLOT] >= 0) sads[dst[SLOT]] = s_;                                                  \
+            } while (0)
+            int t = 0;
+            for (; t + MB_NP < npass; t += MB_NP) {   // steady state: reduce a pass, refill its slot (no branch: the
+#pragma unroll                                        // hardware counts outstanding loads, a branch would drain them)
+                for (int p = 0; p < MB_NP; ++p) {
+                    MB_REDUCE(p);
+                    MB_ISSUE(p, t + p + MB_NP);
+                }
+            }
+            if (npass > 0) {
+#pragma unroll
+                for (int p = 0; p < MB_NP; ++p) MB_REDUCE(p);
+            }
+#undef MB_REDUCE
+#undef MB_ISSUE
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase 3: per query, min / second min (with multiplicity) / argmin / tie
+#pragma unroll
+        for (int k = 0; k < MB_G; ++k) {
+            if (orig[k] < 0) continue;
+            const int j = jg + k * MB_WAVES;
+            if (flags & (1 << k)) {
+                if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
+                continue;
+            }
+            const int n = seg_n[k], st = k * MB_SEG;
+            uint32_t r_d1 = 0xffffffffu, r_d2 = 0xffffffffu, r_w = 0, r_tie = 0;
+            for (int b = 0; b < n; b += VISO_WAVE) {
+                const bool valid = (b + lane) < n;
+                const uint32_t s = valid ? sads[st + b + lane] : 0xffffffffu;
+                const uint32_t m1 = mb_wave_min(s);
+                const bool eq = valid && s == m1;
+                const unsigned long long em = __ballot(eq);
+                const int c = __popcll(em);
+                const uint32_t m2 = mb_wave_min(eq ? 0xffffffffu : s);
+                const uint32_t wfirst = pairs[st + b + (__ffsll((long long)em) - 1)];
+                const uint32_t o2 = c > 1 ? m1 : m2;
+                if (m1 < r_d1) { r_d2 = min(r_d1, o2); r_d1 = m1; r_w = wfirst; r_tie = c > 1; }
+                else if (m1 == r_d1) { r_d2 = r_d1; r_tie = 1; }
+                else r_d2 = min(r_d2, m1);
+            }
+            if (lane == 0) {
+                if (r_tie) {
+                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // exact tie: the largest-key rule is applied by the overflow kernel
+                } else {
+                    bool accept = r_d1 != 0xffffffffu;
+                    int idx = -1;
+                    if (accept) {
+                        if ((int)r_w < wcap) idx = s_idx[r_w]; else idx = P.t.sidx[lo + (int)r_w];
+                        if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
+                            const double bd2 = r_d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)r_d2;
+                            accept = (double)r_d1 < bd2 * mp.ratio;
+                        }
+                    }
+                    P.res[orig[k]] = make_int2(accept ? idx : -1, (int)r_d1);
+                    scored += (unsigned long long)n;
+                }
+            }
+        }
+    }
+    if (lane == 0 && scored) atomicAdd(P.scored, scored);
+}
+
+int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid) {
+    BatchMatchArgs a;
+    a.probs = probs_dev;
+    a.n_probs = n_probs;
+    a.bpp = (cap_max + MB_QPB - 1) / MB_QPB;
+    a.gs = 1; a.gf = 0; a.gc = 1; a._pad = 0;
+    a.bad = bad;
+    a.mp[0] = mp[0];
+    a.mp[1] = mp[1];
+    const int groups = (n_probs + 7) / 8;
+    long long bt = (long long)groups * 8 * a.bpp, bs = bt;
+    BatchMatchArgs at = a, as = a;
+    if (layout == 1) {
+        const int g3 = (groups + 2) / 3;
+        at.gs = 3; at.gf = 1; at.gc = 2; bt = (long long)g3 * 2 * 8 * a.bpp;
+        as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
+    }
+    if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL((match_batch_kernel<0>), dim3((unsigned)bt), dim3(MB_THREADS), 0, s, at);
+    HIP_TRY(hipGetLastError());
+    if (e_mid) HIP_TRY(hipEventRecord(e_mid, s));
+    hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)bs), dim3(MB_THREADS), 0, s, as);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+

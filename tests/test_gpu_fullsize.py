@@ -93,7 +93,7 @@ def test_bench_sized_batch_properties(viso):
     b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
     """The L2-gather kernel (default) and the LDS-resident tile kernel must both
     be bit-exact: ragged counts, duplicated patches (exact SAD ties -> overflow
