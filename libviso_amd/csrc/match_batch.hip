@@ -19,9 +19,10 @@
 
 #define MB_THREADS 256
 #define MB_WAVES 4
-#define MB_QPB 32          // queries per tile (same tiles as match_kernel)
+#define MB_QPB 64          // queries per tile
 #define MB_G 4             // queries batched per wave round
 #define MB_SEG 128         // pair-list entries per query (more in-radius candidates: overflow kernel)
+#define MB_PAD 32          // list padding: 4 passes of 8 pairs (the deepest pipeline) past the last pair
 #define MB_KPCAP 512       // window keypoints staged in LDS
 
 struct BatchMatchArgs {
@@ -48,9 +49,9 @@ __device__ __forceinline__ uint32_t mb_dpp(uint32_t v) {
 }
 
 template <int EPI>
-__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREADS) void match_batch_kernel(BatchMatchArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_pairs[MB_WAVES][MB_G * MB_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_sads[MB_WAVES][MB_G * MB_SEG];
+__global__ __attribute__((amdgpu_waves_per_eu(EPI ? 5 : 6, 8))) __launch_bounds__(MB_THREADS) void match_batch_kernel(BatchMatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pairs[MB_WAVES][MB_G * MB_SEG + MB_PAD];   // + the passes the pipeline may run ahead
+    __shared__ __attribute__((aligned(16))) uint32_t s_sads[MB_WAVES][MB_G * MB_SEG + MB_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MB_WAVES][MB_G][64];
     __shared__ float2 s_kp[MB_KPCAP];
     __shared__ int s_idx[MB_KPCAP];
@@ -115,7 +116,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREA
     // the row gathers are the hot loads: pin their address space (global_load, not flat_load)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* grow_t;
-    const grow_t trows = (grow_t)reinterpret_cast<const u32x4*>(P.t.rows);
+    typedef const __attribute__((address_space(1))) char* gbytes_t;
+    // window base (scalar) + 32-bit byte offset per lane: (window position << 8) | (sub << 4)
+    const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
     uint32_t* pairs = s_pairs[wave];
     uint32_t* sads = s_sads[wave];
     const int g8 = lane >> 3, sub = lane & 7;
@@ -218,30 +221,45 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREA
                 n = wr;
             }
             seg_n[k] = n;
-            npass += (n + 7) >> 3;
+        }
+        // ---------------- phase 1b: close the gaps — segments 1..3 move down behind segment 0 (ascending, each
+        // 64-entry chunk read before it is written, destination never above the source) and get their query tag, so
+        // that the round's pairs are one contiguous list: entry = query << 30 | window position << 8
+        static_assert(MB_G == 4, "segment bookkeeping below is written out for 4 segments");
+        const int c1 = seg_n[0], c2 = c1 + seg_n[1], c3 = c2 + seg_n[2], ntot = c3 + seg_n[3];
+        {
+            const int cs[MB_G] = {0, c1, c2, c3};
+#pragma unroll
+            for (int k = 0; k < MB_G; ++k) {
+                for (int b = 0; b < seg_n[k]; b += VISO_WAVE) {
+                    const int i = b + lane;
+                    uint32_t e = 0;
+                    if (i < seg_n[k]) e = pairs[k * MB_SEG + i];
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < seg_n[k]) pairs[cs[k] + i] = (e << 8) | ((uint32_t)k << 30);   // byte offset of the row | query
+                }
+            }
+            // padding behind the list (copies of the last pair): the pipeline runs up to MB_NP - 1 passes past the
+            // end and the last pass may be partial — those lanes re-score the last pair into scratch slots
+            __builtin_amdgcn_wave_barrier();
+            if (ntot > 0 && lane < MB_PAD) pairs[ntot + lane] = pairs[ntot - 1];
         }
         __builtin_amdgcn_wave_barrier();
-        // ---------------- phase 2: score every pair of the round; one pass = 8 pairs of ONE query (segments are
-        // walked in passes of 8, the last pass of a segment re-scores its last pair in the spare lane groups),
+        // ---------------- phase 2: score every pair of the round, 8 lanes per pair, 8 consecutive pairs per pass
         {
-            static_assert(MB_G == 4, "pass -> (query, pass) mapping below is written out for 4 segments");
-            const int n0 = seg_n[0], n1s = seg_n[1], n2s = seg_n[2], n3 = seg_n[3];
-            const int P1 = (n0 + 7) >> 3, P2 = P1 + ((n1s + 7) >> 3), P3 = P2 + ((n2s + 7) >> 3);
-            // rolling pipeline: the row loads of MB_NP passes (8 pairs each) are in flight while one pass is reduced
-            constexpr int MB_NP = EPI ? 2 : 4;   // the stereo kernel scores ~3 pairs per query and needs its registers for fp64
+            npass = (ntot + 7) >> 3;
+            // rolling pipeline: the row loads of MB_NP passes are in flight while two passes are reduced
+            constexpr int MB_NP = EPI ? 2 : 4;
+            static_assert(MB_NP * 8 <= MB_PAD, "list padding must cover the pipeline depth");   // the stereo kernel scores ~3 pairs per query and needs its registers for fp64
             u32x4 r0[MB_NP], r1[MB_NP];
             int dst[MB_NP], qoff[MB_NP];
 #define MB_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
-                const int tt_ = min((T), npass - 1);   /* passes past the end repeat the last one, store nothing */ \
-                const int kk_ = (tt_ >= P1) + (tt_ >= P2) + (tt_ >= P3);                                   \
-                const int ps_ = kk_ == 0 ? 0 : kk_ == 1 ? P1 : kk_ == 2 ? P2 : P3;                         \
-                const int nk_ = kk_ == 0 ? n0 : kk_ == 1 ? n1s : kk_ == 2 ? n2s : n3;                     \
-                const int i_ = (tt_ - ps_) * 8 + g8;                                                       \
-                const uint32_t e_ = pairs[kk_ * MB_SEG + min(i_, nk_ - 1)];                                \
-                dst[SLOT] = ((T) < npass && i_ < nk_ && sub == 0) ? kk_ * MB_SEG + i_ : -1;                \
-                qoff[SLOT] = kk_;                                                                          \
-                const grow_t row_ = trows + (size_t)(lo + (int)e_) * (VISO_ROW / 8) + sub;   /* 16 uint4 per row */ \
+                const int gi_ = (T) * 8 + g8;                                                              \
+                const uint32_t e_ = pairs[gi_];                                                            \
+                dst[SLOT] = gi_;                                                                           \
+                qoff[SLOT] = (int)(e_ >> 30) * 64 + sub * 4;                                               \
+                const grow_t row_ = (grow_t)(wrows + ((e_ & 0x3fffffffu) | (uint32_t)(sub << 4)));         \
                 r0[SLOT] = row_[0];                                                                        \
                 r1[SLOT] = row_[8];                                                                        \
             } while (0)
@@ -249,37 +267,53 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREA
 #pragma unroll
                 for (int p = 0; p < MB_NP; ++p) MB_ISSUE(p, p);
             }
-#define MB_REDUCE(SLOT)                                                                                   \
+            // two passes reduced together: their DPP steps interleave and fill each other's wait states
+#define MB_REDUCE2(SA, SB)                                                                                \
             do {                                                                                           \
-                const uint32_t* qr_ = &s_qrow[wave][qoff[SLOT]][sub * 4];                                  \
-                const uint4 c0_ = *reinterpret_cast<const uint4*>(qr_);                                    \
-                const uint4 c1_ = *reinterpret_cast<const uint4*>(qr_ + 32);                               \
-                uint32_t s_ = __builtin_amdgcn_sad_u16(r0[SLOT].x, c0_.x, 0u);                             \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].y, c0_.y, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].z, c0_.z, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].w, c0_.w, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].x, c1_.x, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].y, c1_.y, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].z, c1_.z, s_);                                      \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, c1_.w, s_);                                      \
-                s_ += mb_dpp<0xB1>(s_);                                                                    \
-                s_ += mb_dpp<0x4E>(s_);                                                                    \
-                s_ += mb_dpp<0x141>(s_);                                                                   \
-                if (dst[SLOT] >= 0) sads[dst[SLOT]] = s_;                                                  \
+                const uint32_t* qa_ = &s_qrow[wave][0][0] + qoff[SA];                                      \
+                const uint32_t* qb_ = &s_qrow[wave][0][0] + qoff[SB];                                      \
+                const uint4 a0_ = *reinterpret_cast<const uint4*>(qa_);                                    \
+                const uint4 a1_ = *reinterpret_cast<const uint4*>(qa_ + 32);                               \
+                const uint4 b0_ = *reinterpret_cast<const uint4*>(qb_);                                    \
+                const uint4 b1_ = *reinterpret_cast<const uint4*>(qb_ + 32);                               \
+                uint32_t sa_ = __builtin_amdgcn_sad_u16(r0[SA].x, a0_.x, 0u);                              \
+                uint32_t sb_ = __builtin_amdgcn_sad_u16(r0[SB].x, b0_.x, 0u);                              \
+                sa_ = __builtin_amdgcn_sad_u16(r0[SA].y, a0_.y, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r0[SB].y, b0_.y, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r0[SA].z, a0_.z, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r0[SB].z, b0_.z, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r0[SA].w, a0_.w, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r0[SB].w, b0_.w, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r1[SA].x, a1_.x, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r1[SB].x, b1_.x, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r1[SA].y, a1_.y, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r1[SB].y, b1_.y, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r1[SA].z, a1_.z, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r1[SB].z, b1_.z, sb_);                                      \
+                sa_ = __builtin_amdgcn_sad_u16(r1[SA].w, a1_.w, sa_);                                      \
+                sb_ = __builtin_amdgcn_sad_u16(r1[SB].w, b1_.w, sb_);                                      \
+                sa_ += mb_dpp<0xB1>(sa_);                                                                  \
+                sb_ += mb_dpp<0xB1>(sb_);                                                                  \
+                sa_ += mb_dpp<0x4E>(sa_);                                                                  \
+                sb_ += mb_dpp<0x4E>(sb_);                                                                  \
+                sa_ += mb_dpp<0x141>(sa_);                                                                 \
+                sb_ += mb_dpp<0x141>(sb_);                                                                 \
+                if (sub == 0) { sads[dst[SA]] = sa_; sads[dst[SB]] = sb_; }   /* slots past ntot are scratch */ \
             } while (0)
             int t = 0;
-            for (; t + MB_NP < npass; t += MB_NP) {   // steady state: reduce a pass, refill its slot (no branch: the
-#pragma unroll                                        // hardware counts outstanding loads, a branch would drain them)
-                for (int p = 0; p < MB_NP; ++p) {
-                    MB_REDUCE(p);
+            for (; t + MB_NP < npass; t += MB_NP) {   // steady state: reduce two passes, refill their slots (no branch:
+#pragma unroll                                        // the hardware counts outstanding loads, a branch would drain them)
+                for (int p = 0; p < MB_NP; p += 2) {
+                    MB_REDUCE2(p, p + 1);
                     MB_ISSUE(p, t + p + MB_NP);
+                    MB_ISSUE(p + 1, t + p + 1 + MB_NP);
                 }
             }
             if (npass > 0) {
 #pragma unroll
-                for (int p = 0; p < MB_NP; ++p) MB_REDUCE(p);
+                for (int p = 0; p < MB_NP; p += 2) MB_REDUCE2(p, p + 1);
             }
-#undef MB_REDUCE
+#undef MB_REDUCE2
 #undef MB_ISSUE
         }
         __builtin_amdgcn_wave_barrier();
@@ -292,7 +326,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREA
                 if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
                 continue;
             }
-            const int n = seg_n[k], st = k * MB_SEG;
+            const int n = seg_n[k], st = k == 0 ? 0 : k == 1 ? c1 : k == 2 ? c2 : c3;
             uint32_t r_d1 = 0xffffffffu, r_d2 = 0xffffffffu, r_w = 0, r_tie = 0;
             for (int b = 0; b < n; b += VISO_WAVE) {
                 const bool valid = (b + lane) < n;
@@ -302,7 +336,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MB_THREA
                 const unsigned long long em = __ballot(eq);
                 const int c = __popcll(em);
                 const uint32_t m2 = mb_wave_min(eq ? 0xffffffffu : s);
-                const uint32_t wfirst = pairs[st + b + (__ffsll((long long)em) - 1)];
+                const uint32_t wfirst = (pairs[st + b + (__ffsll((long long)em) - 1)] & 0x3fffffffu) >> 8;
                 const uint32_t o2 = c > 1 ? m1 : m2;
                 if (m1 < r_d1) { r_d2 = min(r_d1, o2); r_d1 = m1; r_w = wfirst; r_tie = c > 1; }
                 else if (m1 == r_d1) { r_d2 = r_d1; r_tie = 1; }

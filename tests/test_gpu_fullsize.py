@@ -115,4 +115,4 @@ def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
             assert np.array_equal(b.matches(which, t), want), (variant, which, t)
         b.close(); ctx.close()
     finally:
-        libviso_amd.set_matcher_variant(0)
+        libviso_amd.set_matcher_variant(2)

@@ -65,4 +65,4 @@ def test_match_desc_randomised(viso, oracle, variant):
             n_nonempty += len(want) > 0
         assert n_nonempty > 100
     finally:
-        libviso_amd.set_matcher_variant(0)
+        libviso_amd.set_matcher_variant(2)

@@ -95,6 +95,7 @@ int main() {
     if (run<2>(rows, rpi, n_images, window, passes, blocks, out, clk)) return 1;
     if (run<4>(rows, rpi, n_images, window, passes, blocks, out, clk)) return 1;
     if (run<8>(rows, rpi, n_images, window, passes, blocks, out, clk)) return 1;
-    if (run<4>(rows, rpi, n_images, window, passes * 8, blocks / 8, out, clk)) return 1;   // fewer, longer blocks
+    for (int f = 2; f <= 32; f *= 2)   // fewer, longer blocks: the same work in blocks that live f times longer
+        if (run<4>(rows, rpi, n_images, window, passes * f, blocks / f, out, clk)) return 1;
     return 0;
 }
