@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--matcher", type=int, default=2, help="2 = wave-batched gather kernel (default), 0 = per-query gather kernel, 1 = LDS tile kernel")
+    ap.add_argument("--matcher", type=int, default=3, help="3 = union kernel (default: one row load scored against 4 queries), 2 = wave-batched gather kernel, 0 = per-query gather kernel, 1 = LDS tile kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true",
                     help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
@@ -139,7 +139,7 @@ def main():
     kname = libviso_amd.load().viso_matcher_kernel_name().decode()
     # the timed kernel: the temporal instantiation of the gather matcher (2 of the 3 match_desc calls
     # per frame, ~97 % of the scored pairs) or the tile kernel, which handles all three
-    temporal_only = kname in ("match_kernel<false, 0>", "match_batch_kernel<0>")
+    temporal_only = kname in ("match_kernel<false, 0>", "match_batch_kernel<0>", "match_union_kernel")
     balg = balg_temporal if temporal_only else balg_stereo + balg_temporal
     pairs = int(scored[1:].sum()) if temporal_only else int(scored.sum())
     achieved = balg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -156,7 +156,7 @@ def main():
 
     ab = None
     if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
-        known = {0: "match_kernel<false, 0>", 1: "match_tile_kernel", 2: "match_batch_kernel<0>"}
+        known = {0: "match_kernel<false, 0>", 1: "match_tile_kernel", 2: "match_batch_kernel<0>", 3: "match_union_kernel"}
         names = {int(v): known.get(int(v), "variant %s" % v) for v in args.ab_variants.split(",")}
         rounds = {v: [] for v in names}
         walls = {v: [] for v in names}

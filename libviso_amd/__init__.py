@@ -118,7 +118,7 @@ def _i32(a):
 
 
 def set_matcher_variant(v):
-    """2 = wave-batched gather kernel (default), 0 = per-query gather kernel, 1 = LDS-resident tile kernel; same results."""
+    """3 = union kernel (default), 2 = wave-batched gather kernel, 0 = per-query gather kernel, 1 = LDS-resident tile kernel; same results."""
     load().viso_debug_set_matcher(int(v))
 
 

@@ -136,8 +136,15 @@ int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_it
                                const SolverParamsDev& sp, int cap);
 int launch_match_tile(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                       const MatchParamsDev mp[2], const int* bad);
+struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_kernel (tiles of 64 queries)
+    const MatchProblem* probs;
+    int n_probs, bpp, gs, gf, gc, _pad;
+    const int* bad;
+    MatchParamsDev mp[2];
+};
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid);
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int union_temporal);
+int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);

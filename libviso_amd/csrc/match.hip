@@ -721,10 +721,11 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 // Same results; kept switchable so the two can be timed against each other in one process.
 // Measured on MI355X (bench.py --ab, 769 problems/launch): gather kernel 1.385 ms, tile kernel
 // 1.77 ms — the gather kernel is the default; the tile kernel stays for dense-keypoint studies.
-static int g_matcher_variant = 2;
-extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = (variant >= 0 && variant <= 2) ? variant : 0; }
+static int g_matcher_variant = 3;
+extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = (variant >= 0 && variant <= 3) ? variant : 0; }
 extern "C" const char* viso_matcher_kernel_name(void) {
-    return g_matcher_variant == 1 ? "match_tile_kernel" : g_matcher_variant == 2 ? "match_batch_kernel<0>" : "match_kernel<false, 0>";
+    return g_matcher_variant == 1 ? "match_tile_kernel" : g_matcher_variant == 2 ? "match_batch_kernel<0>" :
+           g_matcher_variant == 3 ? "match_union_kernel" : "match_kernel<false, 0>";
 }
 
 // layout 0: problems in any order (both instantiations enumerate all of them);
@@ -749,8 +750,8 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     if (g_matcher_variant == 1) {
         const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
         if (r < 0) return r;
-    } else if (g_matcher_variant == 2) {
-        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1);
+    } else if (g_matcher_variant == 2 || g_matcher_variant == 3) {
+        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, g_matcher_variant == 3);
         if (r < 0) return r;
         e1 = nullptr;
     } else {

@@ -25,12 +25,6 @@
 #define MB_PAD 32          // list padding: 4 passes of 8 pairs (the deepest pipeline) past the last pair
 #define MB_KPCAP 512       // window keypoints staged in LDS
 
-struct BatchMatchArgs {
-    const MatchProblem* probs;
-    int n_probs, bpp, gs, gf, gc, _pad;
-    const int* bad;
-    MatchParamsDev mp[2];
-};
 
 __device__ __forceinline__ uint32_t mb_wave_min(uint32_t v) {
     const int ident = -1;
@@ -41,6 +35,15 @@ __device__ __forceinline__ uint32_t mb_wave_min(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// bits of |qx - tx| + |qy - ty| (cvflann::L1 order, see l1_kp): the absolute values ride on the add as source
+// modifiers — left to the compiler the two differences are packed and the abs becomes two v_and
+__device__ __forceinline__ uint32_t mb_l1_bits(float qx, float qy, float2 t) {
+    const float dx = qx - t.x, dy = qy - t.y;
+    float d;
+    asm("v_add_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(dx), "v"(dy));
+    return __float_as_uint(d);
 }
 
 template <int CTRL>
@@ -168,8 +171,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(EPI ? 5 : 6, 8))) __launch_bounds_
             const uint32_t ea = (uint32_t)(base + lane), eb = ea + VISO_WAVE;
 #pragma unroll
             for (int k = 0; k < MB_G; ++k) {
-                const bool ina = __float_as_uint(l1_kp(qk[k].x, qk[k].y, ta)) < thr[k];
-                const bool inb = __float_as_uint(l1_kp(qk[k].x, qk[k].y, tb)) < thr[k];
+                const bool ina = mb_l1_bits(qk[k].x, qk[k].y, ta) < thr[k];
+                const bool inb = mb_l1_bits(qk[k].x, qk[k].y, tb) < thr[k];
                 const unsigned long long ma = __ballot(ina), mb = __ballot(inb);
                 const int ca = __popcll(ma);
                 // a segment holds MB_SEG entries; a query that needs more is flagged below, its clamped writes are ignored
@@ -365,7 +368,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(EPI ? 5 : 6, 8))) __launch_bounds_
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid) {
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int union_temporal) {
     BatchMatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
@@ -383,8 +386,13 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
     }
     if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL((match_batch_kernel<0>), dim3((unsigned)bt), dim3(MB_THREADS), 0, s, at);
-    HIP_TRY(hipGetLastError());
+    if (union_temporal) {
+        const int r = launch_match_union_temporal(s, at, bt);
+        if (r < 0) return r;
+    } else {
+        hipLaunchKernelGGL((match_batch_kernel<0>), dim3((unsigned)bt), dim3(MB_THREADS), 0, s, at);
+        HIP_TRY(hipGetLastError());
+    }
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, s));
     hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)bs), dim3(MB_THREADS), 0, s, as);
     HIP_TRY(hipGetLastError());

@@ -93,7 +93,7 @@ def test_bench_sized_batch_properties(viso):
     b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
     """The L2-gather kernel (default) and the LDS-resident tile kernel must both
     be bit-exact: ragged counts, duplicated patches (exact SAD ties -> overflow
@@ -115,4 +115,4 @@ def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
             assert np.array_equal(b.matches(which, t), want), (variant, which, t)
         b.close(); ctx.close()
     finally:
-        libviso_amd.set_matcher_variant(2)
+        libviso_amd.set_matcher_variant(3)

@@ -49,7 +49,7 @@ def _case(rng, F):
     return kp1, kp2, d1, d2, mp
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_match_desc_randomised(viso, oracle, variant):
     F = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
     rng = np.random.default_rng(20260 + variant)
@@ -65,4 +65,4 @@ def test_match_desc_randomised(viso, oracle, variant):
             n_nonempty += len(want) > 0
         assert n_nonempty > 100
     finally:
-        libviso_amd.set_matcher_variant(2)
+        libviso_amd.set_matcher_variant(3)
