@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true",
                     help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent batches in flight per GPU, one HIP stream each (steps go round robin over them)")
     ap.add_argument("--ab-variants", default="0,1,2", help="matcher variants timed by --ab")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
     args = ap.parse_args()
@@ -96,26 +98,37 @@ def main():
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
     seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
-    ctx = libviso_amd.Context(dev_index)
-    batch = libviso_amd.Batch(ctx, nf, args.kp)
-    batch.upload(seq["kp"], seq["desc"], seq["n"])
-    batch.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
+    # S independent batches per GPU, each on its own context / HIP stream: consecutive steps go to
+    # different streams, so one batch's latency-bound stages (sorts, RANSAC) overlap the next one's matcher
+    n_streams = max(1, args.streams)
+    lanes = []
+    for _ in range(n_streams):
+        c = libviso_amd.Context(dev_index)
+        b = libviso_amd.Batch(c, nf, args.kp)
+        b.upload(seq["kp"], seq["desc"], seq["n"])
+        b.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
+        lanes.append((c, b))
+    ctx, batch = lanes[0]
+
+    def sync_all():
+        for c, _ in lanes:
+            c.synchronize()
+        torch.cuda.synchronize()
 
     def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        sync_all()
         if world > 1:
             dist.barrier()
 
     def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
+        """fn(batch) is called once per step, round robin over the streams."""
+        for i in range(warmup):
+            fn(lanes[i % n_streams][1])
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        for i in range(steps):
+            fn(lanes[i % n_streams][1])
+        sync_all()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -124,13 +137,28 @@ def main():
         return dt
 
     # ---- configs[1]: matcher only ------------------------------------------
-    batch.kernel_timing(False)
-    for _ in range(args.warmup):
+    for _, b in lanes:
+        b.kernel_timing(False)
+    for i in range(max(args.warmup, n_streams)):
+        lanes[i % n_streams][1].run_matcher()
+    sync_all()
+    for _, b in lanes:
+        b.kernel_timing(True)
+    dt = timed(lambda b: b.run_matcher(), args.steps, 0)
+    kern_ms_sum, kern_n = 0.0, 0
+    for _, b in lanes:
+        ms, n = b.kernel_ms()
+        kern_ms_sum += ms * n
+        kern_n += n
+        b.kernel_timing(False)
+    kern_ms = kern_ms_sum / max(kern_n, 1)
+    # the same kernel with nothing else on the GPU (one stream, untimed): with several streams the events of
+    # the timed region also see the other streams' kernels sharing the CUs
+    batch.kernel_timing(True)
+    for _ in range(4):
         batch.run_matcher()
     ctx.synchronize()
-    batch.kernel_timing(True)
-    dt = timed(batch.run_matcher, args.steps, 0)
-    kern_ms, kern_n = batch.kernel_ms()
+    kern_ms_alone, _ = batch.kernel_ms()
     batch.kernel_timing(False)
     frames_total = args.frames * args.steps * world
     fps = frames_total / dt
@@ -168,7 +196,11 @@ def main():
                     batch.run_matcher()
                 rounds[v].append(batch.kernel_ms()[0])
                 batch.kernel_timing(False)
-                walls[v].append(timed(batch.run_matcher, 4, 0) * 1e3 / 4)
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    batch.run_matcher()
+                ctx.synchronize()
+                walls[v].append((time.perf_counter() - t0) * 1e3 / 4)
         libviso_amd.set_matcher_variant(args.matcher)
         ab = {"timed_kernel_ms_median": {names[v]: float(np.median(rounds[v])) for v in names},
               "run_matcher_ms_median": {names[v]: float(np.median(walls[v])) for v in names},
@@ -177,9 +209,7 @@ def main():
     # ---- configs[2]: end to end (matcher + circle + RANSAC/GN) ---------------
     e2e = None
     if not args.no_e2e:
-        def full():
-            batch.run()
-        dt2 = timed(full, max(1, args.steps // 2), 1)
+        dt2 = timed(lambda b: b.run(), max(1, args.steps // 2), n_streams)
         tr, ok, n_inl = batch.poses()
         if world > 1:   # the one exchange step: gather per-frame transforms (RCCL over xGMI)
             rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64)], 1), device=coll_dev)
@@ -254,11 +284,13 @@ def main():
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic {args.width}x{args.height} stereo pairs, "
                                    f"{args.kp} features/image, SAD matcher only (pack + 3 match_desc/frame + sort)",
-                       "frames_per_step_per_gpu": args.frames, "parallelism": f"frames sharded over {world} rank(s), no collective"},
+                       "frames_per_step_per_gpu": args.frames, "parallelism": f"frames sharded over {world} rank(s), no collective; {n_streams} batches in flight per GPU (one HIP stream each)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname,
                          "kernel_ms_avg": kern_ms, "kernel_launches": kern_n,
+                         "kernel_ms_single_stream": kern_ms_alone,
+                         "achieved_single_stream": balg / (kern_ms_alone * 1e-3) / 1e9 if kern_ms_alone > 0 else None,
                          "algorithmic_bytes_per_launch": balg,
                          "scored_pairs_per_launch": pairs,
                          "algorithmic_bytes_per_step_all_calls": balg_stereo + balg_temporal,
