@@ -294,8 +294,10 @@ def main():
                          "algorithmic_bytes_per_launch": balg,
                          "scored_pairs_per_launch": pairs,
                          "algorithmic_bytes_per_step_all_calls": balg_stereo + balg_temporal,
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes (f32 boundary accounting) / HIP-event kernel time; "
-                                 "a tiled kernel serves most of them from L2/LDS, so this is effective bandwidth"},
+                         "note": "achieved = SURVEY 8(d) algorithmic bytes (f32 boundary accounting) / HIP-event kernel time in the "
+                                 "timed region (with several streams the kernel shares the CUs with the other batches' kernels; "
+                                 "*_single_stream = the same launch alone); a tiled kernel serves most of the bytes from L2/LDS, "
+                                 "so this is effective bandwidth"},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
             "end_to_end_from_images": e2e_img,

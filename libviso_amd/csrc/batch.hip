@@ -25,7 +25,7 @@ struct viso_batch {
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
-    int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored;
+    int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored; size_t zeroed_bytes;
     double *x, *X, *x_c, *Xp_c;
     TriItem* tri; JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
@@ -59,8 +59,8 @@ extern "C" void viso_batch_destroy(viso_batch* b) try {
     if (!b) return;
     hipStreamSynchronize(b->ctx->stream);
     for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->ovf_cnt, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
-                    b->kp, b->desc, b->n, b->packed, b->bad, b->zero, b->probs, b->res, b->sorted,
+    void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+                    b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -168,12 +168,17 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
     A(dalloc(&b->kp, nf * 2 * c)); A(dalloc(&b->desc, nf * 2 * c * dlen)); A(dalloc(&b->n, nf * 2));
-    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->bad, 4)); A(dalloc(&b->zero, 8));
+    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->zero, 8));
     A(dalloc(&b->probs, (size_t)b->n_probs));
     A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
-    A(dalloc(&b->m_cnt, 3 * nf)); A(dalloc(&b->scored, 3 * nf)); A(dalloc(&b->ovf_cnt, 3 * nf));
+    A(dalloc(&b->m_cnt, 3 * nf));
+    // per-run counters zeroed by ONE memset: scored[3nf] (u64) | ovf_cnt[3nf] (int) | bad (int)
+    b->zeroed_bytes = 3 * nf * sizeof(unsigned long long) + (3 * nf + 4) * sizeof(int);
+    A(dalloc(&b->scored, b->zeroed_bytes / sizeof(unsigned long long) + 1));
+    b->ovf_cnt = r >= 0 ? reinterpret_cast<int*>(b->scored + 3 * nf) : nullptr;
+    b->bad = r >= 0 ? b->ovf_cnt + 3 * nf : nullptr;
     A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
     A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
@@ -186,7 +191,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
               hipMemset(b->tr, 0, nf * 6 * sizeof(double)) == hipSuccess &&
               hipMemset(b->ok, 0, nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->n_inl, 0, nf * sizeof(int)) == hipSuccess &&
-              hipMemset(b->scored, 0, 3 * nf * sizeof(unsigned long long)) == hipSuccess;
+              hipMemset(b->scored, 0, b->zeroed_bytes) == hipSuccess;
     if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_destroy(b); return nullptr; }
     return b;
 }
@@ -250,9 +255,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
         return VISO_ERR_ARG;
     }
     hipStream_t s = b->ctx->stream;
-    HIP_TRY(hipMemsetAsync(b->bad, 0, sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(b->scored, 0, sizeof(unsigned long long) * 3 * (size_t)b->nf, s));
-    HIP_TRY(hipMemsetAsync(b->ovf_cnt, 0, sizeof(int) * 3 * (size_t)b->nf, s));
+    HIP_TRY(hipMemsetAsync(b->scored, 0, b->zeroed_bytes, s));   // scored, ovf_cnt, bad
     int r;
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])

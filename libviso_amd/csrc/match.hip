@@ -583,8 +583,7 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
 // Groups of 8 problems can be strided so that a launch only enumerates the
 // problems of one kind: group = (g / gc) * gs + gf + g % gc  (batches lay the
 // problems out as [8 stereo][8 temporal-left][8 temporal-right] per 8 frames).
-__device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int gs, int gf, int gc, int& prob, int& qblk) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void block_to_problem(int b, int n_probs, int bpp, int gs, int gf, int gc, int& prob, int& qblk) {
     const int xcd = b & 7, slot = b >> 3;
     const int g = slot / bpp;
     prob = ((g / gc) * gs + gf + g % gc) * 8 + xcd;
@@ -595,6 +594,7 @@ __device__ __forceinline__ void block_to_problem(int n_probs, int bpp, int gs, i
 struct MatchArgs {
     const MatchProblem* probs;
     int n_probs, bpp, dlen, gs, gf, gc;
+    int vblocks;   // number of (problem, tile) slots; the grid may be smaller (blocks stride over the slots)
     const int* bad;
     MatchParamsDev mp[2];
 };
@@ -614,16 +614,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MAT
     // the pack kernel decides which variant does the work (no host round trip)
     const bool is_bad = *a.bad != 0;
     if (is_bad != GENERAL) return;
+    for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
+    __syncthreads();   // LDS of the previous slot is free
     int prob, qblk;
-    block_to_problem(a.n_probs, a.bpp, a.gs, a.gf, a.gc, prob, qblk);
-    if (prob < 0) return;
+    block_to_problem(vb, a.n_probs, a.bpp, a.gs, a.gf, a.gc, prob, qblk);
+    if (prob < 0) continue;
     const MatchProblem P = a.probs[prob];
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * VISO_QPB;
-    if (q0 >= n1) return;
+    if (q0 >= n1) continue;
     const int q1 = min(q0 + VISO_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
-    if ((mp.epi != 0) != (EPI != 0)) return;
+    if ((mp.epi != 0) != (EPI != 0)) continue;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // x range of the tile (queries are x-sorted; NaNs sort last and are ignored)
     if (wave == 0) {
@@ -677,6 +679,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MAT
         }
     }
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
+    }
 }
 
 // Queries whose in-radius set exceeds K or the LDS queue (dense keypoint
@@ -746,6 +749,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     const int groups = (n_probs + 7) / 8;
     const long long blocks = (long long)groups * 8 * a.bpp;
     if (blocks > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
+    a.vblocks = (int)blocks;
     if (e0) HIP_TRY(hipEventRecord(e0, s));
     if (g_matcher_variant == 1) {
         const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
@@ -764,6 +768,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
             at.gs = 3; at.gf = 1; at.gc = 2; bt = (long long)g3 * 2 * 8 * a.bpp;
             as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
         }
+        at.vblocks = (int)bt; as.vblocks = (int)bs;
         hipLaunchKernelGGL((match_kernel<false, 0>), dim3((unsigned)bt), dim3(VISO_MATCH_THREADS), 0, s, at);
         HIP_TRY(hipGetLastError());
         if (e1) { HIP_TRY(hipEventRecord(e1, s)); e1 = nullptr; }
@@ -771,9 +776,12 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         HIP_TRY(hipGetLastError());
     }
     if (e1) HIP_TRY(hipEventRecord(e1, s));
-    hipLaunchKernelGGL((match_kernel<true, 0>), dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+    // general (non-u16) path: normally idle (the pack kernel's flag is clear and every block leaves at once), so
+    // it gets a small grid that strides over the (problem, tile) slots when it does have work
+    const unsigned gblocks = (unsigned)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((match_kernel<true, 1>), dim3((unsigned)blocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+    hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(match_overflow_kernel<false>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
