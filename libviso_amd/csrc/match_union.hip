@@ -26,7 +26,7 @@
 #define MU_G 4             // queries per round
 #define MU_UCAP 256        // union list entries per round
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
-#define MU_NP 4            // passes in flight
+#define MU_NP 2            // passes in flight (more costs registers: 5 waves per SIMD without spills beat deeper pipelines)
 #define MU_KPCAP 512       // window keypoints staged in LDS
 
 template <int CTRL>
