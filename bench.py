@@ -136,6 +136,10 @@ def main():
             dt = float(t.item())
         return dt
 
+    def timed1(fn, steps, warmup):
+        """single-stream variant for the secondary figures (image-in mode)"""
+        return timed(lambda _b: fn(), steps, warmup)
+
     # ---- configs[1]: matcher only ------------------------------------------
     for _, b in lanes:
         b.kernel_timing(False)
@@ -175,12 +179,16 @@ def main():
     # comes from the committed rocprofv3 --pmc passes of this same command (profiles/), and is only
     # reported when the workload is the one those passes ran (bench.py defaults).
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_final.json")
-    if os.path.exists(pmc_path) and args.frames == 256 and args.kp == 2000 and args.width == 1241:
-        pmc = json.load(open(pmc_path))
-        if kname in pmc.get("kernel", ""):
-            traffic = pmc["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
+    if args.frames == 256 and args.kp == 2000 and args.width == 1241:
+        for name in ("r01_pmc_v3.json", "r01_pmc_final.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(pmc_path):
+                continue
+            pmc = json.load(open(pmc_path))
+            if kname in pmc.get("kernel", ""):
+                traffic = pmc["hbm_bytes_per_launch_corrected"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
+                break
 
     ab = None
     if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
@@ -229,7 +237,7 @@ def main():
         ib = libviso_amd.Batch(ctx, nfi, args.kp)
         ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
         ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
-        dt3 = timed(lambda: ib.run_images(False), max(1, args.steps // 2), 1)
+        dt3 = timed1(lambda: ib.run_images(False), max(1, args.steps // 2), 1)
         tri, oki, _ = ib.poses()
         e2e_img = {"fps": (nfi - 1) * max(1, args.steps // 2) * world / dt3, "frames": nfi - 1,
                    "workload": "uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
@@ -243,7 +251,7 @@ def main():
         def detect_and_run():
             db.detect()
             db.run_images(False)
-        dt4 = timed(detect_and_run, max(1, args.steps // 2), 1)
+        dt4 = timed1(detect_and_run, max(1, args.steps // 2), 1)
         trd, okd, _ = db.poses()
         e2e_img["with_harris_detection"] = {
             "fps": (nfi - 1) * max(1, args.steps // 2) * world / dt4,

@@ -251,8 +251,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         // ---------------- phase 2: rolling pipeline over the union list
         const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
         const int msh = 31 - (lane & 3);   // membership bit of the query this lane tracks (lanes sub and sub + 4 both track query sub & 3)
-        MuTrack tr;
-        tr.d1 = 0xffffffffu; tr.d2 = 0xffffffffu; tr.w = 0; tr.tie = 0;
+        MuTrack trk[2];   // even / odd passes keep separate trackers: no serial dependency between consecutive passes
+        trk[0].d1 = trk[1].d1 = 0xffffffffu; trk[0].d2 = trk[1].d2 = 0xffffffffu;
+        trk[0].w = trk[1].w = 0; trk[0].tie = trk[1].tie = 0;
         {
             const int npass = (nu + 7) >> 3;
             u32x4 r0[MU_NP], r1[MU_NP];
@@ -287,7 +288,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
                 const uint32_t lo_ = lb0 ? s1_ : s0_, hi_ = lb0 ? s3_ : s2_;                               \
                 const uint32_t mine_ = lb1 ? hi_ : lo_;   /* lanes sub and sub + 4 both track query sub & 3 */ \
                 const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
-                mu_update(tr, member_ ? mine_ : 0xffffffffu, (ent[SLOT] >> 8) & 0xfffffu);                 \
+                mu_update(trk[(SLOT) & 1], member_ ? mine_ : 0xffffffffu, (ent[SLOT] >> 8) & 0xfffffu);                 \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -309,6 +310,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
 #undef MU_SAD
 #undef MU_ISSUE
         }
+        MuTrack tr = trk[0];
+        mu_merge(tr, trk[1]);
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal sub), lane k of group 0 ends up with
         // query k; fetch the original target index, ratio test, store
 #pragma unroll
