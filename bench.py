@@ -51,8 +51,8 @@ def b_alg_bytes(n, scored, m_out, dlen=121):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per batch (per GPU)")
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--width", type=int, default=1241)
