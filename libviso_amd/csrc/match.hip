@@ -60,18 +60,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         keys[i] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (npad >> 1); t += VISO_IMG_THREADS) {
-                const int i = ((t / j) * 2 * j) + (t % j);
-                const int l = i + j;
-                const bool up = (i & k) == 0;
-                const unsigned long long a = keys[i], b = keys[l];
-                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds<VISO_IMG_THREADS>(keys, npad);
     for (int j = threadIdx.x; j < n; j += VISO_IMG_THREADS) {
         const int idx = (int)(uint32_t)keys[j];
         I.skp[j] = I.kp[idx];
@@ -824,18 +813,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
         keys[i] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (npad >> 1); t += VISO_SORT_THREADS) {
-                const int i = ((t / j) * 2 * j) + (t % j);
-                const int l = i + j;
-                const bool up = (i & k) == 0;
-                const unsigned long long a = keys[i], b = keys[l];
-                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds<VISO_SORT_THREADS>(keys, npad);
     int local = 0;
     for (int r = threadIdx.x; r < n1; r += VISO_SORT_THREADS) {
         const unsigned long long k = keys[r];

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t mb_dpp(uint32_t v) {
 }
 
 template <int EPI>
-__global__ __attribute__((amdgpu_waves_per_eu(EPI ? 5 : 6, 8))) __launch_bounds__(MB_THREADS) void match_batch_kernel(BatchMatchArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREADS) void match_batch_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pairs[MB_WAVES][MB_G * MB_SEG + MB_PAD];   // + the passes the pipeline may run ahead
     __shared__ __attribute__((aligned(16))) uint32_t s_sads[MB_WAVES][MB_G * MB_SEG + MB_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MB_WAVES][MB_G][64];

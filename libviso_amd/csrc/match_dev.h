@@ -44,3 +44,35 @@ __device__ __forceinline__ int bucket_of(float x, float x0, float scale) {
     return f <= 0.f ? 0 : (f >= (float)(VISO_NB - 1) ? VISO_NB - 1 : (int)f);
 }
 
+// Ascending bitonic sort of `npad` (power of two, >= 64) 64-bit keys in LDS by a workgroup of THREADS threads.
+// Every wave owns a contiguous chunk of comparators (CW per stage), hence a contiguous chunk of 2*CW keys: the
+// stages whose partner distance j fits the chunk are wave local and need no workgroup barrier (LDS operations of one
+// wave complete in order) — for 2048 keys and 8 waves that is 60 of the 66 stages.  Index arithmetic by shifts.
+// Call with the keys written and a __syncthreads() done; returns after a final __syncthreads().
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int npad) {
+    constexpr int NW = THREADS / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = npad >> 1;
+    const int cw = half >= THREADS ? half / NW : 64;   // comparators per wave and stage
+    const bool active = wave * cw < half;
+    for (int k = 2, lk = 1; k <= npad; k <<= 1, ++lk) {
+        for (int j = k >> 1, lj = lk - 1; j > 0; j >>= 1, --lj) {
+            const bool cross = j > cw;   // partner in another wave's chunk
+            if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if (active) {
+                for (int m = lane; m < cw; m += 64) {
+                    const int t = wave * cw + m;
+                    const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1));
+                    const int l = i + j;
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = keys[i], b = keys[l];
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            if (cross) __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
