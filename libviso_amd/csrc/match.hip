@@ -117,17 +117,22 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 }
 
 // ------------------------------------------------------------------ pack
-// One wave = VISO_PACK_RPW consecutive ORIGINAL rows: lane l converts floats
-// 2l, 2l+1 of a boundary-layout row (one 8-B load; the wave streams the rows'
-// bytes linearly) into one packed dword and the wave writes the whole 256-B
-// row to its x-sorted position rank[i] (two full cache lines).  All loads of a
-// wave are independent and in flight together.
+// One wave = VISO_PACK_RPW consecutive ORIGINAL rows = one contiguous, 16-B aligned run of RPW * dlen floats of
+// the boundary-layout matrix: streamed in with 16-B loads per lane, staged in LDS (the rows are 121 floats long,
+// so row boundaries fall anywhere in a lane's 16 B), then lane l converts floats 2l, 2l+1 of every row into one
+// packed dword and the wave writes each 256-B row to its x-sorted position rank[i] (two full cache lines).
 #define VISO_PACK_RPW 8   // rows per wave
 
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
                                                         int cap, int dlen, int* __restrict__ bad) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    __shared__ __attribute__((aligned(16))) float s_buf[4][VISO_PACK_RPW * VISO_ROW];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+    typedef const __attribute__((address_space(1))) float* gflt_t;
+    typedef const __attribute__((address_space(1))) int* gint_t;
+    typedef __attribute__((address_space(1))) uint32_t* gout_t;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;
     const long long row0 = wave * VISO_PACK_RPW;
     if (row0 >= (long long)n_img * cap) return;
     const int img = (int)(row0 / cap);      // cap is a multiple of VISO_PACK_RPW: a wave never straddles images
@@ -135,30 +140,38 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
     const int n = *I.n;
     const int r0 = (int)(row0 % cap);
     if (r0 >= n) return;
-    float2 v[VISO_PACK_RPW];
-    int dst[VISO_PACK_RPW];
-    const int c = 2 * lane;
+    const int nrows = min(VISO_PACK_RPW, n - r0);
+    const int nf = nrows * dlen;            // floats of this wave's rows, contiguous in the matrix
+    const float* src = I.frows + (size_t)r0 * dlen;
+    float* buf = s_buf[wv];
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+        const gvec_t v = (gvec_t)reinterpret_cast<const f32x4*>(src);
+        const int nq = nf >> 2;
 #pragma unroll
-    for (int k = 0; k < VISO_PACK_RPW; ++k) {
-        const int r = r0 + k;
-        v[k] = make_float2(0.f, 0.f);
-        dst[k] = -1;
-        if (r < n) {
-            dst[k] = I.rank[r];
-            const float* s = I.frows + (size_t)r * dlen;
-            if (c + 1 < dlen) { v[k].x = s[c]; v[k].y = s[c + 1]; }
-            else if (c < dlen) v[k].x = s[c];
+        for (int t = 0; t < (VISO_PACK_RPW * VISO_ROW / 4 + 63) / 64; ++t) {
+            const int q = lane + 64 * t;
+            if (q < nq) *reinterpret_cast<f32x4*>(buf + 4 * q) = v[q];
         }
+        const int e = (nq << 2) + lane;     // the up to 3 floats behind the last full 16 B
+        if (e < nf) buf[e] = ((gflt_t)src)[e];
+    } else {
+        for (int e = lane; e < nf; e += 64) buf[e] = ((gflt_t)src)[e];
     }
+    int dst = 0;
+    if (lane < nrows) dst = ((gint_t)I.rank)[r0 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int c = 2 * lane;
     bool isbad = false;
 #pragma unroll
     for (int k = 0; k < VISO_PACK_RPW; ++k) {
-        if (dst[k] < 0) continue;
-        const float a = v[k].x, b = v[k].y;
+        if (k >= nrows) break;              // wave uniform
+        const float a = c < dlen ? buf[k * dlen + c] : 0.f;
+        const float b = c + 1 < dlen ? buf[k * dlen + c + 1] : 0.f;
         const float ar = rintf(a), br = rintf(b);
         if (!(a == ar) || a < -32768.f || a > 32767.f || !(b == br) || b < -32768.f || b > 32767.f) isbad = true;
         const uint32_t ua = (uint32_t)((int)ar + VISO_BIAS) & 0xffffu, ub = (uint32_t)((int)br + VISO_BIAS) & 0xffffu;
-        reinterpret_cast<uint32_t*>(I.rows + (size_t)dst[k] * VISO_ROW)[lane] = ua | (ub << 16);
+        const int d = __builtin_amdgcn_readlane(dst, k);
+        ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
     }
     if (__any(isbad) && lane == 0) atomicOr(bad, 1);
 }
@@ -674,7 +687,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MAT
 // Queries whose in-radius set exceeds K or the LDS queue (dense keypoint
 // clusters): exact K-cap selection + streaming, reading the window from global
 // memory.  A few waves per problem; empty for ordinary data.
-#define VISO_OVF_BLOCKS 4
+#define VISO_OVF_BLOCKS 2
 
 template <bool GENERAL>
 __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(MatchArgs a) {
@@ -697,7 +710,18 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
         const int j = P.ovf[k];
         Window win;
         win.gkp = P.t.skp; win.gidx = P.t.sidx; win.skp = nullptr; win.sidx = nullptr;
-        win.lo = 0; win.W = n2; win.cap = 0;   // whole image, global reads
+        win.lo = 0; win.W = 0; win.cap = 0;   // the query's own +-radius column window, global reads
+        {
+            const float qx = P.q.skp[j].x, r = mp.radius;
+            if (n2 > 0 && r >= 0.f) {
+                if (qx == qx) {
+                    const float slack = (2.f * fabsf(qx) + fabsf(r)) * 1e-6f + 1e-6f;
+                    const float x0 = P.t.xinfo[0], scale = P.t.xinfo[1];
+                    win.lo = P.t.bstart[bucket_of(qx - r - slack, x0, scale)];
+                    win.W = P.t.bstart[bucket_of(qx + r + slack, x0, scale) + 1] - win.lo;
+                }   // NaN x: no target is in radius
+            }
+        }
         QueryResult r;
         match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
         if (lane == 0) {
