@@ -321,49 +321,98 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
         }
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 3: per query, min / second min (with multiplicity) / argmin / tie
-#pragma unroll
-        for (int k = 0; k < MB_G; ++k) {
-            if (orig[k] < 0) continue;
-            const int j = jg + k * MB_WAVES;
-            if (flags & (1 << k)) {
-                if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
-                continue;
-            }
-            const int n = seg_n[k], st = k == 0 ? 0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-            uint32_t r_d1 = 0xffffffffu, r_d2 = 0xffffffffu, r_w = 0, r_tie = 0;
-            for (int b = 0; b < n; b += VISO_WAVE) {
-                const bool valid = (b + lane) < n;
-                const uint32_t s = valid ? sads[st + b + lane] : 0xffffffffu;
-                const uint32_t m1 = mb_wave_min(s);
-                const bool eq = valid && s == m1;
-                const unsigned long long em = __ballot(eq);
-                const int c = __popcll(em);
-                const uint32_t m2 = mb_wave_min(eq ? 0xffffffffu : s);
-                const uint32_t wfirst = (pairs[st + b + (__ffsll((long long)em) - 1)] & 0x3fffffffu) >> 8;
-                const uint32_t o2 = c > 1 ? m1 : m2;
-                if (m1 < r_d1) { r_d2 = min(r_d1, o2); r_d1 = m1; r_w = wfirst; r_tie = c > 1; }
-                else if (m1 == r_d1) { r_d2 = r_d1; r_tie = 1; }
-                else r_d2 = min(r_d2, m1);
-            }
-            if (lane == 0) {
-                if (r_tie) {
-                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // exact tie: the largest-key rule is applied by the overflow kernel
+        const int nmax = max(max(seg_n[0], seg_n[1]), max(seg_n[2], seg_n[3]));
+        if (EPI && nmax <= 16) {
+            // short lists (the stereo call: ~3 pairs survive the gate): row r of 16 lanes reduces query r, all four at once
+            const int row = lane >> 4, i16 = lane & 15;
+            const int n = row == 0 ? seg_n[0] : row == 1 ? seg_n[1] : row == 2 ? seg_n[2] : seg_n[3];
+            const int st = row == 0 ? 0 : row == 1 ? c1 : row == 2 ? c2 : c3;
+            const int my_orig = row == 0 ? orig[0] : row == 1 ? orig[1] : row == 2 ? orig[2] : orig[3];
+            const bool valid = i16 < n;
+            const uint32_t sv = valid ? sads[st + i16] : 0xffffffffu;
+            auto row_min = [](uint32_t v) {
+                const int ident = -1;
+                v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm 1,0,3,2
+                v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm 2,3,0,1
+                v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+                v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+                return v;
+            };
+            const uint32_t m1 = row_min(sv);
+            const bool eq = valid && sv == m1;
+            const unsigned long long em = __ballot(eq);
+            const uint32_t emr = (uint32_t)(em >> (16 * row)) & 0xffffu;
+            const int c = __popc(emr);
+            const uint32_t m2 = row_min(eq ? 0xffffffffu : sv);
+            const uint32_t r_d2 = c > 1 ? m1 : m2;
+            if (i16 == 0 && my_orig >= 0) {
+                const int j = jg + row * MB_WAVES;
+                if (((flags >> row) & 1) || (m1 != 0xffffffffu && c > 1)) {
+                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // K cap / exact tie: overflow kernel
                 } else {
-                    bool accept = r_d1 != 0xffffffffu;
+                    bool accept = m1 != 0xffffffffu;
                     int idx = -1;
                     if (accept) {
+                        const uint32_t r_w = (pairs[st + (__ffs((int)emr) - 1)] & 0x3fffffffu) >> 8;
                         if ((int)r_w < wcap) idx = s_idx[r_w]; else idx = P.t.sidx[lo + (int)r_w];
                         if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
                             const double bd2 = r_d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)r_d2;
-                            accept = (double)r_d1 < bd2 * mp.ratio;
+                            accept = (double)m1 < bd2 * mp.ratio;
                         }
                     }
-                    P.res[orig[k]] = make_int2(accept ? idx : -1, (int)r_d1);
+                    P.res[my_orig] = make_int2(accept ? idx : -1, (int)m1);
                     scored += (unsigned long long)n;
                 }
             }
+        } else {
+    #pragma unroll
+            for (int k = 0; k < MB_G; ++k) {
+                if (orig[k] < 0) continue;
+                const int j = jg + k * MB_WAVES;
+                if (flags & (1 << k)) {
+                    if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
+                    continue;
+                }
+                const int n = seg_n[k], st = k == 0 ? 0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                uint32_t r_d1 = 0xffffffffu, r_d2 = 0xffffffffu, r_w = 0, r_tie = 0;
+                for (int b = 0; b < n; b += VISO_WAVE) {
+                    const bool valid = (b + lane) < n;
+                    const uint32_t s = valid ? sads[st + b + lane] : 0xffffffffu;
+                    const uint32_t m1 = mb_wave_min(s);
+                    const bool eq = valid && s == m1;
+                    const unsigned long long em = __ballot(eq);
+                    const int c = __popcll(em);
+                    const uint32_t m2 = mb_wave_min(eq ? 0xffffffffu : s);
+                    const uint32_t wfirst = (pairs[st + b + (__ffsll((long long)em) - 1)] & 0x3fffffffu) >> 8;
+                    const uint32_t o2 = c > 1 ? m1 : m2;
+                    if (m1 < r_d1) { r_d2 = min(r_d1, o2); r_d1 = m1; r_w = wfirst; r_tie = c > 1; }
+                    else if (m1 == r_d1) { r_d2 = r_d1; r_tie = 1; }
+                    else r_d2 = min(r_d2, m1);
+                }
+                if (lane == 0) {
+                    if (r_tie) {
+                        P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // exact tie: the largest-key rule is applied by the overflow kernel
+                    } else {
+                        bool accept = r_d1 != 0xffffffffu;
+                        int idx = -1;
+                        if (accept) {
+                            if ((int)r_w < wcap) idx = s_idx[r_w]; else idx = P.t.sidx[lo + (int)r_w];
+                            if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
+                                const double bd2 = r_d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)r_d2;
+                                accept = (double)r_d1 < bd2 * mp.ratio;
+                            }
+                        }
+                        P.res[orig[k]] = make_int2(accept ? idx : -1, (int)r_d1);
+                        scored += (unsigned long long)n;
+                    }
+                }
+            }
+
         }
     }
+    // per-lane partial sums (lane 0 of the generic path, lanes 0/16/32/48 of the short-list path)
+    scored += (unsigned long long)__shfl_xor((long long)scored, 16);
+    scored += (unsigned long long)__shfl_xor((long long)scored, 32);
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
