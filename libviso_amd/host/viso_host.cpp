@@ -240,6 +240,65 @@ struct Ctx {
     Ctx() : c(viso_ctx_create(0, nullptr)) { if (!c) throw std::runtime_error(std::string("viso_ctx_create: ") + viso_last_error()); }
     ~Ctx() { viso_ctx_destroy(c); }
 };
+
+// Two chunks in flight: while the GPU works on one chunk (its own context / HIP stream), the host packs and uploads
+// the next one into the other slot.  A slot's batch is kept and reused while the chunk shape stays the same.  Results
+// are drained strictly in chunk order, so the pose chain is the same as with one chunk at a time.
+struct ChunkPipeline {
+    struct Slot {
+        Ctx ctx;
+        viso_batch* b = nullptr;
+        int nf = 0, cap = 0, dlen = 0;      // shape the batch was created for
+        int global0 = 0;                    // global frame index of the chunk's first frame (its halo)
+        bool busy = false;
+        ~Slot() { if (b) viso_batch_destroy(b); }
+    };
+    Slot slot[2];
+    int next = 0;
+    OdometryResult& out;
+    double pose[16];
+    explicit ChunkPipeline(OdometryResult& o) : out(o) { std::memcpy(pose, out.poses[0].ptr(), sizeof(pose)); }
+
+    // batch of the slot the next chunk goes to (drains the chunk that used it two steps ago first)
+    viso_batch* acquire(int nf, int cap, int dlen, int global0) {
+        Slot& s = slot[next];
+        if (s.busy) drain(s);
+        if (!s.b || s.nf != nf || s.cap != cap || s.dlen != dlen) {
+            if (s.b) viso_batch_destroy(s.b);
+            s.b = viso_batch_create(s.ctx.c, nf, cap, dlen);
+            if (!s.b) throw std::runtime_error(std::string("viso_batch_create: ") + viso_last_error());
+            s.nf = nf; s.cap = cap; s.dlen = dlen;
+        }
+        s.global0 = global0;
+        return s.b;
+    }
+    void submitted() { slot[next].busy = true; next ^= 1; }
+    void drain(Slot& s) {
+        const int nf = s.nf;
+        std::vector<double> tr((size_t)nf * 6);
+        std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        hip_check(viso_batch_get_poses(s.b, tr.data(), ok.data(), ninl.data()), "sequence_odometry");
+        s.busy = false;
+        for (int t = (s.global0 == 0 ? 0 : 1); t < nf; ++t) {
+            out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
+            out.n_inliers.push_back(t == 0 ? 0 : ninl[(size_t)t]);
+            std::array<double, 6> a{};
+            if (t > 0) for (int j = 0; j < 6; ++j) a[(size_t)j] = tr[(size_t)t * 6 + j];
+            out.tr.push_back(a);
+            if (t > 0 && ok[(size_t)t]) {                              // :1313-1321
+                viso_pose_update(pose, a.data(), pose);
+                Matd P(4, 4);
+                std::memcpy(P.ptr(), pose, sizeof(pose));
+                out.poses.push_back(P);
+                out.frame_of_pose.push_back(s.global0 + t);
+            }
+        }
+    }
+    void finish() {   // oldest first
+        if (slot[next].busy) drain(slot[next]);
+        if (slot[next ^ 1].busy) drain(slot[next ^ 1]);
+    }
+};
 }
 
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGenerator frames, int chunk,
@@ -255,12 +314,10 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
     OdometryResult out;
     out.poses.push_back(Matd::eye(4));                                // :1189-1190
     out.frame_of_pose.push_back(0);
-    Ctx ctx;
+    ChunkPipeline pipe(out);
     std::vector<StereoFeatures> buf;                                  // frames of the current chunk (buf[0] = halo)
     int global0 = 0;                                                  // global index of buf[0]
     bool eos = false;
-    double pose[16];
-    std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
     while (!eos) {
         while ((int)buf.size() < chunk + 1) {
             std::optional<StereoFeatures> f = frames();
@@ -275,6 +332,7 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
             if (f.d1.rows) dlen = f.d1.cols; else if (f.d2.rows) dlen = f.d2.cols;
             if ((int)f.kp1.size() != f.d1.rows || (int)f.kp2.size() != f.d2.rows) throw std::invalid_argument("sequence_odometry: keypoint/descriptor count mismatch");
         }
+        cap = (cap + 255) / 256 * 256;                                // coarse capacity classes: batches get reused
         std::vector<float> kp((size_t)nf * 2 * cap * 2, 0.f), desc((size_t)nf * 2 * cap * dlen, 0.f);
         std::vector<int32_t> n((size_t)nf * 2);
         for (int t = 0; t < nf; ++t)
@@ -287,37 +345,19 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
                 for (size_t i = 0; i < k.size(); ++i) { kd[2 * i] = k[i].pt.x; kd[2 * i + 1] = k[i].pt.y; }
                 if (d.rows) std::memcpy(desc.data() + ((size_t)t * 2 + side) * cap * dlen, d.ptr(), sizeof(float) * (size_t)d.rows * dlen);
             }
-        viso_batch* b = viso_batch_create(ctx.c, nf, cap, dlen);
-        if (!b) throw std::runtime_error(std::string("viso_batch_create: ") + viso_last_error());
-        std::vector<double> tr((size_t)nf * 6);
-        std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        viso_batch* b = pipe.acquire(nf, cap, dlen, global0);
         int r = viso_batch_upload(b, 0, nf, kp.data(), desc.data(), n.data());
         if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
-        if (r >= 0) r = viso_batch_run(b);
-        if (r >= 0) r = viso_batch_get_poses(b, tr.data(), ok.data(), ninl.data());
-        viso_batch_destroy(b);
+        if (r >= 0) r = viso_batch_run(b);                            // asynchronous: the next chunk is packed meanwhile
         hip_check(r, "sequence_odometry");
-        for (int t = (global0 == 0 ? 0 : 1); t < nf; ++t) {
-            const int g = global0 + t;
-            out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
-            out.n_inliers.push_back(t == 0 ? 0 : ninl[(size_t)t]);
-            std::array<double, 6> a{};
-            if (t > 0) for (int j = 0; j < 6; ++j) a[(size_t)j] = tr[(size_t)t * 6 + j];
-            out.tr.push_back(a);
-            if (t > 0 && ok[(size_t)t]) {                              // :1313-1321
-                viso_pose_update(pose, a.data(), pose);
-                Matd P(4, 4);
-                std::memcpy(P.ptr(), pose, sizeof(pose));
-                out.poses.push_back(P);
-                out.frame_of_pose.push_back(g);
-            }
-        }
+        pipe.submitted();
         // keep the last frame as the next chunk's halo
         StereoFeatures last = std::move(buf.back());
         buf.clear();
         buf.push_back(std::move(last));
         global0 += nf - 1;
     }
+    pipe.finish();
     return out;
 }
 
@@ -431,12 +471,10 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
     OdometryResult out;
     out.poses.push_back(Matd::eye(4));
     out.frame_of_pose.push_back(0);
-    Ctx ctx;
+    ChunkPipeline pipe(out);
     std::vector<std::pair<Image, Image>> buf;
     int global0 = 0;
     bool eos = false;
-    double pose[16];
-    std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
     while (!eos) {
         while ((int)buf.size() < chunk + 1) {
             StereoImageGenerator::result_type f = images();
@@ -453,36 +491,19 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
                 if (im.rows != rows || im.cols != cols) throw std::invalid_argument("sequence_odometry: image size changes inside a sequence");
                 std::memcpy(img.data() + ((size_t)t * 2 + side) * rows * cols, im.data.data(), (size_t)rows * cols);
             }
-        viso_batch* b = viso_batch_create(ctx.c, nf, MAX_FEATURE_NUM, VISO_DESC_LEN);
-        if (!b) throw std::runtime_error(std::string("viso_batch_create: ") + viso_last_error());
-        std::vector<double> tr((size_t)nf * 6);
-        std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        viso_batch* b = pipe.acquire(nf, MAX_FEATURE_NUM, VISO_DESC_LEN, global0);
         int r = viso_batch_upload_images(b, 0, nf, img.data(), rows, cols, nullptr, nullptr);
         if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
         if (r >= 0) r = viso_batch_detect(b, detector.n(), detector.nbinx(), detector.nbiny(), (double)detector.k());   // :1226-1227
-        if (r >= 0) r = viso_batch_run_images(b, 0);                                                                    // :1230-1313
-        if (r >= 0) r = viso_batch_get_poses(b, tr.data(), ok.data(), ninl.data());
-        viso_batch_destroy(b);
+        if (r >= 0) r = viso_batch_run_images(b, 0);                                                                    // :1230-1313, asynchronous
         hip_check(r, "sequence_odometry");
-        for (int t = (global0 == 0 ? 0 : 1); t < nf; ++t) {
-            out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
-            out.n_inliers.push_back(t == 0 ? 0 : ninl[(size_t)t]);
-            std::array<double, 6> a{};
-            if (t > 0) for (int j = 0; j < 6; ++j) a[(size_t)j] = tr[(size_t)t * 6 + j];
-            out.tr.push_back(a);
-            if (t > 0 && ok[(size_t)t]) {
-                viso_pose_update(pose, a.data(), pose);
-                Matd Pm(4, 4);
-                std::memcpy(Pm.ptr(), pose, sizeof(pose));
-                out.poses.push_back(Pm);
-                out.frame_of_pose.push_back(global0 + t);
-            }
-        }
+        pipe.submitted();
         std::pair<Image, Image> last = std::move(buf.back());
         buf.clear();
         buf.push_back(std::move(last));
         global0 += nf - 1;
     }
+    pipe.finish();
     return out;
 }
 
