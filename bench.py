@@ -136,10 +136,6 @@ def main():
             dt = float(t.item())
         return dt
 
-    def timed1(fn, steps, warmup):
-        """single-stream variant for the secondary figures (image-in mode)"""
-        return timed(lambda _b: fn(), steps, warmup)
-
     # ---- configs[1]: matcher only ------------------------------------------
     for _, b in lanes:
         b.kernel_timing(False)
@@ -234,32 +230,57 @@ def main():
     if args.images:
         nfi = min(nf, 65)
         iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
-        ib = libviso_amd.Batch(ctx, nfi, args.kp)
-        ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
-        ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
-        dt3 = timed1(lambda: ib.run_images(False), max(1, args.steps // 2), 1)
-        tri, oki, _ = ib.poses()
-        e2e_img = {"fps": (nfi - 1) * max(1, args.steps // 2) * world / dt3, "frames": nfi - 1,
+        def timed_lanes(objs, fn, steps, warmup):
+            """round robin over per-stream objects (image-mode batches), same clock discipline as timed()"""
+            for i in range(warmup):
+                fn(objs[i % len(objs)])
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fn(objs[i % len(objs)])
+            sync_all()
+            d = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([d], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            return d
+
+        isteps = max(n_streams, args.steps // 2)
+        ibs = []
+        for c, _ in lanes:   # one image batch per stream, same synthetic frames in each
+            ib = libviso_amd.Batch(c, nfi, args.kp)
+            ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
+            ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+            ibs.append(ib)
+        dt3 = timed_lanes(ibs, lambda b: b.run_images(False), isteps, n_streams)
+        tri, oki, _ = ibs[0].poses()
+        e2e_img = {"fps": (nfi - 1) * isteps * world / dt3, "frames": nfi - 1,
                    "workload": "uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
                    "poses_ok": int(oki[1:].sum()),
                    "max_abs_tr_err_vs_ground_truth": float(np.abs(tri[1:][oki[1:] == 1] - iseq["tr_gt"][1:][oki[1:] == 1]).max()) if oki[1:].any() else None}
+        for ib in ibs:
+            ib.close()
         # complete front-end on device too: binned Harris -> descriptors -> matcher -> solver
-        db = libviso_amd.Batch(ctx, nfi, 1200)
-        db.upload_images_only(iseq["images"])
-        db.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+        dbs = []
+        for c, _ in lanes:
+            db = libviso_amd.Batch(c, nfi, 1200)
+            db.upload_images_only(iseq["images"])
+            db.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+            dbs.append(db)
 
-        def detect_and_run():
-            db.detect()
-            db.run_images(False)
-        dt4 = timed1(detect_and_run, max(1, args.steps // 2), 1)
-        trd, okd, _ = db.poses()
+        def detect_and_run(b):
+            b.detect()
+            b.run_images(False)
+        dt4 = timed_lanes(dbs, detect_and_run, isteps, n_streams)
+        trd, okd, _ = dbs[0].poses()
         e2e_img["with_harris_detection"] = {
-            "fps": (nfi - 1) * max(1, args.steps // 2) * world / dt4,
+            "fps": (nfi - 1) * isteps * world / dt4,
             "workload": "uint8 images only -> binned Harris (1200 corners/image, 24x5 bins) -> descriptors -> matcher + circle + RANSAC/GN",
             "poses_ok": int(okd[1:].sum()),
             "max_abs_tr_err_vs_ground_truth": float(np.abs(trd[1:][okd[1:] == 1] - iseq["tr_gt"][1:][okd[1:] == 1]).max()) if okd[1:].any() else None}
-        db.close()
-        ib.close()
+        for db in dbs:
+            db.close()
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
     cpu = None
