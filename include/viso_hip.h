@@ -234,8 +234,11 @@ int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out);
  * its average duration in ms over the launches since the last reset, measured
  * with hipEvents on the context's stream. */
 const char* viso_matcher_kernel_name(void);
-/* Tuning/debug: 0 (default) = L2-gather kernel, 1 = LDS-resident tile kernel.
- * Identical results; lets bench.py time both in one process. */
+/* Tuning/debug: which implementation of the u16 matcher runs.  3 (default) = match_union_kernel for the temporal
+ * calls (one row load scored against four y-adjacent queries) + match_batch_kernel<1> for the stereo call;
+ * 2 = match_batch_kernel for both; 0 = match_kernel (one query per wave at a time); 1 = match_tile_kernel
+ * (descriptor rows staged in LDS).  Identical results; lets bench.py and the parity tests run all of them in
+ * one process.  Process-wide, not thread safe: set it before launching work. */
 void viso_debug_set_matcher(int variant);
 int viso_batch_kernel_timing(viso_batch* b, int enable);
 int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches);

@@ -733,10 +733,13 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
-// 1 = match_tile_kernel (LDS-resident window, match_tile.hip), 0 = match_kernel<false> (L2 gathers).
-// Same results; kept switchable so the two can be timed against each other in one process.
-// Measured on MI355X (bench.py --ab, 769 problems/launch): gather kernel 1.385 ms, tile kernel
-// 1.77 ms — the gather kernel is the default; the tile kernel stays for dense-keypoint studies.
+// Which implementation of the u16 path runs (include/viso_hip.h, viso_debug_set_matcher):
+//   3 = match_union_kernel (temporal) + match_batch_kernel<1> (stereo)      0.51 + 0.23 ms   <- default
+//   2 = match_batch_kernel<0> + match_batch_kernel<1>                        0.63 + 0.23 ms
+//   0 = match_kernel<false, 0/1> (this file: one query per wave at a time)   0.90 + 0.43 ms
+//   1 = match_tile_kernel (descriptor rows staged in LDS, match_tile.hip)    1.77 ms for both
+// (MI355X, bench.py --ab, 769 problems per launch, one stream.)  Same results; all four stay selectable and
+// are run by the fuzz / full-size parity tests.
 static int g_matcher_variant = 3;
 extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = (variant >= 0 && variant <= 3) ? variant : 0; }
 extern "C" const char* viso_matcher_kernel_name(void) {
