@@ -607,27 +607,20 @@ struct MatchArgs {
 // instantiation carries no fp64 Sampson code and needs fewer registers (more
 // waves per SIMD to hide the L2 gather latency); each instantiation skips the
 // problems of the other kind.
+// One (problem, query tile) slot: the body of match_kernel.  `vb` is the slot number (block index of a full grid).
 template <bool GENERAL, int EPI>
-__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
-    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
-    __shared__ float2 s_kp[VISO_KPCAP];
-    __shared__ int s_idx[VISO_KPCAP];
-    __shared__ float s_xr[2];
-    // the pack kernel decides which variant does the work (no host round trip)
-    const bool is_bad = *a.bad != 0;
-    if (is_bad != GENERAL) return;
-    for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
-    __syncthreads();   // LDS of the previous slot is free
+__device__ __forceinline__ void match_tile_slot(const MatchArgs& a, int vb, uint2 (*s_queue)[VISO_QCAP], float2* s_kp,
+                                                int* s_idx, float* s_xr) {
     int prob, qblk;
     block_to_problem(vb, a.n_probs, a.bpp, a.gs, a.gf, a.gc, prob, qblk);
-    if (prob < 0) continue;
+    if (prob < 0) return;
     const MatchProblem P = a.probs[prob];
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * VISO_QPB;
-    if (q0 >= n1) continue;
+    if (q0 >= n1) return;
     const int q1 = min(q0 + VISO_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
-    if ((mp.epi != 0) != (EPI != 0)) continue;
+    if ((mp.epi != 0) != (EPI != 0)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // x range of the tile (queries are x-sorted; NaNs sort last and are ignored)
     if (wave == 0) {
@@ -681,6 +674,25 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(VISO_MAT
         }
     }
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
+}
+
+template <bool GENERAL, int EPI>
+__global__ __attribute__((amdgpu_waves_per_eu(GENERAL ? 4 : 8, 8))) __launch_bounds__(VISO_MATCH_THREADS) void match_kernel(MatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
+    __shared__ float2 s_kp[VISO_KPCAP];
+    __shared__ int s_idx[VISO_KPCAP];
+    __shared__ float s_xr[2];
+    // the pack kernel decides which variant does the work (no host round trip)
+    const bool is_bad = *a.bad != 0;
+    if (is_bad != GENERAL) return;
+    if constexpr (GENERAL) {
+        // normally idle: launched on a small grid that strides over the slots when it does have work
+        for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
+            __syncthreads();   // LDS of the previous slot is free
+            match_tile_slot<GENERAL, EPI>(a, vb, s_queue, s_kp, s_idx, s_xr);
+        }
+    } else {
+        match_tile_slot<GENERAL, EPI>(a, blockIdx.x, s_queue, s_kp, s_idx, s_xr);
     }
 }
 
