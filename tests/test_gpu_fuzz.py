@@ -3,6 +3,8 @@ small problems with adversarial structure (duplicated keypoints and patches,
 negative / fractional / huge coordinates, NaN and inf keypoints, radius 0 and
 very large radii, K from 1 to beyond n, both gates on and off, odd descriptor
 lengths, non-integer descriptors)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -56,7 +58,7 @@ def test_match_desc_randomised(viso, oracle, variant):
     libviso_amd.set_matcher_variant(variant)
     try:
         n_nonempty = 0
-        for it in range(220):
+        for it in range(int(os.environ.get("VISO_FUZZ_ITERS", "220"))):   # VISO_FUZZ_ITERS=5000 for a long soak
             kp1, kp2, d1, d2, mp = _case(rng, F)
             want = oracle.match_desc(kp1, kp2, d1, d2, mp)
             got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
