@@ -11,8 +11,10 @@
 #include "common.h"
 
 #define HT_X 64
-#define HT_Y 16
+#define HT_Y 32
 #define HT_THREADS 256
+#define HT_IW (HT_X + 8)   // LDS row pitch of the uint8 tile (HT_X + 6 used)
+#define HT_CW (HT_X + 2)   // cov tile width (tile + 1 ring)
 
 __device__ __forceinline__ int h_reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -20,65 +22,125 @@ __device__ __forceinline__ int h_reflect101(int p, int len) {
     return p;
 }
 
-// One workgroup = one 64x16 tile of the response map.  LDS stages: reflected
-// uint8 halo tile -> horizontal 5-tap sums (derivative and smoothing) -> vertical
-// 5-tap sums = Dx, Dy -> cov (3 floats) on the tile + 1 ring -> 3x3 box + response.
-__global__ __launch_bounds__(HT_THREADS) void harris_response_kernel(const uint8_t* __restrict__ images, int rows,
-                                                                     int cols, double k, float* __restrict__ resp) {
-    __shared__ unsigned char s_img[HT_Y + 6][HT_X + 8];
-    __shared__ int s_hd[HT_Y + 6][HT_X + 2];
-    __shared__ int s_hs[HT_Y + 6][HT_X + 2];
-    __shared__ float s_cov[3][HT_Y + 2][HT_X + 2];
-    const int img = blockIdx.z;
-    const int tx0 = blockIdx.x * HT_X, ty0 = blockIdx.y * HT_Y;
-    const uint8_t* im = images + (size_t)img * rows * cols;
+// One workgroup = one 64x32 tile of the response map.
+//   stage 1  uint8 tile + 3-pixel halo -> LDS (BORDER tiles: BORDER_REFLECT_101 per pixel)
+//   stage 2  thread = one column of the cov tile and a band of its rows: horizontal 5-tap sums (derivative and
+//            smoothing) of each image row from 5 LDS bytes, vertical 5-tap sums by a sliding register window
+//            -> Dx, Dy -> the three cov products -> LDS
+//   stage 3  thread = one output column and a strip of 8 rows: 3x3 box sums (row-major float additions, the
+//            contract shared with the oracle) over a sliding window of cov rows -> response
+// BORDER tiles (touching the image edge) take BORDER_REFLECT_101 of the cov image tap by tap.
+template <bool BORDER>
+__device__ __forceinline__ void harris_tile(const uint8_t* __restrict__ im, int rows, int cols, int tx0, int ty0,
+                                            double k, float* __restrict__ out, unsigned char (*s_img)[HT_IW],
+                                            float (*s_cov)[HT_Y + 2][HT_CW]) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < (HT_Y + 6) * (HT_X + 6); idx += HT_THREADS) {
-        const int ly = idx / (HT_X + 6), lx = idx % (HT_X + 6);
-        const int gy = h_reflect101(ty0 - 3 + ly, rows), gx = h_reflect101(tx0 - 3 + lx, cols);
+        const int ly = idx / (HT_X + 6), lx = idx - ly * (HT_X + 6);
+        int gy = ty0 - 3 + ly, gx = tx0 - 3 + lx;
+        if (BORDER) { gy = h_reflect101(gy, rows); gx = h_reflect101(gx, cols); }
         s_img[ly][lx] = im[(size_t)gy * cols + gx];
     }
     __syncthreads();
-    for (int idx = tid; idx < (HT_Y + 6) * (HT_X + 2); idx += HT_THREADS) {
-        const int ly = idx / (HT_X + 2), lx = idx % (HT_X + 2);   // column of global x = tx0 - 1 + lx
-        const int p0 = s_img[ly][lx], p1 = s_img[ly][lx + 1], p2 = s_img[ly][lx + 2], p3 = s_img[ly][lx + 3],
-                  p4 = s_img[ly][lx + 4];
-        s_hd[ly][lx] = -p0 - 2 * p1 + 2 * p3 + p4;
-        s_hs[ly][lx] = p0 + 4 * p1 + 6 * p2 + 4 * p3 + p4;
-    }
-    __syncthreads();
-    const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
-    for (int idx = tid; idx < (HT_Y + 2) * (HT_X + 2); idx += HT_THREADS) {
-        const int ly = idx / (HT_X + 2), lx = idx % (HT_X + 2);   // row of global y = ty0 - 1 + ly
-        const int Dx = s_hd[ly][lx] + 4 * s_hd[ly + 1][lx] + 6 * s_hd[ly + 2][lx] + 4 * s_hd[ly + 3][lx] + s_hd[ly + 4][lx];
-        const int Dy = -s_hs[ly][lx] - 2 * s_hs[ly + 1][lx] + 2 * s_hs[ly + 3][lx] + s_hs[ly + 4][lx];
-        const float dx = (float)Dx * scale, dy = (float)Dy * scale;
-        s_cov[0][ly][lx] = dx * dx;
-        s_cov[1][ly][lx] = dx * dy;
-        s_cov[2][ly][lx] = dy * dy;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < HT_Y * HT_X; idx += HT_THREADS) {
-        const int oy = idx / HT_X, ox = idx % HT_X;
-        const int gy = ty0 + oy, gx = tx0 + ox;
-        if (gy >= rows || gx >= cols) continue;
-        float a = 0.f, b = 0.f, c = 0.f;
+    {
+        // column lx of the cov tile = global x tx0 - 1 + lx; rows ly = global y ty0 - 1 + ly, in 3 bands
+        const int band = tid / HT_CW, lx = tid - band * HT_CW;
+        if (band < 3) {
+            const int r0 = band * 12, r1 = band == 2 ? HT_Y + 2 : r0 + 12;
+            const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
+            int hd[5], hs[5];
 #pragma unroll
-        for (int i = -1; i <= 1; ++i) {
-            const int ly = h_reflect101(gy + i, rows) - (ty0 - 1);
+            for (int t = 0; t < 4; ++t) {
+                const unsigned char* p = &s_img[r0 + t][lx];
+                hd[t + 1] = -(int)p[0] - 2 * (int)p[1] + 2 * (int)p[3] + (int)p[4];
+                hs[t + 1] = (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
+            }
+            for (int ly = r0; ly < r1; ++ly) {
 #pragma unroll
-            for (int j = -1; j <= 1; ++j) {
-                const int lx = h_reflect101(gx + j, cols) - (tx0 - 1);
-                a += s_cov[0][ly][lx];
-                b += s_cov[1][ly][lx];
-                c += s_cov[2][ly][lx];
+                for (int t = 0; t < 4; ++t) { hd[t] = hd[t + 1]; hs[t] = hs[t + 1]; }
+                const unsigned char* p = &s_img[ly + 4][lx];
+                hd[4] = -(int)p[0] - 2 * (int)p[1] + 2 * (int)p[3] + (int)p[4];
+                hs[4] = (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
+                const int Dx = hd[0] + 4 * hd[1] + 6 * hd[2] + 4 * hd[3] + hd[4];
+                const int Dy = -hs[0] - 2 * hs[1] + 2 * hs[3] + hs[4];
+                const float dx = (float)Dx * scale, dy = (float)Dy * scale;
+                s_cov[0][ly][lx] = dx * dx;
+                s_cov[1][ly][lx] = dx * dy;
+                s_cov[2][ly][lx] = dy * dy;
             }
         }
-        const float t1 = a * c, t2 = b * b;
-        const float t3 = t1 - t2;
-        const float tr = a + c;
-        resp[((size_t)img * rows + gy) * cols + gx] = (float)((double)t3 - k * (double)tr * (double)tr);
     }
+    __syncthreads();
+    const int ox = tid & (HT_X - 1), strip = tid >> 6;   // 4 strips of 8 rows
+    const int gx = tx0 + ox;
+    if (gx >= cols) return;
+    if (!BORDER) {
+        // cov rows oy-1, oy, oy+1 of output row oy are local rows oy, oy+1, oy+2; columns ox, ox+1, ox+2
+        float ra[3][3], rb[3][3], rc[3][3];   // [row in window][column]
+        const int oy0 = strip * 8;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ra[r + 1][j] = s_cov[0][oy0 + r][ox + j];
+                rb[r + 1][j] = s_cov[1][oy0 + r][ox + j];
+                rc[r + 1][j] = s_cov[2][oy0 + r][ox + j];
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int oy = oy0 + i, gy = ty0 + oy;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ra[0][j] = ra[1][j]; ra[1][j] = ra[2][j]; ra[2][j] = s_cov[0][oy + 2][ox + j];
+                rb[0][j] = rb[1][j]; rb[1][j] = rb[2][j]; rb[2][j] = s_cov[1][oy + 2][ox + j];
+                rc[0][j] = rc[1][j]; rc[1][j] = rc[2][j]; rc[2][j] = s_cov[2][oy + 2][ox + j];
+            }
+            float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { a += ra[r][j]; b += rb[r][j]; c += rc[r][j]; }
+            const float t1 = a * c, t2 = b * b;
+            const float t3 = t1 - t2;
+            const float tr = a + c;
+            if (gy < rows) out[(size_t)gy * cols + gx] = (float)((double)t3 - k * (double)tr * (double)tr);
+        }
+    } else {
+        for (int i = 0; i < 8; ++i) {
+            const int oy = strip * 8 + i, gy = ty0 + oy;
+            if (gy >= rows) break;
+            float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+            for (int di = -1; di <= 1; ++di) {
+                const int ly = h_reflect101(gy + di, rows) - (ty0 - 1);
+#pragma unroll
+                for (int dj = -1; dj <= 1; ++dj) {
+                    const int lx = h_reflect101(gx + dj, cols) - (tx0 - 1);
+                    a += s_cov[0][ly][lx];
+                    b += s_cov[1][ly][lx];
+                    c += s_cov[2][ly][lx];
+                }
+            }
+            const float t1 = a * c, t2 = b * b;
+            const float t3 = t1 - t2;
+            const float tr = a + c;
+            out[(size_t)gy * cols + gx] = (float)((double)t3 - k * (double)tr * (double)tr);
+        }
+    }
+}
+
+__global__ __launch_bounds__(HT_THREADS) void harris_response_kernel(const uint8_t* __restrict__ images, int rows,
+                                                                     int cols, double k, float* __restrict__ resp) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_img[HT_Y + 6][HT_IW];
+    __shared__ float s_cov[3][HT_Y + 2][HT_CW];
+    const int img = blockIdx.z;
+    const int tx0 = blockIdx.x * HT_X, ty0 = blockIdx.y * HT_Y;
+    const uint8_t* im = images + (size_t)img * rows * cols;
+    float* out = resp + (size_t)img * rows * cols;
+    // interior: the tile's 3-pixel halo (image) and 1-pixel ring (cov) lie inside the image
+    const bool interior = tx0 >= 3 && ty0 >= 3 && tx0 + HT_X + 3 <= cols && ty0 + HT_Y + 3 <= rows;
+    if (interior) harris_tile<false>(im, rows, cols, tx0, ty0, k, out, s_img, s_cov);
+    else harris_tile<true>(im, rows, cols, tx0, ty0, k, out, s_img, s_cov);
 }
 
 struct BinArgs {
@@ -105,7 +167,10 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+#define HB_LIST 256   // keys >= the last optimistic pick collected by the one-walk exact path (per wave)
+
 __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
+    __shared__ unsigned long long s_list[4][HB_LIST];
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nbins = a.nbinx * a.nbiny;
@@ -120,23 +185,31 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
     unsigned long long k0 = 0, k1 = 0, k2 = 0;             // k0 >= k1 >= k2
     {
         // lanes walk the bin in MEMORY order (x fastest: coalesced rows); the key carries the
-        // reference's push position pos = xo * stridey + yo (x outer, y inner, :953-955)
+        // reference's push position pos = xo * stridey + yo (x outer, y inner, :953-955).
+        // Four independent loads per step: the walk is latency bound (60 steps per bin otherwise).
         int yo = lane / a.stridex, xo = lane % a.stridex;
-        for (int idx = lane; idx < P; idx += 64) {
-            const int x = x0 + xo, y = y0 + yo;
-            const int pos = xo * a.stridey + yo;
-            if (x < a.cols && y < a.rows) {
-                const float v = fabsf(r[(size_t)y * a.cols + x]);
-                if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {   // isEqual(response, .0f), src/misc.cpp:10-14
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
+        for (int idx = lane; idx < P; idx += 4 * 64) {
+            float v[4];
+            int pos[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + xo, y = y0 + yo;
+                pos[u] = xo * a.stridey + yo;
+                v[u] = 0.f;   // 0 is skipped by the isEqual test below
+                if (idx + 64 * u < P && x < a.cols && y < a.rows) v[u] = fabsf(r[(size_t)y * a.cols + x]);
+                xo += 64;
+                while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!(fabsf(v[u] - 0.f) <= 1e-6f * fabsf(v[u]))) {   // isEqual(response, .0f), src/misc.cpp:10-14
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(v[u]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos[u]);
                     if (key > k2) {
                         if (key > k1) { k2 = k1; if (key > k0) { k1 = k0; k0 = key; } else k1 = key; }
                         else k2 = key;
                     }
                 }
             }
-            xo += 64;
-            while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
         }
     }
     // ---- merge: `per` rounds over the lanes' heads
@@ -158,34 +231,86 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
     // exact iff no lane used up all three of its keys while more picks could lie below them
     const bool suspicious = (n == a.per) ? (third > last) : (third != 0 && k0 == 0 && n < a.per);
     if (__any(suspicious)) {
-        // ---- exact path: `per` rounds of "largest key below the previous pick"
-        unsigned long long prev = ~0ull;
-        n = 0;
-        for (int round = 0; round < a.per; ++round) {
-            unsigned long long best = 0;
+        // The optimistic picks are `per` real keys of the bin, so every key of the true top `per` is >= the last
+        // optimistic pick: ONE more walk collects all keys >= last (a handful more than `per`) into LDS and the
+        // exact top `per` is selected among them.  Bins where that does not apply (fewer than `per` picks, or an
+        // implausibly long list) take the multi-pass path below.
+        bool done = false;
+        if (n == a.per) {
+            unsigned long long* list = s_list[threadIdx.x >> 6];
+            int cnt = 0;
             int yo = lane / a.stridex, xo = lane % a.stridex;
             for (int idx = lane; idx < P; idx += 64) {
                 const int x = x0 + xo, y = y0 + yo;
                 const int pos = xo * a.stridey + yo;
+                unsigned long long key = 0;
                 if (x < a.cols && y < a.rows) {
                     const float v = fabsf(r[(size_t)y * a.cols + x]);
-                    if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
-                        if (key < prev && key > best) best = key;
-                    }
+                    if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v)))
+                        key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
                 }
+                const bool take = key >= last;   // last != 0 here
+                const unsigned long long m = __ballot(take);
+                const int at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (take && at < HB_LIST) list[at] = key;
+                cnt += __popcll(m);
                 xo += 64;
                 while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
             }
-            best = wave_max_u64(best);
-            if (best == 0) break;
-            prev = best;
-            if (lane == 0) {
-                const int pos = (int)(0xffffffffu - (uint32_t)best);
-                a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
-                a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
+            __builtin_amdgcn_wave_barrier();
+            if (cnt <= HB_LIST) {
+                unsigned long long mine[HB_LIST / 64];
+#pragma unroll
+                for (int u = 0; u < HB_LIST / 64; ++u) mine[u] = (lane + 64 * u < cnt) ? list[lane + 64 * u] : 0ull;
+                n = 0;
+                for (int round = 0; round < a.per; ++round) {
+                    unsigned long long loc = mine[0];
+#pragma unroll
+                    for (int u = 1; u < HB_LIST / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
+                    const unsigned long long best = wave_max_u64(loc);
+                    if (best == 0) break;
+#pragma unroll
+                    for (int u = 0; u < HB_LIST / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
+                    if (lane == 0) {
+                        const int pos = (int)(0xffffffffu - (uint32_t)best);
+                        a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
+                        a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
+                    }
+                    ++n;
+                }
+                done = true;
             }
-            ++n;
+        }
+        if (!done) {
+        // ---- exact path: `per` rounds of "largest key below the previous pick"
+            unsigned long long prev = ~0ull;
+            n = 0;
+            for (int round = 0; round < a.per; ++round) {
+                unsigned long long best = 0;
+                int yo = lane / a.stridex, xo = lane % a.stridex;
+                for (int idx = lane; idx < P; idx += 64) {
+                    const int x = x0 + xo, y = y0 + yo;
+                    const int pos = xo * a.stridey + yo;
+                    if (x < a.cols && y < a.rows) {
+                        const float v = fabsf(r[(size_t)y * a.cols + x]);
+                        if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
+                            if (key < prev && key > best) best = key;
+                        }
+                    }
+                    xo += 64;
+                    while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
+                }
+                best = wave_max_u64(best);
+                if (best == 0) break;
+                prev = best;
+                if (lane == 0) {
+                    const int pos = (int)(0xffffffffu - (uint32_t)best);
+                    a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
+                    a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
+                }
+                ++n;
+            }
         }
     }
     if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
