@@ -26,7 +26,7 @@
 #define MU_G 4             // queries per round
 #define MU_UCAP 256        // union list entries per round
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
-#define MU_NP 2            // passes in flight (more costs registers: 5 waves per SIMD without spills beat deeper pipelines)
+#define MU_NP 2            // passes in flight (3 measured slower even without spills)
 #define MU_KPCAP 512       // window keypoints staged in LDS
 
 template <int CTRL>
@@ -67,7 +67,6 @@ __device__ __forceinline__ void mu_merge(MuTrack& a, const MuTrack& b) {
 
 __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
-    __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][64];
     __shared__ float2 s_kp[MU_KPCAP];
     __shared__ int s_idx[MU_KPCAP];
     __shared__ int s_qord[MU_QPB];
@@ -143,17 +142,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
     typedef const __attribute__((address_space(1))) char* gbytes_t;
     // window base (scalar) + 32-bit byte offset per lane: (window position << 8) | (sub << 4)
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
+    const grow_t qrows = (grow_t)reinterpret_cast<const u32x4*>(P.q.rows);
     uint32_t* ul = s_ul[wave];
     const int g8 = lane >> 3, sub = lane & 7;
     unsigned long long scored = 0;
     constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 4 rounds per wave
 
-    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 3) of the
-    // round, every lane one word of each of the four rows
+    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 3) of the round
     int pli;
     float2 pq;
     int po;
-    uint32_t prow[MU_G];
 #define MU_PREFETCH(R)                                                                                    \
     do {                                                                                                  \
         const int base_ = wave * (MU_QPB / MU_WAVES) + (R) * MU_G;                                        \
@@ -162,10 +160,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         const int jc_ = min(j_, q1 - 1);                                                                  \
         pq = P.q.skp[jc_];                                                                                \
         po = j_ < q1 ? P.q.sidx[jc_] : -1;                                                                \
-        _Pragma("unroll") for (int k_ = 0; k_ < MU_G; ++k_) {                                             \
-            const int jk_ = min(q0 + s_qord[base_ + k_], q1 - 1);                                         \
-            prow[k_] = reinterpret_cast<const uint32_t*>(P.q.rows + (size_t)jk_ * VISO_ROW)[lane];        \
-        }                                                                                                 \
     } while (0)
     MU_PREFETCH(0);
 
@@ -181,7 +175,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
             qk[k].y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), k));
             orig[k] = __builtin_amdgcn_readlane(po, k);
             jq[k] = q0 + __builtin_amdgcn_readlane(pli, k);
-            s_qrow[wave][k][lane] = prow[k];
             cnt[k] = 0;
             // d = |dx| + |dy| is +0, positive or NaN: its bit pattern orders like the value and NaNs are above +inf,
             // so (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in radius: Q1,
@@ -196,12 +189,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         }
         if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
         if (!any_live) continue;   // wave uniform
-        u32x4 qa[MU_G], qb[MU_G];   // this lane's 2 x 16 B of every query row
+        // this lane's 2 x 16 B of every query row, straight from global memory: the loads land during the scan
+        u32x4 qa[MU_G], qb[MU_G];
 #pragma unroll
         for (int k = 0; k < MU_G; ++k) {
-            const uint32_t* qr = &s_qrow[wave][k][sub * 4];
-            qa[k] = *reinterpret_cast<const u32x4*>(qr);
-            qb[k] = *reinterpret_cast<const u32x4*>(qr + 32);
+            const grow_t qr = qrows + (size_t)min(jq[k], q1 - 1) * (VISO_ROW / 8) + sub;   // 16 x 16 B per row
+            qa[k] = qr[0];
+            qb[k] = qr[8];
         }
         // ---------------- phase 1: one scan, membership masks, union list.  entry = mask << 28 | position << 8
         // (mask bit 3 - k = query k)
@@ -251,9 +245,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         // ---------------- phase 2: rolling pipeline over the union list
         const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
         const int msh = 31 - (lane & 3);   // membership bit of the query this lane tracks (lanes sub and sub + 4 both track query sub & 3)
-        MuTrack trk[2];   // even / odd passes keep separate trackers: no serial dependency between consecutive passes
-        trk[0].d1 = trk[1].d1 = 0xffffffffu; trk[0].d2 = trk[1].d2 = 0xffffffffu;
-        trk[0].w = trk[1].w = 0; trk[0].tie = trk[1].tie = 0;
+        MuTrack tr;
+        tr.d1 = 0xffffffffu; tr.d2 = 0xffffffffu; tr.w = 0; tr.tie = 0;
         {
             const int npass = (nu + 7) >> 3;
             u32x4 r0[MU_NP], r1[MU_NP];
@@ -288,7 +281,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
                 const uint32_t lo_ = lb0 ? s1_ : s0_, hi_ = lb0 ? s3_ : s2_;                               \
                 const uint32_t mine_ = lb1 ? hi_ : lo_;   /* lanes sub and sub + 4 both track query sub & 3 */ \
                 const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
-                mu_update(trk[(SLOT) & 1], member_ ? mine_ : 0xffffffffu, (ent[SLOT] >> 8) & 0xfffffu);                 \
+                mu_update(tr, member_ ? mine_ : 0xffffffffu, (ent[SLOT] >> 8) & 0xfffffu);                 \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -310,8 +303,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
 #undef MU_SAD
 #undef MU_ISSUE
         }
-        MuTrack tr = trk[0];
-        mu_merge(tr, trk[1]);
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal sub), lane k of group 0 ends up with
         // query k; fetch the original target index, ratio test, store
 #pragma unroll
