@@ -11,8 +11,9 @@
 //   phase 1 one scan of the window for the round: per target a 4-bit membership mask (which of the four
 //           queries has it in radius, Q1 cut included); targets with a non-zero mask go to the union list
 //   phase 2 rolling pipeline over the union list, 8 lanes per row: load the row once, SAD against the four
-//           query rows (held in registers), lanes sub = 0..3 of each 8-lane group keep a running
-//           (min, second min with multiplicity, argmin, tie) for "their" query — no SAD ever goes to memory
+//           query rows (staged per wave in LDS: 8 x ds_read_b128 per pass cost less than the 32 registers that
+//           would hold them — 6 instead of 5 waves per SIMD), lanes sub = 0..3 of each 8-lane group keep a
+//           running (min, second min with multiplicity, argmin, tie) for "their" query — no SAD goes to memory
 //   phase 3 merge the 8 partial trackers per query across the lane groups, ratio test, store
 //
 // Same results as the other matcher kernels.  Irregular rounds (a query with more than K in-radius
@@ -65,8 +66,9 @@ __device__ __forceinline__ void mu_merge(MuTrack& a, const MuTrack& b) {
     a.d2 = d2;
 }
 
-__global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][64];
     __shared__ float2 s_kp[MU_KPCAP];
     __shared__ int s_idx[MU_KPCAP];
     __shared__ int s_qord[MU_QPB];
@@ -189,14 +191,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         }
         if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
         if (!any_live) continue;   // wave uniform
-        // this lane's 2 x 16 B of every query row, straight from global memory: the loads land during the scan
-        u32x4 qa[MU_G], qb[MU_G];
+        // query rows: one word per lane and row from global memory (the loads land during the scan), then LDS
+        uint32_t qw[MU_G];
 #pragma unroll
-        for (int k = 0; k < MU_G; ++k) {
-            const grow_t qr = qrows + (size_t)min(jq[k], q1 - 1) * (VISO_ROW / 8) + sub;   // 16 x 16 B per row
-            qa[k] = qr[0];
-            qb[k] = qr[8];
-        }
+        for (int k = 0; k < MU_G; ++k)
+            qw[k] = ((const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(P.q.rows))[(size_t)min(jq[k], q1 - 1) * (VISO_ROW / 2) + lane];
         // ---------------- phase 1: one scan, membership masks, union list.  entry = mask << 28 | position << 8
         // (mask bit 3 - k = query k)
         int ucnt = 0;
@@ -242,6 +241,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
         __builtin_amdgcn_wave_barrier();
         if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] & 0x0fffffffu;
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < MU_G; ++k) s_qrow[wave][k][lane] = qw[k];
+        __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2: rolling pipeline over the union list
         const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
         const int msh = 31 - (lane & 3);   // membership bit of the query this lane tracks (lanes sub and sub + 4 both track query sub & 3)
@@ -260,14 +262,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MU_THREA
             } while (0)
 #define MU_SAD(K, SLOT)                                                                                    \
             ({                                                                                             \
-                uint32_t s_ = __builtin_amdgcn_sad_u16(r0[SLOT].x, qa[K].x, 0u);                           \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].y, qa[K].y, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].z, qa[K].z, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].w, qa[K].w, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].x, qb[K].x, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].y, qb[K].y, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].z, qb[K].z, s_);                                    \
-                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, qb[K].w, s_);                                    \
+                const u32x4 qa_ = *reinterpret_cast<const u32x4*>(&s_qrow[wave][K][sub * 4]);           \
+                const u32x4 qb_ = *reinterpret_cast<const u32x4*>(&s_qrow[wave][K][sub * 4 + 32]);      \
+                uint32_t s_ = __builtin_amdgcn_sad_u16(r0[SLOT].x, qa_.x, 0u);                             \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].y, qa_.y, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].z, qa_.z, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r0[SLOT].w, qa_.w, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].x, qb_.x, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].y, qb_.y, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].z, qb_.z, s_);                                      \
+                s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, qb_.w, s_);                                      \
                 s_;                                                                                        \
             })
             // four partial SADs per lane, reduced over the 8 lanes of the group together (their DPP steps
