@@ -144,7 +144,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     typedef const __attribute__((address_space(1))) char* gbytes_t;
     // window base (scalar) + 32-bit byte offset per lane: (window position << 8) | (sub << 4)
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
-    const grow_t qrows = (grow_t)reinterpret_cast<const u32x4*>(P.q.rows);
     uint32_t* ul = s_ul[wave];
     const int g8 = lane >> 3, sub = lane & 7;
     unsigned long long scored = 0;

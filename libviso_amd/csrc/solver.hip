@@ -16,6 +16,12 @@ struct SolverArgs {
 };
 
 // ---- stage 1: one lane per (frame, hypothesis): 3-point GN from zero -------
+// Almost every hypothesis converges (or turns singular) within a few iterations; the ~1-2 % that do not run all 100
+// (src/viso.cpp:1622) and would keep their whole wave (and the kernel: a 0.7 ms serial fp64 chain) waiting.  Stage 1
+// therefore stops after VISO_GN_SPLIT iterations and marks the unfinished ones (ok_h = 2, tr_h = state so far);
+// ransac_coop_kernel continues each of them with a whole wave per hypothesis.
+#define VISO_GN_SPLIT 10
+
 __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= a.n_items * a.iters) return;
@@ -31,11 +37,139 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
         bool valid = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
-        if (valid) ok = gn_serial<3>(S.X, S.obs, S.ld, sample, tr, a.sp);
+        if (valid) ok = gn_serial<3>(S.X, S.obs, S.ld, sample, tr, a.sp, 0, VISO_GN_SPLIT);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];
     S.ok_h[h] = ok;
+}
+
+// ---- stage 1b: one WAVE per unfinished hypothesis: iterations VISO_GN_SPLIT..99, same arithmetic ------------
+// Per iteration: lanes 0..2 evaluate the three sincos, every lane builds the rotation; lane (p, j), p < 3 points,
+// j < 6 parameters, computes column j of point p's three Jacobian rows (and the residuals) exactly as
+// accumulate_point does; lanes 0..26 each sum one entry of J^T J / J^T r over the 12 rows in the reference's order;
+// every lane then solves the same 6x6 system redundantly (no broadcast, no divergence).  Values are bit-identical
+// to gn_serial's: only who computes them changes.
+__global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
+    __shared__ double s_J[4][3][3][6];
+    __shared__ double s_res[4][3][4];
+    __shared__ double s_S[4][27];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    if (wave >= (long long)a.n_items * a.iters) return;
+    const int item = (int)(wave / a.iters), h = (int)(wave % a.iters);
+    const SolverItem S = a.items[item];
+    if (S.ok_h[h] != 2) return;                      // wave uniform
+    const int m = *S.m_ptr;
+    int sample[3];
+    if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
+    else viso_sample3(a.seed, S.frame, h, m, sample);
+    const SolverParamsDev& sp = a.sp;
+    const double* X = S.X;
+    const double* obs = S.obs;
+    const int ld = S.ld;
+    double tr[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * h + j];
+    // this lane's Jacobian job: point p (position in the sample), parameter j
+    const int p = min(lane / 6, 2), j = lane % 6;
+    const int ai = p == 0 ? sample[0] : p == 1 ? sample[1] : sample[2];
+    const double X1p = X[0 * ld + ai], Y1p = X[1 * ld + ai], Z1p = X[2 * ld + ai];
+    const double o0 = obs[0 * ld + ai], o1 = obs[1 * ld + ai], o2 = obs[2 * ld + ai], o3 = obs[3 * ld + ai];
+    const double weight = 1.0 / (fabs(obs[0 * ld + p] - sp.cu) / fabs(sp.cu) + 0.05);   // Q6: position, not index
+    // this lane's normal-equation entry: e < 21 -> A[ep][eq] (upper triangle, row major), e >= 21 -> B[e - 21]
+    int ep = 0, eq = 0;
+    {
+        int e = lane, row = 0, len = 6;
+        while (row < 5 && e >= len) { e -= len; ++row; --len; }
+        if (lane < 21) { ep = row; eq = row + e; } else { ep = min(lane - 21, 5); eq = 0; }
+    }
+    int ok = 0;
+    for (int it = VISO_GN_SPLIT; it < 100; ++it) {
+        // rotation: one sincos per lane (lanes 0..2 matter), then the same products as make_rot
+        double sv, cv;
+        const int l3 = lane % 3;
+        sincos(l3 == 0 ? tr[0] : l3 == 1 ? tr[1] : tr[2], &sv, &cv);
+        const double sx = __shfl(sv, 0), cx = __shfl(cv, 0), sy = __shfl(sv, 1), cy = __shfl(cv, 1), sz = __shfl(sv, 2), cz = __shfl(cv, 2);
+        RotDev R;
+        R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
+        R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
+        R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
+        R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
+        R.rdrx10 = +cx * sy * cz - sx * sz; R.rdrx11 = -cx * sy * sz - sx * cz; R.rdrx12 = -cx * cy;
+        R.rdrx20 = +sx * sy * cz + cx * sz; R.rdrx21 = -sx * sy * sz + cx * cz; R.rdrx22 = -sx * cy;
+        R.rdry00 = -sy * cz;      R.rdry01 = +sy * sz;      R.rdry02 = +cy;
+        R.rdry10 = +sx * cy * cz; R.rdry11 = -sx * cy * sz; R.rdry12 = +sx * sy;
+        R.rdry20 = -cx * cy * cz; R.rdry21 = +cx * cy * sz; R.rdry22 = -cx * sy;
+        R.rdrz00 = -cy * sz;                R.rdrz01 = -cy * cz;
+        R.rdrz10 = -sx * sy * sz + cx * cz; R.rdrz11 = -sx * sy * cz - cx * sz;
+        R.rdrz20 = +cx * sy * sz + sx * cz; R.rdrz21 = +cx * sy * cz - sx * sz;
+        // column j of point p (the switch of accumulate_point, evaluated for all three rotation parameters and
+        // selected: the selected value is the one the switch would have computed)
+        double pred[4], X1c, Y1c, Z1c, X2c;
+        predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
+        const double wf = weight * sp.f, iz2 = 1.0 / (Z1c * Z1c);
+        const double y0 = R.rdrx10 * X1p + R.rdrx11 * Y1p + R.rdrx12 * Z1p, z0 = R.rdrx20 * X1p + R.rdrx21 * Y1p + R.rdrx22 * Z1p;
+        const double x1 = R.rdry00 * X1p + R.rdry01 * Y1p + R.rdry02 * Z1p, y1 = R.rdry10 * X1p + R.rdry11 * Y1p + R.rdry12 * Z1p,
+                     z1 = R.rdry20 * X1p + R.rdry21 * Y1p + R.rdry22 * Z1p;
+        const double x2 = R.rdrz00 * X1p + R.rdrz01 * Y1p, y2 = R.rdrz10 * X1p + R.rdrz11 * Y1p, z2 = R.rdrz20 * X1p + R.rdrz21 * Y1p;
+        const double X1cd = j == 0 ? 0.0 : j == 1 ? x1 : j == 2 ? x2 : j == 3 ? 1.0 : 0.0;
+        const double Y1cd = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : j == 4 ? 1.0 : 0.0;
+        const double Z1cd = j == 0 ? z0 : j == 1 ? z1 : j == 2 ? z2 : j == 5 ? 1.0 : 0.0;
+        if (lane < 18) {
+            s_J[wv][p][0][j] = wf * (X1cd * Z1c - X1c * Z1cd) * iz2;
+            s_J[wv][p][1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) * iz2;
+            s_J[wv][p][2][j] = wf * (X1cd * Z1c - X2c * Z1cd) * iz2;
+            if (j == 0) {
+                s_res[wv][p][0] = weight * (o0 - pred[0]);
+                s_res[wv][p][1] = weight * (o1 - pred[1]);
+                s_res[wv][p][2] = weight * (o2 - pred[2]);
+                s_res[wv][p][3] = weight * (o3 - pred[3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // one entry of J^T J / J^T r per lane, summed over points and rows in the reference's order
+        if (lane < 27) {
+            double acc = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jr = (r == 3) ? 1 : r;
+                    const double lhs = s_J[wv][i][jr][ep];
+                    const double rhs = lane < 21 ? s_J[wv][i][jr][eq] : s_res[wv][i][r];
+                    acc += lhs * rhs;
+                }
+            s_S[wv][lane] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // every lane solves the same system
+        double A[6][6], B[6];
+        {
+            int c = 0;
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+                for (int qq = pp; qq < 6; ++qq) A[pp][qq] = s_S[wv][c++];
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) B[pp] = s_S[wv][21 + pp];
+        }
+        __builtin_amdgcn_wave_barrier();   // s_J / s_S are rewritten next iteration
+        symmetrize(A);
+        if (!lu_solve6(A, B)) { ok = 0; break; }      // src/viso.cpp:1602-1606
+        bool converged = true;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj)
+            if (B[jj] > sp.thresh) converged = false;  // Q7
+        if (converged) { ok = 1; break; }
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) tr[jj] = tr[jj] + B[jj];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) S.tr_h[6 * h + jj] = tr[jj];
+        S.ok_h[h] = ok;
+    }
 }
 
 // ---- stage 2: one wave per (frame, hypothesis): support set size -----------
@@ -230,6 +364,8 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     const long long nh = (long long)n_items * iters;
     if (nh > 0) {
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());

@@ -177,10 +177,12 @@ __device__ __forceinline__ void symmetrize(double A[6][6]) {
 // One thread runs the whole Gauss-Newton loop over `n` active points in the
 // reference's summation order (used for the 3-point RANSAC hypotheses: one
 // lane per hypothesis).  Returns 1 (converged) / 0; tr is in/out.
+// Iterations [it_begin, it_end) of the reference's 100; returns 2 when it_end < 100 is reached without a
+// verdict (tr then holds the state after it_end iterations: ransac_coop_kernel continues from there).
 template <int N>
 __device__ inline int gn_serial(const double* X, const double* obs, int ld, const int (&active)[N],
-                                double tr[6], const SolverParamsDev& sp) {
-    for (int it = 0; it < 100; ++it) {
+                                double tr[6], const SolverParamsDev& sp, int it_begin = 0, int it_end = 100) {
+    for (int it = it_begin; it < it_end; ++it) {
         RotDev R;
         make_rot(tr, R);
         double A[6][6], B[6];
@@ -202,7 +204,7 @@ __device__ inline int gn_serial(const double* X, const double* obs, int ld, cons
 #pragma unroll
         for (int j = 0; j < 6; ++j) tr[j] = tr[j] + B[j];
     }
-    return 0;                                     // :1622
+    return it_end >= 100 ? 0 : 2;                 // :1622
 }
 
 // splitmix64-driven selection sampling == viso_ransac_samples (hostmath.cpp)
