@@ -176,7 +176,7 @@ def main():
     # reported when the workload is the one those passes ran (bench.py defaults).
     traffic, traffic_src = None, None
     if args.frames == 256 and args.kp == 2000 and args.width == 1241:
-        for name in ("r01_pmc_v5.json", "r01_pmc_final.json"):
+        for name in ("r01_pmc_v6.json", "r01_pmc_final.json"):
             pmc_path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc_path):
                 continue
