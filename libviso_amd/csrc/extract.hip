@@ -79,43 +79,84 @@ extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, 
 // Sobel of uint8 is an integer in [-1020, 1020], so the u16 path is always exact.
 // One wave = one keypoint at a time: lane l produces elements 2l and 2l+1.
 #define VISO_EXT_KPW 4   // keypoints per wave
+#define VISO_EXT_WIN 13  // 11x11 descriptor window + the 3x3 Sobel's ring
 
+// One wave = VISO_EXT_KPW keypoints: their 13x13 uint8 windows are fetched first (3 bytes per lane and keypoint, all
+// in flight together, BORDER_REFLECT_101 applied to the coordinates), staged in LDS, then lane l produces elements
+// 2l and 2l+1 of every descriptor from LDS.
 __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __restrict__ imgs, int n_img, int cap,
                                                            const uint8_t* __restrict__ images, int rows, int cols) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    __shared__ unsigned char s_win[4][VISO_EXT_KPW][VISO_EXT_WIN * VISO_EXT_WIN + 7];
+    typedef const __attribute__((address_space(1))) uint8_t* gbyte_t;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;
     const long long k0 = wave * VISO_EXT_KPW;
     if (k0 >= (long long)n_img * cap) return;
     const int img = (int)(k0 / cap);           // cap is a multiple of VISO_EXT_KPW
     const ImageView I = imgs[img];
     const int n = *I.n;
     const int j0 = (int)(k0 % cap);
-    const uint8_t* im = images + (size_t)img * rows * cols;
+    if (j0 >= n) return;
+    const int nk = min(VISO_EXT_KPW, n - j0);
+    const gbyte_t im = (gbyte_t)(images + (size_t)img * rows * cols);
+    // keypoint of lane k (k < nk), broadcast below
+    float2 pl = make_float2(0.f, 0.f);
+    if (lane < nk) pl = I.skp[j0 + lane];
+    int px[VISO_EXT_KPW], py[VISO_EXT_KPW];
 #pragma unroll
     for (int k = 0; k < VISO_EXT_KPW; ++k) {
-        const int j = j0 + k;
-        if (j >= n) return;
-        const float2 p = I.skp[j];
-        const int px = (int)rintf(p.x), py = (int)rintf(p.y);   // Point2i p = kp.pt, src/viso.cpp:1013
+        px[k] = (int)rintf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl.x), k)));   // Point2i p = kp.pt, src/viso.cpp:1013
+        py[k] = (int)rintf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl.y), k)));
+    }
+    // window pixel t of keypoint k: image pixel (py - 6 + t / 13, px - 6 + t % 13), coordinates reflected
+    unsigned char w[VISO_EXT_KPW][3];
+#pragma unroll
+    for (int k = 0; k < VISO_EXT_KPW; ++k) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = lane + 64 * u;
+            w[k][u] = 0;
+            if (k < nk && t < VISO_EXT_WIN * VISO_EXT_WIN) {
+                const int wy = t / VISO_EXT_WIN, wx = t - wy * VISO_EXT_WIN;
+                const int ry = py[k] - 6 + wy, rx = px[k] - 6 + wx;
+                // only neighbours of in-image centres (0 < y < rows, 0 < x < cols) are ever read: rows 0..rows,
+                // columns 0..cols, of which only `rows` / `cols` themselves need the reflection
+                if (ry >= 0 && ry <= rows && rx >= 0 && rx <= cols)
+                    w[k][u] = im[(size_t)reflect101(ry, rows) * cols + reflect101(rx, cols)];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VISO_EXT_KPW; ++k)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = lane + 64 * u;
+            if (t < VISO_EXT_WIN * VISO_EXT_WIN) s_win[wv][k][t] = w[k][u];
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < VISO_EXT_KPW; ++k) {
+        if (k >= nk) break;                       // wave uniform
+        const unsigned char* win = s_win[wv][k];
         uint32_t packed = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 2 * lane + h;
             int v = 0;
             if (c < 121) {
-                const int y = py + c / 11 - 5, x = px + c % 11 - 5;
+                const int ey = c / 11, ex = c - ey * 11;
+                const int y = py[k] + ey - 5, x = px[k] + ex - 5;
                 if (y > 0 && y < rows && x > 0 && x < cols) {   // strict > 0, src/viso.cpp:1018
-                    const int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows);
-                    const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
-                    const uint8_t* r0 = im + (size_t)ym * cols;
-                    const uint8_t* r1 = im + (size_t)y * cols;
-                    const uint8_t* r2 = im + (size_t)yp * cols;
-                    v = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+                    // Sobel centre = window (ey + 1, ex + 1); rows y-1, y, y+1 = window rows ey, ey+1, ey+2
+                    const unsigned char* r0 = win + ey * VISO_EXT_WIN + ex;
+                    const unsigned char* r1 = r0 + VISO_EXT_WIN;
+                    const unsigned char* r2 = r1 + VISO_EXT_WIN;
+                    v = ((int)r0[2] - (int)r0[0]) + 2 * ((int)r1[2] - (int)r1[0]) + ((int)r2[2] - (int)r2[0]);
                 }
             }
             packed |= ((uint32_t)(v + VISO_BIAS) & 0xffffu) << (16 * h);
         }
-        reinterpret_cast<uint32_t*>(I.rows + (size_t)j * VISO_ROW)[lane] = packed;
+        reinterpret_cast<uint32_t*>(I.rows + (size_t)(j0 + k) * VISO_ROW)[lane] = packed;
     }
 }
 
