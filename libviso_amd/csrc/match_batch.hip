@@ -1,19 +1,19 @@
-// match_batch.hip — third implementation of the u16 matcher: same tile / window
-// / L2-gather data path as match_kernel<false, EPI> (match.hip), but every wave
-// batches the work of FOUR queries:
+// match_batch.hip — u16 matcher in rounds of FOUR queries per wave: the stereo instantiation <1> is the default
+// for the stereo call of every frame (match_union.hip takes the temporal calls); <0> is the previous temporal
+// kernel, still selectable.  Same tile / window data path as match_kernel<false, EPI> (match.hip).
 //
-//   phase 1  per query: scan the tile's target window (LDS), (stereo) Sampson
-//            gate, append the surviving candidates to the wave's pair list in LDS
-//   phase 2  one uniform loop over ALL pairs of the four queries: 8 lanes per
-//            pair, two 16-B global loads of the target row + two LDS reads of
-//            the (staged) query row, 8 x v_sad_u16, 3 DPP adds, SAD -> LDS.
-//            Passes are always full and independent of each other (no per-query
-//            tracker, no tail passes, loads of consecutive passes overlap)
-//   phase 3  per query: wave-wide min / second-min / count over its SAD segment
+//   phase 1  one scan of the tile's target window (LDS, NaN padded) for the round's four queries: per-query
+//            candidate segments in LDS; (stereo) fp64 Sampson gate, one candidate per lane, in-place compaction
+//   phase 1b the segments are closed up into one contiguous list, entry = query << 30 | row byte offset, padded so
+//            that neither the last pass nor the passes the pipeline runs ahead need a bounds test
+//   phase 2  rolling pipeline over ALL pairs of the four queries: 8 lanes per pair, two 16-B global loads of the
+//            target row + two LDS reads of the staged query row, 8 x v_sad_u16, 3 DPP adds, SAD -> LDS; two
+//            passes reduced together so that their DPP wait states interleave
+//   phase 3  per query: wave-wide min / second min (with multiplicity) / count over its SAD segment — or, when
+//            all four lists hold at most 16 pairs (the stereo call), one 16-lane row per query, all four at once
 //
-// Same results as the other two kernels.  Irregular queries (more than K or 255
-// in-radius candidates, no room in the pair list, an exact SAD tie) go to
-// match_overflow_kernel.
+// Same results as the other kernels.  Irregular queries (more than K or 128 in-radius candidates, an exact SAD
+// tie) go to match_overflow_kernel.
 #include "common.h"
 #include "match_dev.h"
 
