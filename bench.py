@@ -4,9 +4,17 @@
 A "step" is one pass of the hot path over one batch of synthetic frames that is
 already resident in HBM: by default BASELINE.json configs[1] (1241x376,
 ~2k features/frame, SAD matcher only = pack + 3 match_desc per frame incl. the
-final sort).  The same line also reports configs[2] (matcher + circle join +
-RANSAC/Gauss-Newton, end to end) under "end_to_end", the matcher kernel's
-roofline figures and the CPU oracle timed on the host ("cpu_baseline").
+final sort).  The same JSON line also carries
+
+  end_to_end   configs[2]: matcher + circle join + RANSAC/Gauss-Newton
+  streaming    every step consumes FRESH host frames through pinned asynchronous
+               uploads (feature-in and image-in): the PCIe-inclusive rate
+  roofline     the dominant kernel against the ceilings that can bound it, each
+               a fraction <= 1: HBM (PMC bytes), L2 (PMC requests), VALU issue
+               (PMC instructions), v_sad_u16 issue (scored pairs); kernel time
+               from a single-stream pass measured live with HIP events
+  cpu_baseline the CPU oracle on the host cores: per stage, matcher-only and
+               end to end on one thread, and frames-parallel on all cores
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--kp N]
 
@@ -17,6 +25,7 @@ subsequence: weak scaling), no data-path collective; RCCL only gathers the
 final trajectory in the end-to-end leg.
 """
 import argparse
+import concurrent.futures
 import json
 import os
 import sys
@@ -28,7 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+L2_GATHER_PEAK_GBS = 18800.0   # "Indexed rows: gather": rows shared by every workgroup, served by the XCD's L2, chip-wide
+L2_STREAM_PEAK_GBS = 34500.0   # "L2 (per XCD)": aggregate
+N_SIMD = 1024                  # 256 CUs x 4 SIMD-32
+CLK_GHZ = 2.4                  # max clock: a wave64 VALU instruction occupies its SIMD for 2 cycles
+L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
+PROFILE_ROUND = "r02"
 
 
 def b_alg_bytes(n, scored, m_out, dlen=121):
@@ -48,6 +64,98 @@ def b_alg_bytes(n, scored, m_out, dlen=121):
     return stereo, temporal
 
 
+def b_min_bytes(n, m_out, dlen=121, elem=4):
+    """Compulsory bytes: (8 + elem D)(N1 + N2) + 12 M_out per call; elem = 4 for the reference's
+    f32 boundary layout, 2 for the packed u16 rows the matcher kernels actually read (256-B rows).
+    Returns (stereo, temporal)."""
+    nf = n.shape[0]
+    row = elem * dlen if elem == 4 else 256
+    stereo = temporal = 0
+    for t in range(nf):
+        nL, nR = int(n[t, 0]), int(n[t, 1])
+        stereo += (8 + row) * (nL + nR) + 12 * int(m_out[0, t])
+        if t == 0:
+            continue
+        pL, pR = int(n[t - 1, 0]), int(n[t - 1, 1])
+        temporal += (8 + row) * (nL + pL) + 12 * int(m_out[1, t]) + (8 + row) * (nR + pR) + 12 * int(m_out[2, t])
+    return stereo, temporal
+
+
+def workload_name(args):
+    geo = f"synthetic {args.width}x{args.height} stereo pairs, {args.kp} features/image"
+    if (args.width, args.height, args.kp) == (1241, 376, 2000):
+        tag = "configs[1]"
+    elif (args.width, args.height, args.kp) == (2048, 1024, 8000):
+        tag = "configs[4] geometry, matcher only, this rank's share"
+    else:
+        tag = "custom geometry"
+    return f"{tag}: {geo}, SAD matcher only (pack + 3 match_desc/frame + sort)"
+
+
+def load_pmc(kname, default_workload):
+    """Counter figures of the committed rocprofv3 --pmc passes (profiles/, tools/profile_round.sh + tools/pmc_batch.sh,
+    `--streams 1`, this command's defaults).  PMC counters cannot be read from inside this process; they are only
+    used when the workload is the one those passes ran."""
+    out = {"hbm_bytes": None, "sq": None, "src": []}
+    if not default_workload:
+        return out
+    p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm.json")
+    if os.path.exists(p):
+        d = json.load(open(p))
+        if kname in d.get("kernel", ""):
+            out["hbm_bytes"] = d["hbm_bytes_per_launch_corrected"]
+            out["src"].append(f"profiles/{PROFILE_ROUND}_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                              "one stream, gfx950 x2 fetch correction)")
+    p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_sq.json")
+    if os.path.exists(p):
+        d = json.load(open(p))
+        for k, v in d.items():
+            if kname in k:
+                out["sq"] = v
+                out["src"].append(f"profiles/{PROFILE_ROUND}_pmc_sq.json (rocprofv3 --pmc SQ_* / TCP_* passes, one stream)")
+                break
+    return out
+
+
+def cpu_baseline(seq, st, tm, budget_s):
+    """The oracle (C restatement of the reference's CPU path, -O2) timed on the host cores.  Never on the measured
+    GPU path; outside every GPU timed region."""
+    from oracle import pyoracle   # checker/baseline only
+    nf = seq["kp"].shape[0]
+
+    def run(lo, hi, matcher_only):
+        t0 = time.perf_counter()
+        o = pyoracle.sequence(seq["kp"][lo:hi], seq["desc"][lo:hi], seq["n"][lo:hi], st, tm, seq["param"],
+                              seed=1, first_frame=lo, matcher_only=matcher_only)
+        return time.perf_counter() - t0, o
+
+    # calibrate on 2 pairs, then size every sample to ~budget/4
+    t_cal, _ = run(0, 3, True)
+    per_pair = t_cal / 2
+    k = int(max(2, min(nf - 1, (budget_s / 4) / per_pair)))
+    t_m, o_m = run(0, k + 1, True)
+    t_e, o_e = run(0, k + 1, False)
+    stg = o_e["stage_s"]
+    cores = min(16, len(os.sched_getaffinity(0)))   # the GPU box gives one GPU's CPU share: 16
+    kc = int(max(2, min((nf - 1) // cores, k)))
+    chunks = [(i * kc, i * kc + kc + 1) for i in range(cores)]
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL during the call
+        list(ex.map(lambda c: run(c[0], c[1], False), chunks))
+    t_all = time.perf_counter() - t0
+    return {"value": k / t_m, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C restatement of src/viso.cpp, -O2, 1 thread) matcher-only (configs[1]) on the first {k} "
+                      f"frame pairs of the same batch, {t_m:.1f} s; the reference itself cannot be built here (OpenCV/Boost/Eigen absent)",
+            "end_to_end": {"value": k / t_e, "unit": "frames/s", "cores": 1,
+                           "sample": f"configs[2] (matcher + circle + RANSAC/GN) on the same {k} pairs, {t_e:.1f} s"},
+            "stage_seconds_per_frame": {"neighbour_search": stg[4] / k, "gate_and_sad_walk": (stg[0] - stg[4]) / k,
+                                        "match_circle": stg[1] / k, "collect_triangulate_gather": stg[2] / k,
+                                        "ransac_gauss_newton": stg[3] / k},
+            "all_cores": {"value": kc * cores / t_all, "unit": "frames/s", "cores": cores,
+                          "sample": f"configs[2], {cores} threads x {kc} frame pairs each (frames-parallel; the reference is "
+                                    f"single threaded), {t_all:.1f} s", "nproc": len(os.sched_getaffinity(0))}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,17 +165,18 @@ def main():
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline samples (all of them)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--matcher", type=int, default=3, help="3 = union kernel (default: one row load scored against 4 queries), 2 = wave-batched gather kernel, 0 = per-query gather kernel, 1 = LDS tile kernel")
+    ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--matcher", type=int, default=None, help="kernel for the temporal calls (viso_ctx_set_matcher); default: the build's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true",
-                    help="also time the image-in pipeline (device-side descriptor extraction) on synthetic images")
+                    help="also time the resident image-in pipeline (device-side descriptor extraction / Harris) on synthetic images")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight per GPU, one HIP stream each (steps go round robin over them)")
-    ap.add_argument("--ab-variants", default="0,1,2", help="matcher variants timed by --ab")
-    ap.add_argument("--ab", action="store_true", help="also time the other matcher variant, interleaved, same process")
+    ap.add_argument("--ab-variants", default="", help="matcher variants timed by --ab (default: all of the build)")
+    ap.add_argument("--ab", action="store_true", help="also time the other matcher variants, interleaved, same process")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +203,7 @@ def main():
     from libviso_amd import synth
     from libviso_amd.abi import MatchParams
 
-    libviso_amd.set_matcher_variant(args.matcher)
+    variant = args.matcher if args.matcher is not None else libviso_amd.DEFAULT_MATCHER
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
     seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
@@ -104,6 +213,7 @@ def main():
     lanes = []
     for _ in range(n_streams):
         c = libviso_amd.Context(dev_index)
+        libviso_amd.set_matcher_variant(variant, c)
         b = libviso_amd.Batch(c, nf, args.kp)
         b.upload(seq["kp"], seq["desc"], seq["n"])
         b.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
@@ -120,14 +230,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(fn, steps, warmup):
-        """fn(batch) is called once per step, round robin over the streams."""
+    def timed(fn, steps, warmup, objs=None):
+        """fn(obj) is called once per step, round robin over the per-stream objects (default: the resident batches)."""
+        objs = objs or [b for _, b in lanes]
         for i in range(warmup):
-            fn(lanes[i % n_streams][1])
+            fn(objs[i % len(objs)])
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            fn(lanes[i % n_streams][1])
+            fn(objs[i % len(objs)])
         sync_all()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -151,50 +262,89 @@ def main():
         kern_ms_sum += ms * n
         kern_n += n
         b.kernel_timing(False)
-    kern_ms = kern_ms_sum / max(kern_n, 1)
-    # the same kernel with nothing else on the GPU (one stream, untimed): with several streams the events of
-    # the timed region also see the other streams' kernels sharing the CUs
-    batch.kernel_timing(True)
-    for _ in range(4):
-        batch.run_matcher()
-    ctx.synchronize()
-    kern_ms_alone, _ = batch.kernel_ms()
-    batch.kernel_timing(False)
+    kern_ms_region = kern_ms_sum / max(kern_n, 1)
     frames_total = args.frames * args.steps * world
     fps = frames_total / dt
+
+    # ---- the dominant kernel alone: a single-stream pass, HIP events on its stream ------------
+    # (with several streams the events of the timed region also see the other streams' kernels sharing the CUs,
+    # so that figure can exceed the step time; the roofline uses this pass)
+    n_single = max(8, min(40, args.steps))
+    for _ in range(2):
+        batch.run_matcher()
+    ctx.synchronize()
+    batch.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(n_single):
+        batch.run_matcher()
+    ctx.synchronize()
+    step_ms_single = (time.perf_counter() - t0) * 1e3 / n_single
+    kern_ms, kern_n1 = batch.kernel_ms()
+    batch.kernel_timing(False)
+
     scored, m_out = batch.counters()
     balg_stereo, balg_temporal = b_alg_bytes(seq["n"], scored, m_out)
-    kname = libviso_amd.load().viso_matcher_kernel_name().decode()
-    # the timed kernel: the temporal instantiation of the gather matcher (2 of the 3 match_desc calls
-    # per frame, ~97 % of the scored pairs) or the tile kernel, which handles all three
-    temporal_only = kname in ("match_kernel<false, 0>", "match_batch_kernel<0>", "match_union_kernel")
-    balg = balg_temporal if temporal_only else balg_stereo + balg_temporal
-    pairs = int(scored[1:].sum()) if temporal_only else int(scored.sum())
-    achieved = balg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the figure
-    # comes from the committed rocprofv3 --pmc passes of this same command (profiles/), and is only
-    # reported when the workload is the one those passes ran (bench.py defaults).
-    traffic, traffic_src = None, None
-    if args.frames == 256 and args.kp == 2000 and args.width == 1241:
-        for name in ("r01_pmc_v6.json", "r01_pmc_final.json"):
-            pmc_path = os.path.join(ROOT, "profiles", name)
-            if not os.path.exists(pmc_path):
-                continue
-            pmc = json.load(open(pmc_path))
-            if kname in pmc.get("kernel", ""):
-                traffic = pmc["hbm_bytes_per_launch_corrected"]
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
-                break
+    bmin32_s, bmin32_t = b_min_bytes(seq["n"], m_out, elem=4)
+    bmin16_s, bmin16_t = b_min_bytes(seq["n"], m_out, elem=2)
+    kname = libviso_amd.matcher_kernel_name(ctx)
+    pairs = int(scored[1:].sum())              # the timed kernel takes the temporal problems (2 of 3 calls, ~97 % of the pairs)
+    t_k = kern_ms * 1e-3
+    default_workload = (args.frames, args.kp, args.width, args.height) == (256, 2000, 1241, 376)
+    pmc = load_pmc(kname, default_workload)
+    ceilings = {}
+    # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
+    # elements = one (query, candidate) pair; a SIMD-32 issues one per 2 cycles
+    sad_peak = N_SIMD * CLK_GHZ * 1e9 / 2
+    ceilings["sad_valu"] = {"achieved": pairs / t_k, "peak": sad_peak, "unit": "scored pairs/s",
+                            "frac": pairs / t_k / sad_peak,
+                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each, 2 cycles per instruction per SIMD-32, 1024 SIMDs at 2.4 GHz"}
+    if pmc["hbm_bytes"] is not None:
+        a = pmc["hbm_bytes"] / t_k / 1e9
+        ceilings["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                           "what": "PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) / live single-stream kernel time"}
+    if pmc["sq"] is not None:
+        sq = pmc["sq"]
+        if "SQ_INSTS_VALU" in sq:
+            v = sq["SQ_INSTS_VALU"] * 2 / (N_SIMD * CLK_GHZ * 1e9) / t_k
+            ceilings["valu_issue"] = {"achieved": sq["SQ_INSTS_VALU"] / t_k, "peak": sad_peak, "unit": "VALU wave-instructions/s",
+                                      "frac": v, "what": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"}
+        if "TCP_TCC_READ_REQ_sum" in sq:
+            l2b = sq["TCP_TCC_READ_REQ_sum"] * L2_REQ_BYTES
+            peak = L2_GATHER_PEAK_GBS if kname == "match_union_kernel" else L2_STREAM_PEAK_GBS
+            a = l2b / t_k / 1e9
+            ceilings["l2"] = {"achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak,
+                              "what": "TCP_TCC_READ_REQ_sum x 128 B (row gathers served by the XCD L2) against the guide's "
+                                      + ("indexed-row gather rate" if kname == "match_union_kernel" else "aggregate L2 rate")}
+    bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
+    top = ceilings[bound]
+    roofline = {
+        "bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+        "traffic": pmc["hbm_bytes"], "traffic_source": "; ".join(pmc["src"]) or None,
+        "kernel": kname, "kernel_ms": kern_ms, "kernel_launches": kern_n1,
+        "kernel_ms_source": f"HIP events on the kernel's stream, {kern_n1} launches, ONE batch in flight (step alone: {step_ms_single:.3f} ms)",
+        "kernel_ms_in_timed_region_overlapped": kern_ms_region,
+        "kernel_ms_in_timed_region_note": f"{n_streams} batches in flight share the CUs: not a per-step cost, may exceed ms_per_step",
+        "ceilings": ceilings,
+        "scored_pairs_per_launch": pairs,
+        "effective_bandwidth": {"algorithmic_bytes_per_launch": balg_temporal, "GB/s": balg_temporal / t_k / 1e9,
+                                "note": "SURVEY 8(d) B_alg (every scored pair counted as a fresh 484-B f32 row) / kernel time: an "
+                                        "effective figure served by L2/LDS, not comparable with the HBM peak"},
+        "compulsory_bytes": {"per_launch_f32_boundary": bmin32_t, "per_launch_u16_rows": bmin16_t,
+                             "per_step_all_calls_f32_boundary": bmin32_s + bmin32_t,
+                             "hbm_frac_if_only_compulsory_u16": bmin16_t / t_k / 1e9 / HBM_PEAK_GBS},
+        "algorithmic_bytes_per_step_all_calls": balg_stereo + balg_temporal,
+    }
 
     ab = None
     if args.ab:   # interleaved rounds in ONE process (cdna guide rule 24)
-        known = {0: "match_kernel<false, 0>", 1: "match_tile_kernel", 2: "match_batch_kernel<0>", 3: "match_union_kernel"}
-        names = {int(v): known.get(int(v), "variant %s" % v) for v in args.ab_variants.split(",")}
-        rounds = {v: [] for v in names}
-        walls = {v: [] for v in names}
+        vs = [int(v) for v in args.ab_variants.split(",")] if args.ab_variants else list(libviso_amd.MATCHER_VARIANTS)
+        rounds = {v: [] for v in vs}
+        walls = {v: [] for v in vs}
+        names = {}
         for _ in range(5):
-            for v in names:
-                libviso_amd.set_matcher_variant(v)
+            for v in vs:
+                libviso_amd.set_matcher_variant(v, ctx)
+                names[v] = libviso_amd.matcher_kernel_name(ctx)
                 batch.kernel_timing(True)
                 for _ in range(4):
                     batch.run_matcher()
@@ -205,10 +355,10 @@ def main():
                     batch.run_matcher()
                 ctx.synchronize()
                 walls[v].append((time.perf_counter() - t0) * 1e3 / 4)
-        libviso_amd.set_matcher_variant(args.matcher)
-        ab = {"timed_kernel_ms_median": {names[v]: float(np.median(rounds[v])) for v in names},
-              "run_matcher_ms_median": {names[v]: float(np.median(walls[v])) for v in names},
-              "note": "timed kernel = temporal instantiation only for variants 0 and 2, the whole u16 kernel for 1"}
+        libviso_amd.set_matcher_variant(variant, ctx)
+        ab = {"timed_kernel_ms_median": {names[v]: float(np.median(rounds[v])) for v in vs},
+              "run_matcher_ms_median": {names[v]: float(np.median(walls[v])) for v in vs},
+              "note": "timed kernel = the kernel that takes the temporal problems; one stream"}
 
     # ---- configs[2]: end to end (matcher + circle + RANSAC/GN) ---------------
     e2e = None
@@ -225,27 +375,81 @@ def main():
                "poses_ok": int(ok[1:].sum()), "frames": int(args.frames),
                "max_abs_tr_err_vs_ground_truth": err}
 
-    # ---- image-in pipeline: uint8 images + keypoints resident in HBM ---------
+    # ---- streaming: every step consumes fresh host frames (pinned, asynchronous, stream ordered) -------------
+    # sequence_odometry reads new images every frame (src/viso.cpp:1205-1231); the resident figures above never
+    # touch PCIe.  Two different host sequences (the batch's and its time reversal: other pairs, other poses)
+    # alternate, so no step re-reads what the device already holds; copies on one lane's stream overlap the other
+    # lanes' kernels.
+    streaming = None
+    iseq = None
+    nfi = min(nf, 65)
+    if not args.no_streaming:
+        hosts = []
+        for rev in (False, True):
+            pk = libviso_amd.PinnedArray(seq["kp"].shape, np.float32)
+            pd = libviso_amd.PinnedArray(seq["desc"].shape, np.float32)
+            pk.a[...] = seq["kp"][::-1] if rev else seq["kp"]
+            pd.a[...] = seq["desc"][::-1] if rev else seq["desc"]
+            hosts.append((pk, pd, np.ascontiguousarray(seq["n"][::-1] if rev else seq["n"])))
+        cnt = {"i": 0}
+
+        def stream_step(full):
+            def f(b):
+                pk, pd, nn = hosts[cnt["i"] % 2]
+                cnt["i"] += 1
+                b.upload_async(pk.a, pd.a, nn)
+                (b.run if full else b.run_matcher)()
+            return f
+        s_steps = max(2 * n_streams, args.steps // 4)
+        dts = timed(stream_step(False), s_steps, n_streams)
+        dte = timed(stream_step(True), s_steps, n_streams) if not args.no_e2e else None
+        bytes_step = seq["kp"].nbytes + seq["desc"].nbytes + seq["n"].nbytes
+        streaming = {"feature_in": {"fps_matcher": args.frames * s_steps * world / dts,
+                                    "fps_end_to_end": args.frames * s_steps * world / dte if dte else None,
+                                    "host_bytes_per_step": bytes_step, "pcie_GBps": bytes_step * s_steps / dts / 1e9,
+                                    "workload": "every step: viso_batch_upload_async of N x 121 f32 descriptors + keypoints from pinned "
+                                                "host memory, then the resident pipeline; alternating between two different sequences"}}
+        for pk, pd, _ in hosts:
+            pk.close(); pd.close()
+        for _, b in lanes:   # the resident legs below expect the original sequence
+            b.upload(seq["kp"], seq["desc"], seq["n"])
+        # image-in: uint8 images + keypoints cross PCIe, descriptors are extracted on the device
+        iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
+        ibs, ihosts = [], []
+        for c, _ in lanes:
+            ib = libviso_amd.Batch(c, nfi, args.kp)
+            ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
+            ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
+            ibs.append(ib)
+        for rev in (False, True):
+            pi = libviso_amd.PinnedArray(iseq["images"].shape, np.uint8)
+            pk = libviso_amd.PinnedArray(iseq["kp"].shape, np.float32)
+            pi.a[...] = iseq["images"][::-1] if rev else iseq["images"]
+            pk.a[...] = iseq["kp"][::-1] if rev else iseq["kp"]
+            ihosts.append((pi, pk, np.ascontiguousarray(iseq["n"][::-1] if rev else iseq["n"])))
+
+        def img_step(b):
+            pi, pk, nn = ihosts[cnt["i"] % 2]
+            cnt["i"] += 1
+            b.upload_images_async(pi.a, pk.a, nn)
+            b.run_images(False)
+        i_steps = max(2 * n_streams, args.steps // 2)
+        dti = timed(img_step, i_steps, n_streams, objs=ibs)
+        ibytes = iseq["images"].nbytes + iseq["kp"].nbytes + iseq["n"].nbytes
+        streaming["image_in"] = {"fps_end_to_end": (nfi - 1) * i_steps * world / dti, "frames_per_step": nfi - 1,
+                                 "host_bytes_per_step": ibytes, "pcie_GBps": ibytes * i_steps / dti / 1e9,
+                                 "workload": "every step: uint8 stereo images + keypoints uploaded asynchronously from pinned memory -> "
+                                             "Sobel descriptor windows on device -> matcher + circle + RANSAC/GN"}
+        for pi, pk, _ in ihosts:
+            pi.close(); pk.close()
+        for ib in ibs:
+            ib.close()
+
+    # ---- resident image-in pipeline: uint8 images + keypoints already in HBM ---------
     e2e_img = None
     if args.images:
-        nfi = min(nf, 65)
-        iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
-        def timed_lanes(objs, fn, steps, warmup):
-            """round robin over per-stream objects (image-mode batches), same clock discipline as timed()"""
-            for i in range(warmup):
-                fn(objs[i % len(objs)])
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                fn(objs[i % len(objs)])
-            sync_all()
-            d = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([d], dtype=torch.float64, device=coll_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                d = float(t.item())
-            return d
-
+        if iseq is None:
+            iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
         isteps = max(n_streams, args.steps // 2)
         ibs = []
         for c, _ in lanes:   # one image batch per stream, same synthetic frames in each
@@ -253,10 +457,10 @@ def main():
             ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
             ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
             ibs.append(ib)
-        dt3 = timed_lanes(ibs, lambda b: b.run_images(False), isteps, n_streams)
+        dt3 = timed(lambda b: b.run_images(False), isteps, n_streams, objs=ibs)
         tri, oki, _ = ibs[0].poses()
         e2e_img = {"fps": (nfi - 1) * isteps * world / dt3, "frames": nfi - 1,
-                   "workload": "uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
+                   "workload": "resident uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
                    "poses_ok": int(oki[1:].sum()),
                    "max_abs_tr_err_vs_ground_truth": float(np.abs(tri[1:][oki[1:] == 1] - iseq["tr_gt"][1:][oki[1:] == 1]).max()) if oki[1:].any() else None}
         for ib in ibs:
@@ -272,37 +476,20 @@ def main():
         def detect_and_run(b):
             b.detect()
             b.run_images(False)
-        dt4 = timed_lanes(dbs, detect_and_run, isteps, n_streams)
+        dt4 = timed(detect_and_run, isteps, n_streams, objs=dbs)
         trd, okd, _ = dbs[0].poses()
         e2e_img["with_harris_detection"] = {
             "fps": (nfi - 1) * isteps * world / dt4,
-            "workload": "uint8 images only -> binned Harris (1200 corners/image, 24x5 bins) -> descriptors -> matcher + circle + RANSAC/GN",
+            "workload": "resident uint8 images only -> binned Harris (1200 corners/image, 24x5 bins) -> descriptors -> matcher + circle + RANSAC/GN",
             "poses_ok": int(okd[1:].sum()),
             "max_abs_tr_err_vs_ground_truth": float(np.abs(trd[1:][okd[1:] == 1] - iseq["tr_gt"][1:][okd[1:] == 1]).max()) if okd[1:].any() else None}
         for db in dbs:
             db.close()
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
+    # ---- CPU baseline: the oracle on bounded samples of the same workload (rank 0, N = 1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import pyoracle   # checker/baseline only; never on the measured path
-        n_s = 2
-        t_used, frames_done = 0.0, 0
-        per_frame = None
-        while True:
-            hi = min(nf, 1 + n_s)
-            t0 = time.perf_counter()
-            pyoracle.sequence(seq["kp"][:hi], seq["desc"][:hi], seq["n"][:hi], st, tm, seq["param"],
-                              seed=1, matcher_only=True)
-            t_used = time.perf_counter() - t0
-            frames_done = hi - 1
-            per_frame = t_used / frames_done
-            if t_used >= args.cpu_seconds * 0.5 or hi == nf:
-                break
-            n_s = min(nf - 1, max(n_s * 2, int(args.cpu_seconds / per_frame)))
-        cpu = {"value": frames_done / t_used, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"oracle (C restatement, -O2, 1 thread) matcher-only on the first {frames_done} "
-                         f"frame pairs of the same batch, {t_used:.1f} s"}
+        cpu = cpu_baseline(seq, st, tm, args.cpu_seconds)
 
     if rank == 0:
         line = {
@@ -311,30 +498,22 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic {args.width}x{args.height} stereo pairs, "
-                                   f"{args.kp} features/image, SAD matcher only (pack + 3 match_desc/frame + sort)",
-                       "frames_per_step_per_gpu": args.frames, "parallelism": f"frames sharded over {world} rank(s), no collective; {n_streams} batches in flight per GPU (one HIP stream each)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname,
-                         "kernel_ms_avg": kern_ms, "kernel_launches": kern_n,
-                         "kernel_ms_single_stream": kern_ms_alone,
-                         "achieved_single_stream": balg / (kern_ms_alone * 1e-3) / 1e9 if kern_ms_alone > 0 else None,
-                         "algorithmic_bytes_per_launch": balg,
-                         "scored_pairs_per_launch": pairs,
-                         "algorithmic_bytes_per_step_all_calls": balg_stereo + balg_temporal,
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes (f32 boundary accounting) / HIP-event kernel time in the "
-                                 "timed region (with several streams the kernel shares the CUs with the other batches' kernels; "
-                                 "*_single_stream = the same launch alone); a tiled kernel serves most of the bytes from L2/LDS, "
-                                 "so this is effective bandwidth"},
+            "config": {"workload": workload_name(args),
+                       "frames_per_step_per_gpu": args.frames,
+                       "residency": "inputs resident in HBM when the timed region starts (the PCIe-inclusive rate is under \"streaming\")",
+                       "parallelism": f"frames sharded over {world} rank(s), no collective; {n_streams} batches in flight per GPU (one HIP stream each)"},
+            "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "streaming": streaming,
             "end_to_end_from_images": e2e_img,
             "matcher_ab": ab,
         }
         print(json.dumps(line), flush=True)
-    batch.close()
-    ctx.close()
+    for c, b in lanes:
+        b.close()
+    for c, b in lanes:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

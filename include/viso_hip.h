@@ -77,10 +77,20 @@ typedef struct viso_ctx viso_ctx;
 /* device: HIP device ordinal.  stream: a hipStream_t to run on, or NULL to let
  * the context create its own.  Returns NULL on failure (viso_last_error()). */
 viso_ctx* viso_ctx_create(int device, void* stream);
-void viso_ctx_destroy(viso_ctx* ctx);
+/* Waits for the stream, frees the context.  VISO_OK, or VISO_ERR_HIP with the first HIP error met in
+ * viso_last_error() (everything that can be freed still is).  Destroy batches first, and destroy both before
+ * the process starts exiting: not from static destructors that may run after the HIP runtime's own. */
+int viso_ctx_destroy(viso_ctx* ctx);
 /* hipStream_t the context launches on. */
 void* viso_ctx_stream(viso_ctx* ctx);
 int viso_ctx_synchronize(viso_ctx* ctx);
+/* Which kernel takes the temporal match_desc calls of this context (ctx == NULL: the default context of the
+ * plain family): 3 = match_union_kernel (rows gathered from L2, one row load scored against four y-adjacent
+ * queries).  Identical results from every variant; the parity tests run all of them.  Further variants exist in
+ * -DVISO_DEBUG_VARIANTS builds only.  Returns VISO_ERR_ARG for a variant this build does not have. */
+int viso_ctx_set_matcher(viso_ctx* ctx, int variant);
+/* Name of that kernel as it appears in rocprofv3 summaries. */
+const char* viso_ctx_matcher_kernel_name(viso_ctx* ctx);
 const char* viso_last_error(void);
 /* "libviso_hip <version> gfx950 ..." */
 const char* viso_version(void);
@@ -178,12 +188,26 @@ int viso_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_feat
 typedef struct viso_batch viso_batch;
 
 viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, int dlen);
-void viso_batch_destroy(viso_batch* b);
+/* Waits for the context's stream, frees the batch; return value as viso_ctx_destroy. */
+int viso_batch_destroy(viso_batch* b);
+
+/* Stream rule for everything below: a batch's kernels run asynchronously on its context's stream.  Every call
+ * that writes batch inputs (upload*, set_params, detect) is ordered against that stream — the synchronous ones
+ * wait for it, the *_async ones are enqueued on it — so it is safe to call them while a run is in flight.
+ * Every entry point selects the context's device (hipSetDevice) first: one process may drive several GPUs. */
 
 /* Upload host data for frames [f0, f0+nf) (layout as above, tightly packed
- * over nf frames).  Synchronous copy. */
+ * over nf frames).  Synchronous: returns when the data is on the device. */
 int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
                       const float* desc, const int32_t* n);
+/* Same, enqueued on the context's stream: returns at once.  The host buffers must stay untouched until the
+ * stream has passed the copies (viso_ctx_synchronize / any result getter of a later run).  Buffers from
+ * viso_host_alloc (pinned) are copied by DMA and overlap kernels of other contexts: the streaming mode of a
+ * host that feeds new frames every step (sequence_odometry consumes fresh data per frame, src/viso.cpp:1205-1231). */
+int viso_batch_upload_async(viso_batch* b, int f0, int nf, const float* kp,
+                            const float* desc, const int32_t* n);
+void* viso_host_alloc(size_t bytes);
+int viso_host_free(void* p);
 /* Device pointers of the boundary-layout buffers, for producers that already
  * live on the GPU (a device-side extractor, torch): kp, desc, n as above. */
 int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, void** n);
@@ -207,6 +231,10 @@ int viso_batch_run(viso_batch* b);
 int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
                              const float* kp, const int32_t* n);
 int viso_batch_run_images(viso_batch* b, int matcher_only);
+/* viso_batch_upload_images enqueued on the stream (see viso_batch_upload_async); the image buffers must already
+ * exist for this geometry (one synchronous viso_batch_upload_images call allocates them). */
+int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
+                                   const float* kp, const int32_t* n);
 /* HarrisBinnedFeatureDetector::detectImpl (src/viso.cpp:926-975) on every
  * uploaded image (pass kp = n = NULL to viso_batch_upload_images): fills the
  * batch's keypoints on the device.  cv::cornerHarris(blockSize 3, ksize 5, k)
@@ -230,16 +258,13 @@ int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl)
  * per (which,t) the number of scored (query,candidate) pairs C
  * and matches emitted M_out.  scored/m_out: [3][n_frames] int64. */
 int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out);
-/* Name of the kernel that dominates a matcher run (for rocprof summaries) and
- * its average duration in ms over the launches since the last reset, measured
- * with hipEvents on the context's stream. */
-const char* viso_matcher_kernel_name(void);
-/* Tuning/debug: which implementation of the u16 matcher runs.  3 (default) = match_union_kernel for the temporal
- * calls (one row load scored against four y-adjacent queries) + match_batch_kernel<1> for the stereo call;
- * 2 = match_batch_kernel for both; 0 = match_kernel (one query per wave at a time); 1 = match_tile_kernel
- * (descriptor rows staged in LDS).  Identical results; lets bench.py and the parity tests run all of them in
- * one process.  Process-wide, not thread safe: set it before launching work. */
-void viso_debug_set_matcher(int variant);
+/* flags [n_frames][2]: 1 where the last run found descriptor values of that image that the packed u16 rows cannot
+ * hold (not integers in [-32768, 32767], or dlen > 128).  Only the match_desc calls that read such an image take
+ * the general kernel (float differences summed in double, the arithmetic of cv::norm at src/viso.cpp:702); all
+ * other calls of the batch stay on the u16 kernels.  Same results either way. */
+int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags);
+/* Duration of the kernel that takes the temporal calls (viso_ctx_matcher_kernel_name), measured with hipEvents
+ * on the context's stream: average in ms over the runs since the last viso_batch_kernel_ms call. */
 int viso_batch_kernel_timing(viso_batch* b, int enable);
 int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches);
 

@@ -7,9 +7,12 @@ for tests and bench.py: a ctypes loader and numpy-in/numpy-out wrappers with
 the reference's function names.  There is NO CPU fallback: if the library is
 missing, or no HIP device is present, calls raise.
 """
+import atexit
 import ctypes as C
 import os
 import subprocess
+import sys
+import weakref
 
 import numpy as np
 
@@ -56,7 +59,15 @@ def load():
     MP, PP = declare_common(L, "viso_")
     L.viso_last_error.restype = C.c_char_p
     L.viso_version.restype = C.c_char_p
-    L.viso_matcher_kernel_name.restype = C.c_char_p
+    L.viso_ctx_matcher_kernel_name.restype = C.c_char_p
+    L.viso_ctx_matcher_kernel_name.argtypes = [C.c_void_p]
+    L.viso_ctx_set_matcher.argtypes = [C.c_void_p, C.c_int]
+    L.viso_host_alloc.restype = C.c_void_p
+    L.viso_host_alloc.argtypes = [C.c_size_t]
+    L.viso_host_free.argtypes = [C.c_void_p]
+    L.viso_batch_upload_async.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, i32p]
+    L.viso_batch_upload_images_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                                 f32p, i32p]
     L.viso_match_desc.restype = C.c_int
     L.viso_match_desc.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, f32p, C.c_int, MP, i32p, intp]
     L.viso_minimize_reproj.restype = C.c_int
@@ -84,6 +95,7 @@ def load():
     L.viso_batch_get_pose.argtypes = [C.c_void_p, C.c_int, f64p, intp, i32p, intp]
     L.viso_batch_get_poses.argtypes = [C.c_void_p, f64p, i32p, i32p]
     L.viso_batch_get_counters.argtypes = [C.c_void_p, i64p, i64p]
+    L.viso_batch_get_general_path_flags.argtypes = [C.c_void_p, i32p]
     L.viso_batch_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.viso_batch_kernel_ms.argtypes = [C.c_void_p, f64p, intp]
     L.viso_batch_upload_images.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
@@ -94,8 +106,6 @@ def load():
     L.viso_harris_response.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
     L.viso_detect_harris_binned.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_double, f32p, f32p, intp]
-    L.viso_debug_set_matcher.argtypes = [C.c_int]
-    L.viso_debug_set_matcher.restype = None
     _lib = L
     return L
 
@@ -117,9 +127,64 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-def set_matcher_variant(v):
-    """3 = union kernel (default), 2 = wave-batched gather kernel, 0 = per-query gather kernel, 1 = LDS-resident tile kernel; same results."""
-    load().viso_debug_set_matcher(int(v))
+MATCHER_VARIANTS = (3,)   # what this build of libviso_hip.so offers (viso_ctx_set_matcher)
+DEFAULT_MATCHER = 3
+
+
+def set_matcher_variant(v, ctx=None):
+    """Which kernel takes the temporal calls: of `ctx`, or of the plain family's default context."""
+    r = load().viso_ctx_set_matcher(ctx.h if ctx is not None else None, int(v))
+    if r != 1:
+        _err("viso_ctx_set_matcher", r)
+
+
+def matcher_kernel_name(ctx=None):
+    return load().viso_ctx_matcher_kernel_name(ctx.h if ctx is not None else None).decode()
+
+
+# Handles that are still open when the interpreter exits are closed HERE, from an atexit hook: that runs before
+# the HIP runtime's own teardown, whereas a __del__ during interpreter finalisation can run after it (calling
+# hipStreamSynchronize then aborts the process from inside the runtime).  Batches first, then contexts.
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    objs = list(_live)
+    for o in sorted(objs, key=lambda o: isinstance(o, Context)):
+        try:
+            o.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
+
+
+class PinnedArray:
+    """numpy view of hipHostMalloc memory (viso_host_alloc) for the *_async uploads."""
+
+    def __init__(self, shape, dtype):
+        self.L = load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.p = self.L.viso_host_alloc(self.nbytes)
+        if not self.p:
+            raise VisoError("viso_host_alloc: " + self.L.viso_last_error().decode())
+        buf = (C.c_char * self.nbytes).from_address(self.p)
+        self.a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        _live.add(self)
+
+    def close(self):
+        if self.p:
+            self.a = None
+            self.L.viso_host_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        if not sys.is_finalizing():
+            try:
+                self.close()
+            except Exception:
+                pass
 
 
 # ------------------------------------------------------------ plain family
@@ -293,6 +358,7 @@ class Context:
         self.h = self.L.viso_ctx_create(device, stream)
         if not self.h:
             raise VisoError("viso_ctx_create: " + self.L.viso_last_error().decode())
+        _live.add(self)
 
     def synchronize(self):
         r = self.L.viso_ctx_synchronize(self.h)
@@ -301,10 +367,14 @@ class Context:
 
     def close(self):
         if self.h:
-            self.L.viso_ctx_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            r = self.L.viso_ctx_destroy(h)
+            if r != 1:
+                _err("viso_ctx_destroy", r)
 
     def __del__(self):
+        if sys.is_finalizing():   # the atexit hook has closed everything that was still open
+            return
         try:
             self.close()
         except Exception:
@@ -320,6 +390,7 @@ class Batch:
         self.h = self.L.viso_batch_create(ctx.h, n_frames, cap, dlen)
         if not self.h:
             raise VisoError("viso_batch_create: " + self.L.viso_last_error().decode())
+        _live.add(self)
 
     def _chk(self, where, r):
         if r != 1:
@@ -331,6 +402,22 @@ class Batch:
         assert kp.shape == (nf, 2, self.cap, 2) and desc.shape == (nf, 2, self.cap, self.dlen)
         self._chk("viso_batch_upload", self.L.viso_batch_upload(self.h, f0, nf, ptr(kp, C.c_float),
                                                                  ptr(desc, C.c_float), ptr(n, C.c_int32)))
+
+    def upload_async(self, kp, desc, n, f0=0):
+        """Enqueue the copies on the context's stream; kp/desc should be PinnedArray views and must stay untouched
+        until the stream has passed them."""
+        assert kp.dtype == np.float32 and desc.dtype == np.float32 and kp.flags.c_contiguous and desc.flags.c_contiguous
+        n = _i32(n)
+        nf = kp.shape[0]
+        self._chk("viso_batch_upload_async", self.L.viso_batch_upload_async(self.h, f0, nf, ptr(kp, C.c_float),
+                                                                             ptr(desc, C.c_float), ptr(n, C.c_int32)))
+
+    def upload_images_async(self, images, kp, n, f0=0):
+        assert images.dtype == np.uint8 and images.flags.c_contiguous and kp.dtype == np.float32 and kp.flags.c_contiguous
+        n = _i32(n)
+        nf, _, rows, cols = images.shape
+        self._chk("viso_batch_upload_images_async", self.L.viso_batch_upload_images_async(
+            self.h, f0, nf, ptr(images, C.c_uint8), rows, cols, ptr(kp, C.c_float), ptr(n, C.c_int32)))
 
     def upload_images(self, images, kp, n, f0=0):
         """Image-in mode: uint8 images [nf][2][rows][cols] + keypoints (descriptors are extracted on the device)."""
@@ -403,6 +490,11 @@ class Batch:
         self._chk("viso_batch_get_counters", self.L.viso_batch_get_counters(self.h, ptr(sc, C.c_int64), ptr(mo, C.c_int64)))
         return sc, mo
 
+    def general_path_flags(self):
+        f = np.zeros((self.nf, 2), np.int32)
+        self._chk("viso_batch_get_general_path_flags", self.L.viso_batch_get_general_path_flags(self.h, ptr(f, C.c_int32)))
+        return f
+
     def kernel_timing(self, enable):
         self._chk("viso_batch_kernel_timing", self.L.viso_batch_kernel_timing(self.h, int(enable)))
 
@@ -419,10 +511,14 @@ class Batch:
 
     def close(self):
         if self.h:
-            self.L.viso_batch_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            r = self.L.viso_batch_destroy(h)
+            if r != 1:
+                _err("viso_batch_destroy", r)
 
     def __del__(self):
+        if sys.is_finalizing():   # the atexit hook has closed everything that was still open
+            return
         try:
             self.close()
         except Exception:

@@ -19,7 +19,7 @@ struct viso_batch {
     viso_ctx* ctx;
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
-    float2* kp; float* desc; int* n; uint16_t* packed; int* bad; int* zero;
+    float2* kp; float* desc; int* n; uint16_t* packed; int* bad_img; int* bad_any; int* zero;
     float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
@@ -36,8 +36,18 @@ struct viso_batch {
     unsigned long long seed, first_frame;
     bool params_set;
     bool timing;
+    // matcher-kernel timing: event pairs of the runs not yet read back (bounded: the oldest pair is folded into
+    // the running sum and reused once VISO_EVENT_POOL pairs are outstanding)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_next;            // ring position of the oldest outstanding pair
+    double ev_ms_sum; int ev_n;
 };
+#define VISO_EVENT_POOL 64
+
+static int enter(viso_batch* b) {   // every entry point that allocates, copies or launches
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    return VISO_OK;
+}
 
 static inline int prob_slot(int which, int t) { return (t / 8) * 24 + which * 8 + (t % 8); }
 
@@ -55,18 +65,23 @@ static void free_solver_bufs(viso_batch* b) {
     b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
 }
 
-extern "C" void viso_batch_destroy(viso_batch* b) try {
-    if (!b) return;
-    hipStreamSynchronize(b->ctx->stream);
-    for (auto& e : b->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+// Frees everything it can; the first HIP error met is recorded (viso_last_error) and returned.  Like
+// viso_ctx_destroy it must run before the HIP runtime starts unloading (not from static destructors).
+extern "C" int viso_batch_destroy(viso_batch* b) {
+    if (!b) return VISO_OK;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    note(hipSetDevice(b->ctx->device));
+    note(hipStreamSynchronize(b->ctx->stream));
+    for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl};
-    for (void* p : ptrs) if (p) hipFree(p);
-    free_solver_bufs(b);
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h};
+    for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
-} catch (...) {   // the HIP runtime may already be gone at process exit
+    if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
+    return VISO_OK;
 }
 
 static int build_items(viso_batch* b) {
@@ -82,11 +97,13 @@ static int build_items(viso_batch* b) {
             v.skp = b->skp + i * kpi; v.sidx = b->sidx + i * kpi; v.rank = b->rank + i * kpi;
             v.bstart = b->bstart + i * (VISO_NB + 1); v.xinfo = b->xinfo + i * 2;
             v.rows = b->packed + i * dsi;
+            v.bad = b->bad_img + i;
         }
     {
         ImageView& e = V[(size_t)nf * 2];
         e = V[0];
         e.n = b->zero;
+        e.bad = b->zero + 5;
     }
     HIP_TRY(hipMemcpy(b->views, V.data(), sizeof(ImageView) * V.size(), hipMemcpyHostToDevice));
     std::vector<MatchProblem> P((size_t)b->n_probs);
@@ -161,6 +178,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
     b->n_probs = ((n_frames + 7) / 8) * 24;
     b->params_set = false; b->timing = false;
+    b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
     b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
@@ -174,11 +192,12 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
     A(dalloc(&b->m_cnt, 3 * nf));
-    // per-run counters zeroed by ONE memset: scored[3nf] (u64) | ovf_cnt[3nf] (int) | bad (int)
-    b->zeroed_bytes = 3 * nf * sizeof(unsigned long long) + (3 * nf + 4) * sizeof(int);
+    // per-run counters zeroed by ONE memset: scored[3nf] (u64) | ovf_cnt[3nf] (int) | bad_img[2nf] (int) | bad_any (int)
+    b->zeroed_bytes = 3 * nf * sizeof(unsigned long long) + (3 * nf + 2 * nf + 4) * sizeof(int);
     A(dalloc(&b->scored, b->zeroed_bytes / sizeof(unsigned long long) + 1));
     b->ovf_cnt = r >= 0 ? reinterpret_cast<int*>(b->scored + 3 * nf) : nullptr;
-    b->bad = r >= 0 ? b->ovf_cnt + 3 * nf : nullptr;
+    b->bad_img = r >= 0 ? b->ovf_cnt + 3 * nf : nullptr;
+    b->bad_any = r >= 0 ? b->bad_img + 2 * nf : nullptr;
     A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
     A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
@@ -202,10 +221,72 @@ extern "C" int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
     for (int i = 0; i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
     if (nf == 0) return VISO_OK;
+    int r;
+    if ((r = enter(b)) < 0) return r;
+    // the batch's kernels run on a non-blocking stream: order the copies behind them, then wait (synchronous call)
+    hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
-    HIP_TRY(hipMemcpy(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VISO_OK;
+}
+
+// Pinned host memory for the *_async uploads (hipHostMalloc): copies from it run as DMA on the context's stream.
+extern "C" void* viso_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { viso_set_error("viso_host_alloc: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" int viso_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return VISO_OK;
+}
+
+// viso_batch_upload without the wait: the three copies are enqueued on the context's stream (behind the batch's
+// previous run, in front of the next one) and the call returns.  The host buffers must stay untouched until the
+// stream has passed the copies (viso_ctx_synchronize, or any result getter of a later run); with buffers from
+// viso_host_alloc the copies are true DMA and overlap the kernels of other contexts.  `n` is validated now and
+// copied through a small pinned slot of the batch, so the caller's n array need not be pinned.
+extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const float* kp, const float* desc,
+                                       const int32_t* n) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload_async: bad argument"); return VISO_ERR_ARG; }
+    for (int i = 0; i < 2 * nf; ++i)
+        if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_async: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
+    if (nf == 0) return VISO_OK;
+    int r;
+    if ((r = enter(b)) < 0) return r;
+    hipStream_t s = b->ctx->stream;
+    const size_t c = (size_t)b->cap;
+    HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
+    return VISO_OK;
+}
+
+extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
+                                              const float* kp, const int32_t* n) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
+        viso_set_error("viso_batch_upload_images_async: bad argument");
+        return VISO_ERR_ARG;
+    }
+    if (!b->images || rows != b->img_rows || cols != b->img_cols) {
+        viso_set_error("viso_batch_upload_images_async: image buffers not allocated for %d x %d (call viso_batch_upload_images once first)", rows, cols);
+        return VISO_ERR_ARG;
+    }
+    for (int i = 0; n && i < 2 * nf; ++i)
+        if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_images_async: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
+    if (nf == 0) return VISO_OK;
+    int r;
+    if ((r = enter(b)) < 0) return r;
+    hipStream_t s = b->ctx->stream;
+    const size_t per = (size_t)rows * cols, c = (size_t)b->cap;
+    HIP_TRY(hipMemcpyAsync(b->images + (size_t)f0 * 2 * per, images, per * 2 * (size_t)nf, hipMemcpyHostToDevice, s));
+    if (kp) {
+        HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
+    }
     return VISO_OK;
 }
 
@@ -224,12 +305,16 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         viso_set_error("viso_batch_set_params: bad argument");
         return VISO_ERR_ARG;
     }
+    int r0;
+    if ((r0 = enter(b)) < 0) return r0;
+    // kernels of a run still in flight read the solver items rewritten below (null-stream copies do not order
+    // against the context's non-blocking stream)
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     fill_match_params(&b->mp[0], stereo);
     fill_match_params(&b->mp[1], temporal);
     fill_solver_params(&b->sp, p);
     b->seed = seed; b->first_frame = first_frame_index;
     if (p->ransac_iter != b->iters || !b->tr_h) {
-        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
         free_solver_bufs(b);
         b->iters = p->ransac_iter;
         const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
@@ -254,22 +339,32 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
         viso_set_error("viso_batch_run_images: no images uploaded (or descriptor length is not 121)");
         return VISO_ERR_ARG;
     }
-    hipStream_t s = b->ctx->stream;
-    HIP_TRY(hipMemsetAsync(b->scored, 0, b->zeroed_bytes, s));   // scored, ovf_cnt, bad
     int r;
+    if ((r = enter(b)) < 0) return r;
+    hipStream_t s = b->ctx->stream;
+    HIP_TRY(hipMemsetAsync(b->scored, 0, b->zeroed_bytes, s));   // scored, ovf_cnt, bad_img, bad_any
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
         if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols)) < 0) return r;
     } else {
-        if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad)) < 0) return r;
+        if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any)) < 0) return r;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        b->events.push_back({e0, e1});
+        if (b->events.size() < VISO_EVENT_POOL) {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            b->events.push_back({e0, e1});
+        } else {   // pool full: fold the oldest pair into the running sum (waits for that run) and reuse it
+            auto& e = b->events[b->ev_next];
+            float ms = 0;
+            HIP_TRY(hipEventSynchronize(e.second));
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { b->ev_ms_sum += ms; ++b->ev_n; }
+            e0 = e.first; e1 = e.second;
+            b->ev_next = (b->ev_next + 1) % VISO_EVENT_POOL;
+        }
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad, e0, e1, 1)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     return VISO_OK;
 }
@@ -298,8 +393,10 @@ extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uin
     }
     for (int i = 0; n && i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_images: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
+    int r0;
+    if ((r0 = enter(b)) < 0) return r0;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));   // a run in flight may still read what the (null-stream) copies below rewrite
     if (b->images && (rows != b->img_rows || cols != b->img_cols)) {
-        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
         HIP_TRY(hipFree(b->images));
         b->images = nullptr;
     }
@@ -330,6 +427,8 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
     const int nbins = nbinx * nbiny, per = n_features / nbins;
     if ((long long)nbins * per > b->cap) { viso_set_error("viso_batch_detect: %d features exceed the batch capacity %d", nbins * per, b->cap); return VISO_ERR_ARG; }
     const int n_img = b->nf * 2;
+    int r0;
+    if ((r0 = enter(b)) < 0) return r0;
     hipStream_t s = b->ctx->stream;
     if (!b->h_resp) HIP_TRY(hipMalloc((void**)&b->h_resp, sizeof(float) * (size_t)n_img * b->img_rows * b->img_cols));
     const size_t slots = (size_t)nbins * (per > 0 ? per : 1);
@@ -364,6 +463,7 @@ extern "C" int viso_batch_get_keypoints(viso_batch* b, int t, int side, float* k
 
 static int run_rest(viso_batch* b) {
     int r;
+    if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
     HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, s));            // vector<double> tr(6,0), :1312
     if ((r = launch_collect_triangulate(s, b->tri, b->nf, b->sp, b->cap)) < 0) return r;   // :1245-1247
@@ -377,14 +477,15 @@ static int run_rest(viso_batch* b) {
 extern "C" int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches) {
     if (!b) return VISO_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    double tot = 0;
-    int n = 0;
+    double tot = b->ev_ms_sum;
+    int n = b->ev_n;
     for (auto& e : b->events) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }   // folded pairs were re-recorded since
         hipEventDestroy(e.first); hipEventDestroy(e.second);
     }
     b->events.clear();
+    b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     if (matcher_ms_avg) *matcher_ms_avg = n ? tot / n : 0.0;
     if (n_launches) *n_launches = n;
     return VISO_OK;
@@ -433,6 +534,15 @@ extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int3
     if (tr) HIP_TRY(hipMemcpy(tr, b->tr, sizeof(double) * 6 * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (ok) HIP_TRY(hipMemcpy(ok, b->ok, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (n_inl) HIP_TRY(hipMemcpy(n_inl, b->n_inl, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
+    return VISO_OK;
+}
+
+// Which images the pack kernel flagged in the last run (descriptor values that are not integers in
+// [-32768, 32767]): the problems reading them took the general (double) kernel, all others the u16 kernels.
+extern "C" int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags) {
+    if (!b || !flags) return VISO_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipMemcpy(flags, b->bad_img, sizeof(int) * 2 * (size_t)b->nf, hipMemcpyDeviceToHost));
     return VISO_OK;
 }
 

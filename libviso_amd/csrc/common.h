@@ -46,6 +46,8 @@ struct ImageView {               // one image's keypoints + descriptors on the d
     int* bstart;                 // [VISO_NB+1] first sorted position of each column bucket
     float* xinfo;                // [2] x0, scale of the bucket map
     uint16_t* rows;              // [n][128] packed descriptor rows, x-sorted order
+    int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
+                                 //     every problem that reads the image then takes the general (double) kernel
 };
 
 struct MatchProblem {            // one match_desc call (reference src/viso.cpp:669)
@@ -70,6 +72,7 @@ struct viso_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    int matcher_variant;         // viso_ctx_set_matcher
     // grow-only scratch for the plain (host-pointer) family
     void* scratch[16];
     size_t scratch_bytes[16];
@@ -83,12 +86,15 @@ viso_ctx* viso_default_ctx();
 // x-sort every image's keypoints (+ inverse permutation and column index)
 int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max);
 // pack boundary-layout float descriptors into biased u16 rows in x-sorted order;
-// sets *bad to 1 when a value is not an integer in [-32768, 32767] or dlen > 128.
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad);
+// sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
+// dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any);
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], const int* bad);
+                 const MatchParamsDev mp[2], const int* bad, int variant);
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1, int layout);
+                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant);
+const char* matcher_kernel_name(int variant);
+#define VISO_MATCHER_DEFAULT 3
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);
@@ -134,16 +140,14 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);
-int launch_match_tile(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                      const MatchParamsDev mp[2], const int* bad);
 struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_kernel (tiles of 64 queries)
     const MatchProblem* probs;
     int n_probs, bpp, gs, gf, gc, _pad;
-    const int* bad;
+    const int* bad;              // "some image of this run is flagged": lets the (normally idle) general kernels leave at once
     MatchParamsDev mp[2];
 };
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int union_temporal);
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int variant);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols);

@@ -30,6 +30,7 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     viso_ctx* c = new viso_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
+    c->matcher_variant = VISO_MATCHER_DEFAULT;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -42,13 +43,40 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     return c;
 }
 
-extern "C" void viso_ctx_destroy(viso_ctx* c) try {
-    if (!c) return;
-    hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 16; ++i) if (c->scratch[i]) hipFree(c->scratch[i]);
-    if (c->own_stream) hipStreamDestroy(c->stream);
+// Frees everything it can and reports the FIRST HIP error it met (viso_last_error).  Must not be called once the
+// HIP runtime is being unloaded (static destructors / atexit handlers that run after it): destroy contexts before
+// the process starts exiting (the Python wrapper does so from an atexit hook of its own).
+extern "C" int viso_ctx_destroy(viso_ctx* c) {
+    if (!c) return VISO_OK;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    note(hipSetDevice(c->device));
+    note(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 16; ++i) if (c->scratch[i]) note(hipFree(c->scratch[i]));
+    if (c->own_stream) note(hipStreamDestroy(c->stream));
     delete c;
-} catch (...) {   // the HIP runtime may already be gone at process exit
+    if (first != hipSuccess) { viso_set_error("viso_ctx_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
+    return VISO_OK;
+}
+
+static viso_ctx* ctx_or_default(viso_ctx* c) { return c ? c : viso_default_ctx(); }
+
+extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
+    c = ctx_or_default(c);
+    if (!c) return VISO_ERR_HIP;
+#ifdef VISO_DEBUG_VARIANTS
+    const bool known = variant >= 2 && variant <= 4;
+#else
+    const bool known = variant == 3 || variant == 4;
+#endif
+    if (!known) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
+    c->matcher_variant = variant;
+    return VISO_OK;
+}
+
+extern "C" const char* viso_ctx_matcher_kernel_name(viso_ctx* c) {
+    c = ctx_or_default(c);
+    return matcher_kernel_name(c ? c->matcher_variant : VISO_MATCHER_DEFAULT);
 }
 
 extern "C" void* viso_ctx_stream(viso_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -61,6 +89,7 @@ extern "C" int viso_ctx_synchronize(viso_ctx* c) {
 
 int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out) {
     if (bytes < 256) bytes = 256;
+    HIP_TRY(hipSetDevice(c->device));
     if (c->scratch_bytes[slot] < bytes) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->scratch[slot]) HIP_TRY(hipFree(c->scratch[slot]));
@@ -137,12 +166,12 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         HIP_TRY(hipMemcpyAsync(dk2, kp2, sizeof(float2) * n2, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(df2, d2, sizeof(float) * (size_t)n2 * dlen, hipMemcpyHostToDevice, s));
     }
-    // dmisc: [0]=n1 [1]=n2 [2]=bad [3]=m_cnt [4..5]=scored (u64)
+    // dmisc: [0]=n1 [1]=n2 [2]=bad (both images share one flag) [3]=m_cnt [4..5]=scored (u64) [6]=ovf_cnt [7]=bad_any
     int hm[8] = {n1, n2, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, s));
     auto view = [&](unsigned char* base, size_t n, const float2* kp, const float* f, const int* np, uint16_t* rows) {
         ImageView v{};
-        v.kp = kp; v.frows = f; v.n = np; v.rows = rows;
+        v.kp = kp; v.frows = f; v.n = np; v.rows = rows; v.bad = dmisc + 2;
         v.skp = (float2*)base;
         v.sidx = (int*)(base + 8 * n);
         v.rank = (int*)(base + 12 * n);
@@ -163,11 +192,15 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     const ImageView* dviews = reinterpret_cast<const ImageView*>(dprob + 1);
     const int capmax = n1 > n2 ? n1 : (int)n2a;
     if ((r = launch_sort_kp(s, dviews, 2, capmax)) < 0) return r;
-    if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2)) < 0) return r;
+    if (dlen > VISO_ROW) {   // rows do not fit: the one shared flag
+        const int one[1] = {1};
+        HIP_TRY(hipMemcpyAsync(dmisc + 2, one, sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dmisc + 7, one, sizeof(int), hipMemcpyHostToDevice, s));
+    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7)) < 0) return r;
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];
-    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 2)) < 0) return r;
+    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant)) < 0) return r;
     if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
     int m = 0;
     HIP_TRY(hipMemcpyAsync(&m, dmisc + 3, sizeof(int), hipMemcpyDeviceToHost, s));

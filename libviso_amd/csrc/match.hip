@@ -124,7 +124,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 #define VISO_PACK_RPW 8   // rows per wave
 
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
-                                                        int cap, int dlen, int* __restrict__ bad) {
+                                                        int cap, int dlen, int* __restrict__ bad_any) {
     __shared__ __attribute__((aligned(16))) float s_buf[4][VISO_PACK_RPW * VISO_ROW];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) f32x4* gvec_t;
@@ -173,13 +173,20 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
         const int d = __builtin_amdgcn_readlane(dst, k);
         ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
     }
-    if (__any(isbad) && lane == 0) atomicOr(bad, 1);
+    if (__any(isbad) && lane == 0) { atomicOr(I.bad, 1); atomicOr(bad_any, 1); }
 }
 
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad) {
-    if (dlen > VISO_ROW) {  // rows do not fit the packed format: force the general path
-        int one = 1;
-        HIP_TRY(hipMemcpyAsync(bad, &one, sizeof(int), hipMemcpyHostToDevice, s));
+__global__ void flag_all_kernel(int* flags, int n, int* any) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = 1;
+    if (i == 0) *any = 1;
+}
+
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any) {
+    if (n_img <= 0) return VISO_OK;
+    if (dlen > VISO_ROW) {  // rows do not fit the packed format: every image takes the general path
+        hipLaunchKernelGGL(flag_all_kernel, dim3((n_img + 255) / 256), dim3(256), 0, s, bad_img, n_img, bad_any);
+        HIP_TRY(hipGetLastError());
         return VISO_OK;
     }
     // the kernel addresses rows as img * capp + r with capp a multiple of the rows per wave,
@@ -188,7 +195,7 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
     const int blocks = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad);
+    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -615,6 +622,7 @@ __device__ __forceinline__ void match_tile_slot(const MatchArgs& a, int vb, uint
     block_to_problem(vb, a.n_probs, a.bpp, a.gs, a.gf, a.gc, prob, qblk);
     if (prob < 0) return;
     const MatchProblem P = a.probs[prob];
+    if (((*P.q.bad | *P.t.bad) != 0) != GENERAL) return;   // decided per problem by the pack kernel (no host round trip)
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * VISO_QPB;
     if (q0 >= n1) return;
@@ -682,10 +690,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(GENERAL ? 4 : 8, 8))) __launch_bou
     __shared__ float2 s_kp[VISO_KPCAP];
     __shared__ int s_idx[VISO_KPCAP];
     __shared__ float s_xr[2];
-    // the pack kernel decides which variant does the work (no host round trip)
-    const bool is_bad = *a.bad != 0;
-    if (is_bad != GENERAL) return;
     if constexpr (GENERAL) {
+        if (*a.bad == 0) return;   // no image of this run is flagged: nothing to do
         // normally idle: launched on a small grid that strides over the slots when it does have work
         for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
             __syncthreads();   // LDS of the previous slot is free
@@ -704,11 +710,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(GENERAL ? 4 : 8, 8))) __launch_bou
 template <bool GENERAL>
 __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(MatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
-    const bool is_bad = *a.bad != 0;
-    if (is_bad != GENERAL) return;
+    if (GENERAL && *a.bad == 0) return;
     const int prob = blockIdx.x / VISO_OVF_BLOCKS, sub = blockIdx.x % VISO_OVF_BLOCKS;
     if (prob >= a.n_probs) return;
     const MatchProblem P = a.probs[prob];
+    if (((*P.q.bad | *P.t.bad) != 0) != GENERAL) return;
     const int n_ovf = *P.ovf_cnt;
     if (n_ovf == 0) return;
     const int n2 = *P.t.n;
@@ -745,25 +751,22 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
-// Which implementation of the u16 path runs (include/viso_hip.h, viso_debug_set_matcher):
-//   3 = match_union_kernel (temporal) + match_batch_kernel<1> (stereo)      0.51 + 0.23 ms   <- default
-//   2 = match_batch_kernel<0> + match_batch_kernel<1>                        0.63 + 0.23 ms
-//   0 = match_kernel<false, 0/1> (this file: one query per wave at a time)   0.90 + 0.43 ms
-//   1 = match_tile_kernel (descriptor rows staged in LDS, match_tile.hip)    1.77 ms for both
-// (MI355X, bench.py --ab, 769 problems per launch, one stream.)  Same results; all four stay selectable and
-// are run by the fuzz / full-size parity tests.
-static int g_matcher_variant = 3;
-extern "C" void viso_debug_set_matcher(int variant) { g_matcher_variant = (variant >= 0 && variant <= 3) ? variant : 0; }
-extern "C" const char* viso_matcher_kernel_name(void) {
-    return g_matcher_variant == 1 ? "match_tile_kernel" : g_matcher_variant == 2 ? "match_batch_kernel<0>" :
-           g_matcher_variant == 3 ? "match_union_kernel" : "match_kernel<false, 0>";
+// Which kernel takes the temporal problems of the u16 path (viso_ctx_set_matcher, per context):
+//   4 = match_strip_kernel  (window rows resident in LDS, match_strip.hip)          <- default
+//   3 = match_union_kernel  (rows gathered from L2, one load scored against four queries, match_union.hip)
+//   2 = match_batch_kernel<0> (rows gathered from L2, one pair per 8-lane group, match_batch.hip; built only
+//       with -DVISO_DEBUG_VARIANTS)
+// The stereo problems always take match_batch_kernel<1>.  Same results from all of them (parity tests run each).
+const char* matcher_kernel_name(int variant) {
+    return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : "match_strip_kernel";
 }
 
 // layout 0: problems in any order (both instantiations enumerate all of them);
 // layout 1: the batch order [8 stereo][8 temporal-left][8 temporal-right] per 8 frames.
+// e0/e1 (may be null) bracket the kernel that takes the temporal problems: the dominant kernel.
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], const int* bad,
-                       hipEvent_t e0, hipEvent_t e1, int layout) {
+                       hipEvent_t e0, hipEvent_t e1, int layout, int variant) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
     a.probs = probs_dev;
@@ -779,32 +782,11 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     if (blocks > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
     a.vblocks = (int)blocks;
     if (e0) HIP_TRY(hipEventRecord(e0, s));
-    if (g_matcher_variant == 1) {
-        const int r = launch_match_tile(s, probs_dev, n_probs, cap_max, mp, bad);
+    {
+        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, variant);
         if (r < 0) return r;
-    } else if (g_matcher_variant == 2 || g_matcher_variant == 3) {
-        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, g_matcher_variant == 3);
-        if (r < 0) return r;
-        e1 = nullptr;
-    } else {
-        // the events bracket the temporal instantiation only: the dominant kernel
-        // (2/3 of the problems, ~97 % of the scored pairs)
-        MatchArgs at = a, as = a;   // temporal / stereo enumerations
-        long long bt = blocks, bs = blocks;
-        if (layout == 1) {
-            const int g3 = (groups + 2) / 3;
-            at.gs = 3; at.gf = 1; at.gc = 2; bt = (long long)g3 * 2 * 8 * a.bpp;
-            as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
-        }
-        at.vblocks = (int)bt; as.vblocks = (int)bs;
-        hipLaunchKernelGGL((match_kernel<false, 0>), dim3((unsigned)bt), dim3(VISO_MATCH_THREADS), 0, s, at);
-        HIP_TRY(hipGetLastError());
-        if (e1) { HIP_TRY(hipEventRecord(e1, s)); e1 = nullptr; }
-        hipLaunchKernelGGL((match_kernel<false, 1>), dim3((unsigned)bs), dim3(VISO_MATCH_THREADS), 0, s, as);
-        HIP_TRY(hipGetLastError());
     }
-    if (e1) HIP_TRY(hipEventRecord(e1, s));
-    // general (non-u16) path: normally idle (the pack kernel's flag is clear and every block leaves at once), so
+    // general (non-u16) path: normally idle (no image is flagged and every block leaves at once), so
     // it gets a small grid that strides over the (problem, tile) slots when it does have work
     const unsigned gblocks = (unsigned)(blocks < 2048 ? blocks : 2048);
     hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
@@ -819,8 +801,8 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
 }
 
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], const int* bad) {
-    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0);
+                 const MatchParamsDev mp[2], const int* bad, int variant) {
+    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant);
 }
 
 

@@ -59,7 +59,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     __shared__ float2 s_kp[MB_KPCAP];
     __shared__ int s_idx[MB_KPCAP];
     __shared__ float s_xr[2];
-    if (*a.bad != 0) return;
     int prob, qblk;
     {
         const int b = blockIdx.x;
@@ -70,6 +69,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
         if (prob >= a.n_probs) return;
     }
     const MatchProblem P = a.probs[prob];
+    if ((*P.q.bad | *P.t.bad) != 0) return;   // non-integer descriptors: the general kernel does this problem
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * MB_QPB;
     if (q0 >= n1) return;
@@ -417,7 +417,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int union_temporal) {
+                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int variant) {
     BatchMatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
@@ -435,12 +435,15 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
     }
     if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
-    if (union_temporal) {
-        const int r = launch_match_union_temporal(s, at, bt);
-        if (r < 0) return r;
-    } else {
+#ifdef VISO_DEBUG_VARIANTS
+    if (variant == 2) {
         hipLaunchKernelGGL((match_batch_kernel<0>), dim3((unsigned)bt), dim3(MB_THREADS), 0, s, at);
         HIP_TRY(hipGetLastError());
+    } else
+#endif
+    {
+        const int r = launch_match_union_temporal(s, at, bt);
+        if (r < 0) return r;
     }
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, s));
     hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)bs), dim3(MB_THREADS), 0, s, as);

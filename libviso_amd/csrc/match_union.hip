@@ -73,7 +73,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     __shared__ int s_idx[MU_KPCAP];
     __shared__ int s_qord[MU_QPB];
     __shared__ float s_xr[2];
-    if (*a.bad != 0) return;
     int prob, qblk;
     {
         const int b = blockIdx.x;
@@ -84,6 +83,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
         if (prob >= a.n_probs) return;
     }
     const MatchProblem P = a.probs[prob];
+    if ((*P.q.bad | *P.t.bad) != 0) return;   // non-integer descriptors: the general kernel does this problem
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * MU_QPB;
     if (q0 >= n1) return;

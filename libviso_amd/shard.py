@@ -42,14 +42,12 @@ def gpu_engine(device=0):
     return run
 
 
-def run_sharded(seq_kp, seq_desc, seq_n, stereo, temporal, param, seed, engine, rank, world,
-                dist=None, device="cpu"):
-    """Process this rank's frame range with `engine`, all-gather the records and
-    return (tr [n_frames,6], ok [n_frames], n_inl [n_frames]) for the whole
-    sequence on every rank."""
+def local_records(seq_kp, seq_desc, seq_n, stereo, temporal, param, seed, engine, rank, world):
+    """This rank's share of the work: rec [n_frames, 8] = tr[6], ok, n_inl with only the rows of the
+    pairs (t-1, t), t in (first, last], filled in."""
     n_frames = seq_kp.shape[0]
     first, last = partition(n_frames, world)[rank]
-    rec = np.zeros((n_frames, 8), np.float64)          # tr[6], ok, n_inl
+    rec = np.zeros((n_frames, 8), np.float64)
     if last > first:
         tr, ok, n_inl = engine(seq_kp[first:last + 1], seq_desc[first:last + 1], seq_n[first:last + 1],
                                stereo, temporal, param, seed, first)
@@ -57,14 +55,29 @@ def run_sharded(seq_kp, seq_desc, seq_n, stereo, temporal, param, seed, engine, 
         rec[first + 1:last + 1, :6] = tr[1:]
         rec[first + 1:last + 1, 6] = ok[1:]
         rec[first + 1:last + 1, 7] = n_inl[1:]
+    return rec
+
+
+def stitch(parts, n_frames):
+    """parts[r] = rank r's rec (what the all-gather delivers) -> (tr, ok, n_inl) of the whole sequence."""
+    full = np.zeros((n_frames, 8), np.float64)
+    for r, (a, b) in enumerate(partition(n_frames, len(parts))):
+        full[a + 1:b + 1] = np.asarray(parts[r])[a + 1:b + 1]
+    return full[:, :6].copy(), full[:, 6].astype(np.int32), full[:, 7].astype(np.int32)
+
+
+def run_sharded(seq_kp, seq_desc, seq_n, stereo, temporal, param, seed, engine, rank, world,
+                dist=None, device="cpu"):
+    """Process this rank's frame range with `engine`, all-gather the records and
+    return (tr [n_frames,6], ok [n_frames], n_inl [n_frames]) for the whole
+    sequence on every rank."""
+    n_frames = seq_kp.shape[0]
+    rec = local_records(seq_kp, seq_desc, seq_n, stereo, temporal, param, seed, engine, rank, world)
+    parts = [rec]
     if world > 1:
         import torch
         t = torch.from_numpy(rec).to(device)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)                       # fixed-size records, one collective
-        ranges = partition(n_frames, world)
-        full = np.zeros_like(rec)
-        for r, (a, b) in enumerate(ranges):
-            full[a + 1:b + 1] = parts[r].cpu().numpy()[a + 1:b + 1]
-        rec = full
-    return rec[:, :6].copy(), rec[:, 6].astype(np.int32), rec[:, 7].astype(np.int32)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)                         # fixed-size records, one collective
+        parts = [p.cpu().numpy() for p in out]
+    return stitch(parts, n_frames)

@@ -244,7 +244,7 @@ def sequence(kp, desc, n, stereo, temporal, param, seed=0, first_frame=0, matche
     dlen = desc.shape[-1]
     tr = np.zeros((nf, 6)); ok = np.zeros(nf, np.int32); ninl = np.zeros(nf, np.int32)
     scored = np.zeros((3, nf), np.int64); mout = np.zeros((3, nf), np.int64)
-    st = np.zeros(4)
+    st = np.zeros(5)   # match_desc total, circle, gather + triangulate, RANSAC/GN, neighbour-search share of [0]
     r = lib().oracle_sequence(ptr(kp, C.c_float), ptr(desc, C.c_float), ptr(n, C.c_int32), nf, cap,
                               dlen, C.byref(stereo), C.byref(temporal), C.byref(param), seed,
                               first_frame, int(matcher_only), ptr(tr, C.c_double), ptr(ok, C.c_int32),

@@ -119,6 +119,15 @@ static int cmp_match(const void* a, const void* b) {
     return (x[0] > y[0]) - (x[0] < y[0]);
 }
 
+/* wall time spent in the neighbour search (:685) of the oracle_match_desc calls of this thread, for the per-stage
+ * CPU baseline (the reference logs only whole-call times, :674,725) */
+static __thread double g_search_s = 0;
+static double mono_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int oracle_match_desc(const float* kp1, int n1, const float* kp2, int n2,
                       const float* d1, const float* d2, int dlen,
                       const viso_match_params* mp,
@@ -128,7 +137,9 @@ int oracle_match_desc(const float* kp1, int n1, const float* kp2, int n2,
     int32_t* neighbors = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 > 0 ? n1 : 1) * K);
     if (!neighbors) return VISO_ERR_NOMEM;
     /* :685 — sp.radius (double) is passed as `float radius` */
+    const double ts0 = mono_s();
     oracle_radius_search(kp1, n1, kp2, n2, (float)mp->radius, K, neighbors, NULL);
+    g_search_s += mono_s() - ts0;
     int m = 0;
     int64_t nscored = 0;
     for (int i = 0; i < n1; ++i) {
@@ -725,7 +736,8 @@ int oracle_sequence(const float* kp, const float* desc, const int32_t* n,
     double* x_c = (double*)malloc(sizeof(double) * 4 * (size_t)cap);
     double* Xp_c = (double*)malloc(sizeof(double) * 3 * (size_t)cap);
     int n_lr = 0, n_lr_prev = 0;
-    double st[4] = {0, 0, 0, 0};
+    double st[5] = {0, 0, 0, 0, 0};   /* match_desc total, circle, gather+triangulate, RANSAC/GN, of [0]: neighbour search */
+    g_search_s = 0;
     for (int t = 0; t < nf; ++t) {
         const float* kp1 = kp + ((size_t)t * 2 + 0) * kps;
         const float* kp2 = kp + ((size_t)t * 2 + 1) * kps;
@@ -785,6 +797,7 @@ int oracle_sequence(const float* kp, const float* desc, const int32_t* n,
         ok[t] = r; n_inl_out[t] = ni;
         for (int j = 0; j < 6; ++j) tr_out[6 * t + j] = tr[j];
     }
+    st[4] = g_search_s;
     if (stage_s) memcpy(stage_s, st, sizeof(st));
     free(mlr); free(mlr_prev); free(m11); free(m22); free(circ); free(pcl); free(inl);
     free(x); free(X); free(X_prev); free(x_c); free(Xp_c);

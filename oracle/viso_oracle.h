@@ -93,7 +93,7 @@ int oracle_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_fe
 /* One sequence_odometry loop body over in-memory frames (src/viso.cpp:1205-1327),
  * without the front-end: frames laid out as viso_batch (kp [nf][2][cap][2],
  * desc [nf][2][cap][dlen], n [nf][2]).  Outputs per frame t: tr [nf][6],
- * ok [nf], n_inl [nf]; optional per-stage seconds in stage_s[4]
+ * ok [nf], n_inl [nf]; optional per-stage seconds in stage_s[5] (match_desc, circle, gather+triangulate, RANSAC/GN, neighbour-search share of match_desc)
  * (neighbour search+SAD+sort, circle, triangulate/gather, RANSAC/GN).
  * matcher_only != 0 stops after the three match_desc calls. */
 int oracle_sequence(const float* kp, const float* desc, const int32_t* n,

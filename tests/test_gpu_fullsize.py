@@ -15,11 +15,16 @@ def _run_batch(seq, seed=3, full=True):
     nf, _, cap, _ = seq["kp"].shape
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
     ctx = libviso_amd.Context(0)
+    if _VARIANT[0] is not None:
+        libviso_amd.set_matcher_variant(_VARIANT[0], ctx)
     b = libviso_amd.Batch(ctx, nf, cap)
     b.upload(seq["kp"], seq["desc"], seq["n"])
     b.set_params(st, tm, seq["param"], seed=seed)
     (b.run if full else b.run_matcher)()
     return ctx, b, st, tm
+
+
+_VARIANT = [None]   # matcher variant of the contexts _run_batch creates (None: the build's default)
 
 
 def _per_call(oracle, seq, which, t, st, tm):
@@ -52,12 +57,22 @@ def test_config2_3_full_size_vs_oracle(viso, oracle):
 
 
 def test_config5_stress_size_vs_oracle(viso, oracle):
-    seq = synth.make_sequence(102, 2, n_kp=8000, width=2048, height=1024)
-    ctx, b, st, tm = _run_batch(seq, full=False)
+    """configs[4] geometry (2048x1024, 8000 features/image), whole pipeline: matcher, circle join, RANSAC/GN."""
+    seq = synth.make_sequence(102, 3, n_kp=8000, width=2048, height=1024)
+    ctx, b, st, tm = _run_batch(seq, full=True)
     sc, _ = b.counters()
-    for which, t in ((0, 0), (0, 1), (1, 1), (2, 1)):
+    for which, t in ((0, 0), (0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2)):
         want, wsc = _per_call(oracle, seq, which, t, st, tm)
         assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc
+    want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=3)
+    tr, ok, n_inl = b.poses()
+    assert np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"]) and ok[1:].all()
+    for t in (1, 2):
+        circ, pcl = b.circle(t)       # match_circle (:207-243) over the four (already verified) match lists
+        _, wc, wp, _ = oracle.match_circle(b.matches(0, t), b.matches(0, t - 1), b.matches(1, t), b.matches(2, t))
+        assert len(circ) > 100 and np.array_equal(circ, wc) and np.array_equal(pcl, wp)
+        a, r = libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])
+        assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-5
     b.close(); ctx.close()
 
 
@@ -93,12 +108,12 @@ def test_bench_sized_batch_properties(viso):
     b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", libviso_amd.MATCHER_VARIANTS)
 def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
-    """The L2-gather kernel (default) and the LDS-resident tile kernel must both
-    be bit-exact: ragged counts, duplicated patches (exact SAD ties -> overflow
-    kernel), dense clusters (K cap), and the 8000-keypoint chunked window."""
-    libviso_amd.set_matcher_variant(variant)
+    """Every matcher variant of the build must be bit-exact: ragged counts, duplicated patches (exact SAD ties ->
+    overflow kernel), dense clusters (K cap), and the 8000-keypoint window."""
+    libviso_amd.set_matcher_variant(variant)        # plain family
+    _VARIANT[0] = variant                           # batches: per context (see _run_batch)
     try:
         seq = synth.make_sequence(104, 4, n_kp=900, width=300, height=120, ragged=True, dup_frac=0.1)
         ctx, b, st, tm = _run_batch(seq, full=False)
@@ -115,4 +130,5 @@ def test_both_matcher_kernels_agree_with_oracle(viso, oracle, variant):
             assert np.array_equal(b.matches(which, t), want), (variant, which, t)
         b.close(); ctx.close()
     finally:
-        libviso_amd.set_matcher_variant(3)
+        _VARIANT[0] = None
+        libviso_amd.set_matcher_variant(libviso_amd.DEFAULT_MATCHER)

@@ -51,7 +51,7 @@ def _case(rng, F):
     return kp1, kp2, d1, d2, mp
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", libviso_amd.MATCHER_VARIANTS)
 def test_match_desc_randomised(viso, oracle, variant):
     F = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
     rng = np.random.default_rng(20260 + variant)
@@ -67,4 +67,4 @@ def test_match_desc_randomised(viso, oracle, variant):
             n_nonempty += len(want) > 0
         assert n_nonempty > 100
     finally:
-        libviso_amd.set_matcher_variant(3)
+        libviso_amd.set_matcher_variant(libviso_amd.DEFAULT_MATCHER)

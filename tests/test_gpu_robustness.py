@@ -1,0 +1,148 @@
+"""Robustness of the batch family on the device: process teardown with live handles, the per-image
+general-path flag, asynchronous (pinned, stream-ordered) uploads, uploads while a run is in flight."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exit_with_live_handles_keeps_the_python_exit_code():
+    """A Batch and a Context leaked by an exception: the process must end with the traceback's exit code (1), not
+    with an abort from inside the HIP runtime (round 1: exit 134, std::bad_variant_access)."""
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import libviso_amd
+        from libviso_amd import synth
+        from libviso_amd.abi import MatchParams
+        seq = synth.make_sequence(1, 3, n_kp=300, width=400, height=200)
+        ctx = libviso_amd.Context(0)
+        b = libviso_amd.Batch(ctx, 3, 300)
+        b.upload(seq["kp"], seq["desc"], seq["n"])
+        b.set_params(MatchParams.stereo(seq["F"]), MatchParams.temporal(), seq["param"], seed=1)
+        b.run()
+        keep = [b, ctx]                      # still alive at interpreter exit
+        raise RuntimeError("leak on purpose")
+    """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "leak on purpose" in r.stderr and "terminate called" not in r.stderr
+
+
+def test_destroy_reports_instead_of_swallowing(viso):
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 2, 64)
+    b.close(); b.close()                     # idempotent
+    ctx.close(); ctx.close()
+    assert viso.viso_batch_destroy(None) == 1 and viso.viso_ctx_destroy(None) == 1
+
+
+def _per_call(oracle, seq, which, t, st, tm):
+    n = seq["n"]
+    q = (0, t) if which < 2 else (1, t)
+    tg = (1, t) if which == 0 else ((0, t - 1) if which == 1 else (1, t - 1))
+    nq, nt = n[q[1], q[0]], n[tg[1], tg[0]]
+    return oracle.match_desc(seq["kp"][q[1], q[0], :nq], seq["kp"][tg[1], tg[0], :nt],
+                             seq["desc"][q[1], q[0], :nq], seq["desc"][tg[1], tg[0], :nt],
+                             st if which == 0 else tm, return_scored=True)
+
+
+def test_one_fractional_descriptor_flags_one_image_only(viso, oracle):
+    """16 frames, ONE non-integer descriptor value in image (t=7, right): only that image is flagged, so only the
+    match_desc calls that read it (stereo 7, temporal-right 7 and 8) take the general kernel; everything stays
+    bit-exact and the SAD counters equal the oracle's."""
+    seq = synth.make_sequence(41, 16, n_kp=500, width=640, height=240)
+    seq["desc"][7, 1, 123, 17] += 0.5
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 16, 500)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.set_params(st, tm, seq["param"], seed=2)
+    b.run()
+    flags = b.general_path_flags()
+    want_flags = np.zeros((16, 2), np.int32); want_flags[7, 1] = 1
+    assert np.array_equal(flags, want_flags)
+    sc, _ = b.counters()
+    for t in range(16):
+        for which in range(3 if t else 1):
+            want, wsc = _per_call(oracle, seq, which, t, st, tm)
+            assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc, (which, t)
+    want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=2)
+    tr, ok, n_inl = b.poses()
+    assert np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"])
+    # the flag is per run: integer data again -> no image flagged
+    seq["desc"][7, 1, 123, 17] -= 0.5
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.run()
+    assert not b.general_path_flags().any()
+    b.close(); ctx.close()
+
+
+def test_async_upload_streams_fresh_frames(viso):
+    """The streaming mode: two different sequences alternate through ONE batch by pinned asynchronous uploads,
+    three lanes deep, nothing synchronised between enqueue and run; each result equals the synchronous path's."""
+    nf, kp = 9, 400
+    seqs = [synth.make_sequence(500 + i, nf, n_kp=kp, width=640, height=240) for i in range(2)]
+    st, tm = MatchParams.stereo(seqs[0]["F"]), MatchParams.temporal()
+    want = []
+    for s in seqs:
+        ctx = libviso_amd.Context(0)
+        b = libviso_amd.Batch(ctx, nf, kp)
+        b.upload(s["kp"], s["desc"], s["n"])
+        b.set_params(st, tm, s["param"], seed=3)
+        b.run()
+        want.append(b.poses() + (b.matches(1, 4),))
+        b.close(); ctx.close()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, kp)
+    b.set_params(st, tm, seqs[0]["param"], seed=3)
+    pins = []
+    for s in seqs:
+        pk = libviso_amd.PinnedArray(s["kp"].shape, np.float32); pk.a[...] = s["kp"]
+        pd = libviso_amd.PinnedArray(s["desc"].shape, np.float32); pd.a[...] = s["desc"]
+        pins.append((pk, pd))
+    for step in range(6):
+        i = step % 2
+        b.upload_async(pins[i][0].a, pins[i][1].a, seqs[i]["n"])     # enqueued behind the previous run
+        b.run()
+        if step >= 4:                                                 # the last two steps: check both sequences
+            tr, ok, ninl = b.poses()
+            assert np.array_equal(tr, want[i][0]) and np.array_equal(ok, want[i][1]) and np.array_equal(ninl, want[i][2])
+            assert np.array_equal(b.matches(1, 4), want[i][3])
+    b.close(); ctx.close()
+    for pk, pd in pins:
+        pk.close(); pd.close()
+
+
+def test_synchronous_upload_waits_for_a_run_in_flight(viso):
+    """viso_batch_upload / set_params called right behind an asynchronous run must not corrupt that run."""
+    nf, kp = 33, 1000
+    a = synth.make_sequence(600, nf, n_kp=kp)
+    c = synth.make_sequence(601, nf, n_kp=kp)
+    st, tm = MatchParams.stereo(a["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, kp)
+    b.upload(a["kp"], a["desc"], a["n"])
+    b.set_params(st, tm, a["param"], seed=4)
+    b.run()
+    ref = b.poses()
+    for _ in range(3):
+        b.run()                                  # asynchronous
+        b.upload(c["kp"], c["desc"], c["n"])     # must wait for it
+        b.set_params(st, tm, c["param"], seed=4)
+        b.upload(a["kp"], a["desc"], a["n"])
+        b.set_params(st, tm, a["param"], seed=4)
+        b.run()
+        got = b.poses()
+        assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    b.close(); ctx.close()

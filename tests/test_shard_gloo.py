@@ -2,7 +2,7 @@
 all-gather of per-frame records (gloo here, RCCL on GPUs), and the result does
 not depend on the partition.  The per-rank engine in this CPU test is the
 oracle; on the GPU box the same driver runs the HIP batch pipeline
-(tests/test_gpu_shard.py)."""
+(tests/test_gpu_shard.py, same driver, engine = shard.gpu_engine)."""
 import os
 import socket
 import sys
