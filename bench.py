@@ -137,8 +137,9 @@ def cpu_baseline(seq, st, tm, budget_s):
     t_e, o_e = run(0, k + 1, False)
     stg = o_e["stage_s"]
     cores = min(16, len(os.sched_getaffinity(0)))   # the GPU box gives one GPU's CPU share: 16
-    kc = int(max(2, min((nf - 1) // cores, k)))
-    chunks = [(i * kc, i * kc + kc + 1) for i in range(cores)]
+    kc = int(max(2, min(nf - 1, k // 2)))          # per thread; ranges start at staggered frames and may overlap
+    step = max(1, (nf - 1 - kc) // max(1, cores - 1))
+    chunks = [(min(i * step, nf - 1 - kc), min(i * step, nf - 1 - kc) + kc + 1) for i in range(cores)]
     t0 = time.perf_counter()
     with concurrent.futures.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL during the call
         list(ex.map(lambda c: run(c[0], c[1], False), chunks))

@@ -25,6 +25,7 @@ struct viso_batch {
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
+    int* tile_flag; int tiles;   // [3][nf][tiles] per-64-query-tile scratch of the stereo kernels
     int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored; size_t zeroed_bytes;
     double *x, *X, *x_c, *Xp_c;
     TriItem* tri; JoinItem* join; SolverItem* sitems;
@@ -77,7 +78,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->tile_flag};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -107,7 +108,7 @@ static int build_items(viso_batch* b) {
     }
     HIP_TRY(hipMemcpy(b->views, V.data(), sizeof(ImageView) * V.size(), hipMemcpyHostToDevice));
     std::vector<MatchProblem> P((size_t)b->n_probs);
-    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.ovf = b->pos; p.ovf_cnt = b->zero + 4; p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
+    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.tile_flag = b->tile_flag; p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.ovf = b->pos; p.ovf_cnt = b->zero + 4; p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
     auto img_kp = [&](int t, int side) { return b->kp + ((size_t)t * 2 + side) * kpi; };
     for (int t = 0; t < nf; ++t) {
         for (int which = 0; which < 3; ++which) {
@@ -123,6 +124,7 @@ static int build_items(viso_batch* b) {
             p.res = b->res + o * cap; p.sorted = b->sorted + o * cap * 3; p.pos = b->pos + o * cap;
             p.m_cnt = b->m_cnt + o; p.scored = b->scored + o;
             p.ovf = p.pos; p.ovf_cnt = b->ovf_cnt + o;   // pos is rewritten by the final sort
+            p.tile_flag = b->tile_flag + o * b->tiles;
             p.pidx = which == 0 ? 0 : 1; p.cap = cap;
         }
     }
@@ -192,6 +194,8 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
     A(dalloc(&b->m_cnt, 3 * nf));
+    b->tiles = (cap + 63) / 64;
+    A(dalloc(&b->tile_flag, 3 * nf * (size_t)b->tiles));
     // per-run counters zeroed by ONE memset: scored[3nf] (u64) | ovf_cnt[3nf] (int) | bad_img[2nf] (int) | bad_any (int)
     b->zeroed_bytes = 3 * nf * sizeof(unsigned long long) + (3 * nf + 2 * nf + 4) * sizeof(int);
     A(dalloc(&b->scored, b->zeroed_bytes / sizeof(unsigned long long) + 1));

@@ -59,6 +59,8 @@ struct MatchProblem {            // one match_desc call (reference src/viso.cpp:
     unsigned long long* scored;  // out: number of SAD evaluations (C of SURVEY 8(d))
     int* ovf;                    // scratch: sorted positions of queries left to the overflow kernel
     int* ovf_cnt;                // scratch: their count (zeroed before every run)
+    int* tile_flag;              // scratch, stereo call: per 64-query tile, 1 = match_batch_kernel<1> does the tile
+                                 //     (written by match_stereo_kernel for every tile, read by the kernel behind it)
     int pidx;                    // 0 = stereo params, 1 = temporal params
     int cap;                     // row capacity of res/sorted/pos
 };
@@ -149,6 +151,8 @@ struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int variant);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
+int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
+int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);

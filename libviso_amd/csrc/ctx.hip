@@ -160,6 +160,8 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (8), 16-B aligned pieces
     auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 8 + 15) / 16) * 16; };
     if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
+    int* dtile;
+    if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(dk1, kp1, sizeof(float2) * n1, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(df1, d1, sizeof(float) * (size_t)n1 * dlen, hipMemcpyHostToDevice, s));
     if (n2) {
@@ -185,6 +187,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     P.t = view(daux + aux_bytes((size_t)n1), n2a, dk2, df2, dmisc + 1, du2);
     P.res = dres; P.sorted = dsorted; P.pos = dpos;
     P.m_cnt = dmisc + 3; P.scored = (unsigned long long*)(dmisc + 4); P.pidx = 0; P.cap = n1;
+    P.tile_flag = dtile;
     P.ovf = dpos; P.ovf_cnt = dmisc + 6;   // pos is written by the final sort, after the overflow pass
     struct { MatchProblem p; ImageView v[2]; } up;
     up.p = P; up.v[0] = P.q; up.v[1] = P.t;

@@ -58,7 +58,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MB_WAVES][MB_G][64];
     __shared__ float2 s_kp[MB_KPCAP];
     __shared__ int s_idx[MB_KPCAP];
-    __shared__ float s_xr[2];
+    __shared__ float s_xr[4];
     int prob, qblk;
     {
         const int b = blockIdx.x;
@@ -76,17 +76,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     const int q1 = min(q0 + MB_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
     if ((mp.epi != 0) != (EPI != 0)) return;
+    if (EPI && P.tile_flag[qblk] == 0) return;   // match_stereo_kernel (narrow epipolar band) has done this tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // ---- tile window (identical to match_kernel)
     if (wave == 0) {
-        float x = (q0 + lane < q1) ? P.q.skp[q0 + lane].x : __builtin_nanf("");
-        float mn = x, mx = x;
+        const float2 qv = (q0 + lane < q1) ? P.q.skp[q0 + lane] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        float mn = qv.x, mx = qv.x;
+        float yn = qv.y, yx = qv.y;
+        bool ynan = qv.y != qv.y && (q0 + lane < q1);
 #pragma unroll
         for (int m = 1; m < VISO_WAVE; m <<= 1) {
             mn = fminf(mn, __shfl_xor(mn, m));
             mx = fmaxf(mx, __shfl_xor(mx, m));
+            if (EPI) {
+                yn = fminf(yn, __shfl_xor(yn, m));
+                yx = fmaxf(yx, __shfl_xor(yx, m));
+            }
         }
         if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
+        if (EPI) {
+            // epipolar band of the tile (match_dev.h): targets with |dy| > band cannot pass the Sampson gate
+            const bool anynan = __any(ynan);
+            if (lane == 0) s_xr[2] = anynan ? __builtin_huge_valf() : epipolar_band(mp.F, mp.sampson_thresh, mn, mx, yn, yx, mp.radius);
+        }
     }
     __syncthreads();
     int lo = 0, W = 0;
@@ -116,6 +128,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     __syncthreads();
     const float radius = mp.radius;
     const int K = mp.K;
+    const float band = EPI ? s_xr[2] : 0.f;
     // the row gathers are the hot loads: pin their address space (global_load, not flat_load)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* grow_t;
@@ -147,6 +160,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
         // ---------------- phase 1: one scan of the window for the round's MB_G queries
         float2 qk[MB_G];      // wave uniform (scalar registers)
         int orig[MB_G], cnt[MB_G], seg_n[MB_G];
+        int qn[MB_G];   // queued (EPI: in radius AND inside the epipolar band); cnt = all in radius (the K cap counts those)
         uint32_t thr[MB_G];
 #pragma unroll
         for (int k = 0; k < MB_G; ++k) {
@@ -155,6 +169,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
             orig[k] = __builtin_amdgcn_readlane(po, k);
             s_qrow[wave][k][lane] = prow[k];
             cnt[k] = 0;
+            qn[k] = 0;
             // d = |dx| + |dy| is +0, positive or NaN, so its bit pattern orders like the value and every NaN is
             // above +inf: (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in
             // radius: Q1, src/viso.cpp:693) or bits(radius) + 1.  Dead slots (past the tile) get 0: nothing passes.
@@ -171,15 +186,21 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
             const uint32_t ea = (uint32_t)(base + lane), eb = ea + VISO_WAVE;
 #pragma unroll
             for (int k = 0; k < MB_G; ++k) {
-                const bool ina = mb_l1_bits(qk[k].x, qk[k].y, ta) < thr[k];
-                const bool inb = mb_l1_bits(qk[k].x, qk[k].y, tb) < thr[k];
+                bool ina = mb_l1_bits(qk[k].x, qk[k].y, ta) < thr[k];
+                bool inb = mb_l1_bits(qk[k].x, qk[k].y, tb) < thr[k];
+                if (EPI) {
+                    cnt[k] += __popcll(__ballot(ina)) + __popcll(__ballot(inb));
+                    ina = ina && fabsf(qk[k].y - ta.y) <= band;
+                    inb = inb && fabsf(qk[k].y - tb.y) <= band;
+                }
                 const unsigned long long ma = __ballot(ina), mb = __ballot(inb);
                 const int ca = __popcll(ma);
                 // a segment holds MB_SEG entries; a query that needs more is flagged below, its clamped writes are ignored
                 uint32_t* dst = pairs + k * MB_SEG;
-                if (ina) dst[min(cnt[k] + mbcnt(ma), MB_SEG - 1)] = ea;
-                if (inb) dst[min(cnt[k] + ca + mbcnt(mb), MB_SEG - 1)] = eb;
-                cnt[k] += ca + __popcll(mb);
+                if (ina) dst[min(qn[k] + mbcnt(ma), MB_SEG - 1)] = ea;
+                if (inb) dst[min(qn[k] + ca + mbcnt(mb), MB_SEG - 1)] = eb;
+                qn[k] += ca + __popcll(mb);
+                if (!EPI) cnt[k] = qn[k];
             }
         }
         if (W > wcap) {   // windows wider than MB_KPCAP (dense data only): the rest from global memory
@@ -188,48 +209,31 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
                 for (int base = wcap; base < W; base += VISO_WAVE) {
                     const int w = base + lane;
                     bool in = false;
-                    if (w < W) in = __float_as_uint(l1_kp(qk[k].x, qk[k].y, P.t.skp[lo + w])) < thr[k];
+                    float2 t2 = make_float2(0.f, 0.f);
+                    if (w < W) { t2 = P.t.skp[lo + w]; in = __float_as_uint(l1_kp(qk[k].x, qk[k].y, t2)) < thr[k]; }
+                    if (EPI) {
+                        cnt[k] += __popcll(__ballot(in));
+                        in = in && fabsf(qk[k].y - t2.y) <= band;
+                    }
                     const unsigned long long m = __ballot(in);
-                    if (in) pairs[k * MB_SEG + min(cnt[k] + mbcnt(m), MB_SEG - 1)] = (uint32_t)w;
-                    cnt[k] += __popcll(m);
+                    if (in) pairs[k * MB_SEG + min(qn[k] + mbcnt(m), MB_SEG - 1)] = (uint32_t)w;
+                    qn[k] += __popcll(m);
+                    if (!EPI) cnt[k] = qn[k];
                 }
             }
         }
         int flags = 0, npass = 0;
 #pragma unroll
         for (int k = 0; k < MB_G; ++k) {
-            const bool fits = cnt[k] <= K && cnt[k] <= MB_SEG;
+            const bool fits = cnt[k] <= K && qn[k] <= MB_SEG;
             if (!fits && orig[k] >= 0) flags |= 1 << k;   // left to the overflow kernel
-            int n = fits ? cnt[k] : 0;
-            if (EPI && n > 0) {   // Sampson gate, one candidate per lane, in-place compaction of the segment
-                uint32_t* seg = pairs + k * MB_SEG;
-                int wr = 0;
-                for (int b = 0; b < n; b += VISO_WAVE) {
-                    const int i = b + lane;
-                    bool pass = false;
-                    uint32_t e = 0;
-                    if (i < n) {
-                        e = seg[i];
-                        float2 t2;
-                        if ((int)e < wcap) t2 = s_kp[e]; else t2 = P.t.skp[lo + (int)e];
-                        const double s = sampson_dev(mp.F, qk[k].x, qk[k].y, t2.x, t2.y);
-                        pass = isfinite(s) && !(s > mp.sampson_thresh);
-                    }
-                    const unsigned long long m = __ballot(pass);
-                    const int pos = wr + mbcnt(m);
-                    __builtin_amdgcn_wave_barrier();
-                    if (pass) seg[pos] = e;
-                    wr += __popcll(m);
-                }
-                n = wr;
-            }
-            seg_n[k] = n;
+            seg_n[k] = fits ? qn[k] : 0;
         }
         // ---------------- phase 1b: close the gaps — segments 1..3 move down behind segment 0 (ascending, each
         // 64-entry chunk read before it is written, destination never above the source) and get their query tag, so
         // that the round's pairs are one contiguous list: entry = query << 30 | window position << 8
         static_assert(MB_G == 4, "segment bookkeeping below is written out for 4 segments");
-        const int c1 = seg_n[0], c2 = c1 + seg_n[1], c3 = c2 + seg_n[2], ntot = c3 + seg_n[3];
+        int c1 = seg_n[0], c2 = c1 + seg_n[1], c3 = c2 + seg_n[2], ntot = c3 + seg_n[3];
         {
             const int cs[MB_G] = {0, c1, c2, c3};
 #pragma unroll
@@ -242,11 +246,42 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
                     if (i < seg_n[k]) pairs[cs[k] + i] = (e << 8) | ((uint32_t)k << 30);   // byte offset of the row | query
                 }
             }
-            // padding behind the list (copies of the last pair): the pipeline runs up to MB_NP - 1 passes past the
-            // end and the last pass may be partial — those lanes re-score the last pair into scratch slots
             __builtin_amdgcn_wave_barrier();
-            if (ntot > 0 && lane < MB_PAD) pairs[ntot + lane] = pairs[ntot - 1];
         }
+        if (EPI && ntot > 0) {
+            // Sampson gate (src/viso.cpp:695-701) over the candidates of ALL FOUR queries at once, one candidate per
+            // lane (the epipolar band leaves a handful per query, so a round usually is one pass), in-place compaction
+            // that keeps the list ordered by query.  sampson_dev is the reference's arithmetic, bit for bit.
+            int wr = 0;
+            seg_n[0] = seg_n[1] = seg_n[2] = seg_n[3] = 0;
+            for (int b = 0; b < ntot; b += VISO_WAVE) {
+                const int i = b + lane;
+                bool pass = false;
+                uint32_t e = 0;
+                if (i < ntot) {
+                    e = pairs[i];
+                    const uint32_t kq = e >> 30, w = (e & 0x3fffffffu) >> 8;
+                    float2 t2;
+                    if ((int)w < wcap) t2 = s_kp[w]; else t2 = P.t.skp[lo + (int)w];
+                    const float qx = kq == 0 ? qk[0].x : kq == 1 ? qk[1].x : kq == 2 ? qk[2].x : qk[3].x;
+                    const float qy = kq == 0 ? qk[0].y : kq == 1 ? qk[1].y : kq == 2 ? qk[2].y : qk[3].y;
+                    const double sd = sampson_dev(mp.F, qx, qy, t2.x, t2.y);
+                    pass = isfinite(sd) && !(sd > mp.sampson_thresh);
+                }
+                const unsigned long long m = __ballot(pass);
+                const int pos = wr + mbcnt(m);
+                __builtin_amdgcn_wave_barrier();
+                if (pass) pairs[pos] = e;   // pos <= i: in place
+                wr += __popcll(m);
+#pragma unroll
+                for (int k = 0; k < MB_G; ++k) seg_n[k] += __popcll(__ballot(pass && (e >> 30) == (uint32_t)k));
+            }
+            c1 = seg_n[0]; c2 = c1 + seg_n[1]; c3 = c2 + seg_n[2]; ntot = c3 + seg_n[3];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // padding behind the list (copies of the last pair): the pipeline runs up to MB_NP - 1 passes past the
+        // end and the last pass may be partial — those lanes re-score the last pair into scratch slots
+        if (ntot > 0 && lane < MB_PAD) pairs[ntot + lane] = pairs[ntot - 1];
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2: score every pair of the round, 8 lanes per pair, 8 consecutive pairs per pass
         {
@@ -441,11 +476,18 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         HIP_TRY(hipGetLastError());
     } else
 #endif
-    {
+    if (variant == 4) {
+        const int r = launch_match_strip_temporal(s, at, cap_max);
+        if (r < 0) return r;
+    } else {
         const int r = launch_match_union_temporal(s, at, bt);
         if (r < 0) return r;
     }
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, s));
+    {   // stereo problems: lane-per-query kernel for tiles with a narrow epipolar band, the kernel below for the rest
+        const int r = launch_match_stereo(s, as, cap_max);
+        if (r < 0) return r;
+    }
     hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)bs), dim3(MB_THREADS), 0, s, as);
     HIP_TRY(hipGetLastError());
     return VISO_OK;

@@ -34,6 +34,55 @@ __device__ __forceinline__ double sampson_dev(const double* F, float p1x, float 
     return ad2 / (Fx0 * Fx0 + Fx1 * Fx1 + Ftx0 * Ftx0 + Ftx1 * Ftx1);
 }
 
+// Epipolar band (stereo call): a bound `band` such that every target p2 within L1 distance r of a query p1 of the
+// box [xa,xb] x [ya,yb] with |p2.y - p1.y| > band is REJECTED by the gate of src/viso.cpp:695-701 (its computed
+// Sampson value exceeds thresh, or is not finite).  The gate itself stays sampson_dev, bit for bit; the band only
+// spares candidates that cannot pass from being evaluated.  Derivation (a = (x1,y1,1), b = a + (dx,dy,0)):
+//   e = b' F a = a' F a + dx (F a)_0 + dy (F a)_1,  |e| >= |dy| m1 - r M0 - G
+//   den = (F a)_0^2 + (F a)_1^2 + (F' b)_0^2 + (F' b)_1^2 <= D
+// with m1 = min |(F a)_1|, M0 = max |(F a)_0|, M1 = max |(F a)_1| and G >= |a' F a| over the query box, N0, N1 =
+// max |(F' b)_{0,1}| over the box grown by r; the computed value is >= (|e| (1 - 1e-6) - 1e-9 T)^2 (1 - 1e-6) / D
+// (T bounds the sum of the absolute terms of e: double summation, one rounding to float, one float product, one
+// double division — the slack is orders of magnitude above their error), so it exceeds thresh whenever
+// |dy| > band.  Returns +inf (no restriction) whenever F, the box or thresh admit no finite band.
+// For a rectified pair (F ~ [0 0 0; 0 0 -c; 0 c 0]) band = sqrt(2 thresh) (1 + 4e-6): |dy| <= 1 for thresh = 1.
+__device__ __forceinline__ float epipolar_band(const double* F, double thresh, float xa, float xb, float ya, float yb, float r) {
+    const float inf = __builtin_huge_valf();
+    if (!(thresh >= 0.0) || !(r >= 0.f) || !(xa <= xb) || !(ya <= yb)) return inf;
+    const double x[2] = {(double)xa, (double)xb}, y[2] = {(double)ya, (double)yb};
+    const double X = fmax(fabs(x[0]), fabs(x[1])), Y = fmax(fabs(y[0]), fabs(y[1]));
+    double m1 = 1.7976931348623157e308, M0 = 0, M1 = 0;
+    bool pos = false, neg = false;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {   // linear functions: extrema at the corners
+            const double f0 = F[0] * x[i] + F[1] * y[j] + F[2];
+            const double f1 = F[3] * x[i] + F[4] * y[j] + F[5];
+            M0 = fmax(M0, fabs(f0)); M1 = fmax(M1, fabs(f1));
+            m1 = fmin(m1, fabs(f1));
+            pos = pos || f1 > 0; neg = neg || f1 < 0;
+        }
+    if (pos && neg) m1 = 0;
+    // corner values carry a rounding error of a few ulp of the absolute sums: shrink / grow by a relative 1e-9 of those
+    const double S0 = fabs(F[0]) * X + fabs(F[1]) * Y + fabs(F[2]), S1 = fabs(F[3]) * X + fabs(F[4]) * Y + fabs(F[5]);
+    m1 -= 1e-9 * S1; M0 += 1e-9 * S0; M1 += 1e-9 * S1;
+    if (!(m1 > 0)) return inf;
+    const double Xt = X + (double)r, Yt = Y + (double)r;
+    const double N0 = fabs(F[0]) * Xt + fabs(F[3]) * Yt + fabs(F[6]), N1 = fabs(F[1]) * Xt + fabs(F[4]) * Yt + fabs(F[7]);
+    const double G = fabs(F[0]) * X * X + fabs(F[1] + F[3]) * X * Y + fabs(F[4]) * Y * Y + fabs(F[2] + F[6]) * X +
+                     fabs(F[5] + F[7]) * Y + fabs(F[8]) +
+                     1e-9 * ((fabs(F[1]) + fabs(F[3])) * X * Y + (fabs(F[2]) + fabs(F[6])) * X + (fabs(F[5]) + fabs(F[7])) * Y);
+    const double T = Xt * (fabs(F[0]) * X + fabs(F[1]) * Y + fabs(F[2])) + Yt * (fabs(F[3]) * X + fabs(F[4]) * Y + fabs(F[5])) +
+                     fabs(F[6]) * X + fabs(F[7]) * Y + fabs(F[8]);
+    const double D = M0 * M0 + M1 * M1 + N0 * N0 + N1 * N1;
+    const double Emin = (sqrt(thresh * D) * (1.0 + 2e-6) + 1e-9 * T) * (1.0 + 2e-6);
+    const double band = ((Emin + (double)r * M0 + G) / m1) * (1.0 + 1e-6) + 1e-6;
+    if (!(band == band) || band > 3.0e38) return inf;
+    // round up to float: a float >= band
+    float bf = (float)band;
+    if ((double)bf < band) bf = __uint_as_float(__float_as_uint(bf) + 1u);
+    return bf;
+}
+
 __device__ __forceinline__ bool key_less(uint32_t ad, uint32_t ai, uint32_t bd, uint32_t bi) {
     return ad < bd || (ad == bd && ai < bi);
 }

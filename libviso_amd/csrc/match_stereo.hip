@@ -1,0 +1,335 @@
+// match_stereo.hip — the stereo call (epipolar gate on, src/viso.cpp:1240), ONE LANE PER QUERY.
+//
+// With the Sampson gate on, ~3 of a query's ~50 in-radius targets are ever scored.  match_batch_kernel<1> still
+// paid a wave-wide scan of the whole +-radius column window per query and a wave-wide fp64 gate pass per round:
+// ~200 vector instructions per query for 3 SADs.  Here a wave owns a tile of 64 x-adjacent queries, one per lane:
+//
+//   band    the tile's epipolar band (match_dev.h, epipolar_band): targets with |dy| > band are rejected by the
+//           gate whatever their x, so they are never looked at; sqrt(2 thresh) for a rectified pair;
+//   index   the tile's column window of the target image (keypoints only: 8 B each), bucket-sorted by y inside
+//           the wave (LDS histogram with returning atomics, DPP scan): 64 buckets;
+//   walk    every lane walks the few entries of the buckets its band touches: L1 radius + Q1 cut + band test,
+//           then the exact gate (sampson_dev, the reference's arithmetic bit for bit) on what is left;
+//   score   the survivors of all 64 queries form one flat pair list, scored 8 lanes per pair (two 16-B row gathers
+//           for the target, two for the query, 8 x v_sad_u16, 3 DPP adds), SADs to LDS;
+//   reduce  every lane folds its own few SADs into (min, second min with multiplicity, argmin, tie).
+//
+// The K cap (max_neighbors, applied by the reference BEFORE the gate, :181/:692) needs the number of in-radius
+// targets: the y index gives an upper bound in O(1) (entries with |dy| <= radius); only if that bound exceeds K
+// (dense clusters) is the exact count taken.  Irregular queries (more than K in radius, an exact SAD tie, more
+// than ST_SLOTS survivors) go to match_overflow_kernel, tiles whose band is wide or unbounded (pairs that are not
+// rectified) to match_batch_kernel<1>, which walks the full radius: the tile flag tells it which.
+#include "common.h"
+#include "match_dev.h"
+
+#define ST_THREADS 256
+#define ST_WAVES 4
+#define ST_QPW 64            // queries per wave = per tile
+#define ST_WCAP 448          // window keypoints per chunk (7 per lane)
+#define ST_NBY 64            // y buckets
+#define ST_SLOTS 8           // candidates per query and chunk that may reach the scorer
+#define ST_PCAP (ST_QPW * ST_SLOTS)
+#define ST_PAD 16            // the scoring pipeline runs up to 2 passes of 8 pairs past the end
+#define ST_BAND_MAX 6.0f     // wider bands: match_batch_kernel<1>
+
+struct StWaveLds {
+    float2 ykp[ST_WCAP];                 // window keypoints in y-bucket order
+    uint16_t ypos[ST_WCAP];              // their window positions
+    int hist[ST_NBY + 1];                // bucket counts, then bucket starts (hist[ST_NBY] = number of entries)
+    uint16_t slot[ST_SLOTS][ST_QPW];     // per query: y-order indices of its candidates
+    uint32_t flat[ST_PCAP + ST_PAD];     // query << 16 | window position
+    uint32_t sads[ST_PCAP + ST_PAD];
+};
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t st_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// inclusive prefix sum over the wave (values < 2^16)
+__device__ __forceinline__ int st_scan_incl(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < VISO_WAVE; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
+    if (y != y) return ST_NBY - 1;
+    const float f = floorf((y - y0) * scale);
+    return f <= 0.f ? 0 : (f >= (float)(ST_NBY - 1) ? ST_NBY - 1 : (int)f);
+}
+
+__global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs a) {
+    __shared__ __attribute__((aligned(16))) StWaveLds s_w[ST_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int prob, tile;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        const int g = slot / a.bpp;                 // a.bpp = blocks (of ST_WAVES tiles) per problem
+        prob = ((g / a.gc) * a.gs + a.gf + g % a.gc) * 8 + xcd;
+        tile = (slot % a.bpp) * ST_WAVES + wave;
+        if (prob >= a.n_probs) return;
+    }
+    const MatchProblem P = a.probs[prob];
+    const MatchParamsDev& mp = a.mp[P.pidx];
+    if (mp.epi == 0) return;                        // temporal problems: the other kernels
+    if ((*P.q.bad | *P.t.bad) != 0) return;         // non-integer descriptors: the general kernel does this problem
+    const int n1 = *P.q.n, n2 = *P.t.n;
+    const int q0 = tile * ST_QPW;
+    if (q0 >= n1) return;
+    const int q1 = min(q0 + ST_QPW, n1);
+    StWaveLds& L = s_w[wave];
+    // ---- the lane's query
+    const int j = q0 + lane;
+    const bool live = j < q1;
+    const float2 qv = live ? P.q.skp[j] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    const int orig = live ? P.q.sidx[j] : -1;
+    const float radius = mp.radius;
+    const int K = mp.K;
+    // ---- tile: x range -> window, y range -> band
+    float xa = qv.x, xb = qv.x, ya = qv.y, yb = qv.y;
+#pragma unroll
+    for (int m = 1; m < VISO_WAVE; m <<= 1) {
+        xa = fminf(xa, __shfl_xor(xa, m)); xb = fmaxf(xb, __shfl_xor(xb, m));
+        ya = fminf(ya, __shfl_xor(ya, m)); yb = fmaxf(yb, __shfl_xor(yb, m));
+    }
+    const bool ynan = __any(live && qv.y != qv.y);
+    float band = __builtin_huge_valf();
+    if (!ynan) band = epipolar_band(mp.F, mp.sampson_thresh, xa, xb, ya, yb, radius);
+    band = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(band)));
+    const bool mine = band <= ST_BAND_MAX;
+    if (lane == 0) P.tile_flag[tile] = mine ? 0 : 1;   // 1: match_batch_kernel<1> walks the full radius for this tile
+    if (!mine) return;
+    int lo = 0, W = 0;
+    if (n2 > 0 && xa == xa && radius >= 0.f) {
+        const float slack = (fabsf(xa) + fabsf(xb) + fabsf(radius)) * 1e-6f + 1e-6f;
+        const float x0 = P.t.xinfo[0], scale = P.t.xinfo[1];
+        lo = P.t.bstart[bucket_of(xa - radius - slack, x0, scale)];
+        W = P.t.bstart[bucket_of(xb + radius + slack, x0, scale) + 1] - lo;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    W = __builtin_amdgcn_readfirstlane(W);
+    // Q1 (src/viso.cpp:693): (d <= radius && d < d0cut) as one unsigned compare of the bits of d (see match_union.hip)
+    uint32_t thr = __float_as_uint(radius) + 1u;
+    if (n2 > 0) {
+        const float2 kp0 = P.t.skp[P.t.rank[0]];
+        const float d0 = l1_kp(qv.x, qv.y, kp0);
+        if (d0 <= radius) thr = __float_as_uint(d0);
+    }
+    if (!live) thr = 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* grow_t;
+    typedef const __attribute__((address_space(1))) char* gbytes_t;
+    const gbytes_t trows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows);
+    const gbytes_t qrows = (gbytes_t)reinterpret_cast<const char*>(P.q.rows) + (size_t)q0 * (VISO_ROW * 2);
+    const int g8 = lane >> 3, sub = lane & 7;
+    // per-query state, carried over the chunks
+    uint32_t d1 = 0xffffffffu, d2 = 0xffffffffu, bw = 0, tie = 0;
+    int cnt_ub = 0, nscored = 0;
+    bool force = false;   // more survivors than slots: the overflow kernel redoes the query
+
+    for (int cb = 0; cb < W; cb += ST_WCAP) {
+        const int cw = min(W - cb, ST_WCAP);
+        // ---- y index of the chunk: bucket sort inside the wave
+        float2 e_kp[ST_WCAP / 64];
+        int e_b[ST_WCAP / 64], e_r[ST_WCAP / 64];
+        float y0 = __builtin_huge_valf(), y1 = -__builtin_huge_valf();
+#pragma unroll
+        for (int i = 0; i < ST_WCAP / 64; ++i) {
+            const int w = lane + 64 * i;
+            e_kp[i] = w < cw ? P.t.skp[lo + cb + w] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+            y0 = fminf(y0, e_kp[i].y); y1 = fmaxf(y1, e_kp[i].y);
+        }
+#pragma unroll
+        for (int m = 1; m < VISO_WAVE; m <<= 1) {
+            y0 = fminf(y0, __shfl_xor(y0, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+        }
+        float yscale = 0.f;
+        if (y1 > y0) yscale = (float)ST_NBY / (y1 - y0);
+        if (!(yscale > 0.f) || !(yscale < 3.0e38f)) yscale = 0.f;
+        if (!(y0 == y0) || !(fabsf(y0) < 3.0e38f)) { y0 = 0.f; yscale = 0.f; }
+        L.hist[lane] = 0;
+        if (lane == 0) L.hist[ST_NBY] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < ST_WCAP / 64; ++i) {
+            e_b[i] = st_bucket(e_kp[i].y, y0, yscale);
+            e_r[i] = 0;
+            if (lane + 64 * i < cw) e_r[i] = atomicAdd(&L.hist[e_b[i]], 1);   // returning LDS atomic: rank inside the bucket
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int h = L.hist[lane];
+            const int incl = st_scan_incl(h, lane);
+            __builtin_amdgcn_wave_barrier();
+            L.hist[lane] = incl - h;           // bucket start
+            if (lane == 63) L.hist[ST_NBY] = incl;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < ST_WCAP / 64; ++i) {
+            if (lane + 64 * i < cw) {
+                const int p = L.hist[e_b[i]] + e_r[i];
+                L.ykp[p] = e_kp[i];
+                L.ypos[p] = (uint16_t)(lane + 64 * i);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- walk: the buckets the lane's band touches
+        int n = 0;
+        {
+            // the bucket map is monotone in y; `ys` covers the rounding of the float differences the tests below take
+            const float ys = (fabsf(qv.y) + fabsf(radius)) * 1e-6f + 1e-6f;
+            const int s0 = L.hist[st_bucket(qv.y - band - ys, y0, yscale)];
+            const int s1 = L.hist[st_bucket(qv.y + band + ys, y0, yscale) + 1];
+            // upper bound of the in-radius count (K cap): entries with |dy| <= radius
+            cnt_ub += L.hist[st_bucket(qv.y + radius + ys, y0, yscale) + 1] - L.hist[st_bucket(qv.y - radius - ys, y0, yscale)];
+            for (int i = s0; __any(i < s1); ++i) {
+                if (i < s1) {
+                    const float2 t = L.ykp[i];
+                    const float dx = qv.x - t.x, dy = qv.y - t.y;
+                    const bool in = __float_as_uint(fabsf(dx) + fabsf(dy)) < thr && fabsf(dy) <= band;
+                    if (in) {
+                        if (n < ST_SLOTS) L.slot[n][lane] = (uint16_t)i; else force = true;
+                        n = min(n + 1, ST_SLOTS);
+                    }
+                }
+            }
+        }
+        // ---- the exact gate on what is left (src/viso.cpp:695-701), compaction in place
+        int n2g = 0;
+        for (int s = 0; __any(s < n); ++s) {
+            if (s < n) {
+                const int i = L.slot[s][lane];
+                const float2 t = L.ykp[i];
+                const double sd = sampson_dev(mp.F, qv.x, qv.y, t.x, t.y);
+                if (isfinite(sd) && !(sd > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i; ++n2g; }
+            }
+        }
+        // ---- flat pair list of the tile
+        const int incl = st_scan_incl(n2g, lane);
+        const int base = incl - n2g;
+        const int ntot = __builtin_amdgcn_readlane(incl, 63);
+        for (int s = 0; s < n2g; ++s) L.flat[base + s] = ((uint32_t)lane << 16) | (uint32_t)L.ypos[L.slot[s][lane]];
+        __builtin_amdgcn_wave_barrier();
+        if (ntot > 0 && lane < ST_PAD) L.flat[ntot + lane] = L.flat[ntot - 1];
+        __builtin_amdgcn_wave_barrier();
+        // ---- score: 8 lanes per pair, 8 pairs per pass, two passes in flight
+        {
+            const int npass = (ntot + 7) >> 3;
+            const gbytes_t wrows = trows + (size_t)(lo + cb) * (VISO_ROW * 2);
+            u32x4 t0[2], t1[2], u0[2], u1[2];
+            int dst[2];
+#define ST_ISSUE(SLOT, T)                                                                                  \
+            do {                                                                                           \
+                const int gi_ = (T) * 8 + g8;                                                              \
+                const uint32_t e_ = L.flat[gi_];                                                           \
+                dst[SLOT] = gi_;                                                                           \
+                const grow_t tr_ = (grow_t)(wrows + (((e_ & 0xffffu) << 8) | (uint32_t)(sub << 4)));       \
+                const grow_t qr_ = (grow_t)(qrows + (((e_ >> 16) << 8) | (uint32_t)(sub << 4)));           \
+                t0[SLOT] = tr_[0]; t1[SLOT] = tr_[8];                                                      \
+                u0[SLOT] = qr_[0]; u1[SLOT] = qr_[8];                                                      \
+            } while (0)
+#define ST_REDUCE(SLOT)                                                                                    \
+            do {                                                                                           \
+                uint32_t s_ = __builtin_amdgcn_sad_u16(t0[SLOT].x, u0[SLOT].x, 0u);                        \
+                s_ = __builtin_amdgcn_sad_u16(t0[SLOT].y, u0[SLOT].y, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t0[SLOT].z, u0[SLOT].z, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t0[SLOT].w, u0[SLOT].w, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t1[SLOT].x, u1[SLOT].x, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t1[SLOT].y, u1[SLOT].y, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t1[SLOT].z, u1[SLOT].z, s_);                                 \
+                s_ = __builtin_amdgcn_sad_u16(t1[SLOT].w, u1[SLOT].w, s_);                                 \
+                s_ += st_dpp<0xB1>(s_);                                                                    \
+                s_ += st_dpp<0x4E>(s_);                                                                    \
+                s_ += st_dpp<0x141>(s_);                                                                   \
+                if (sub == 0) L.sads[dst[SLOT]] = s_;   /* slots past ntot are scratch */                  \
+            } while (0)
+            if (npass > 0) { ST_ISSUE(0, 0); ST_ISSUE(1, 1); }
+            int t = 0;
+            for (; t + 2 < npass; t += 2) {
+                ST_REDUCE(0); ST_ISSUE(0, t + 2);
+                ST_REDUCE(1); ST_ISSUE(1, t + 3);
+            }
+            if (npass > 0) { ST_REDUCE(0); ST_REDUCE(1); }
+#undef ST_REDUCE
+#undef ST_ISSUE
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- reduce: the lane's own SADs into its running order statistics
+        for (int s = 0; s < n2g; ++s) {
+            const uint32_t v = L.sads[base + s];
+            const uint32_t w = (L.flat[base + s] & 0xffffu) + (uint32_t)cb;
+            const bool lt = v < d1, eq = v == d1;
+            d2 = (v <= d1) ? d1 : min(d2, v);
+            bw = lt ? w : bw;
+            tie = lt ? 0u : (eq ? 1u : tie);
+            d1 = min(d1, v);
+        }
+        nscored += n2g;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- K cap: exact in-radius count where the bound does not settle it (dense clusters only)
+    int cnt = cnt_ub;
+    {
+        unsigned long long need = __ballot(live && cnt_ub > K);
+        while (need) {
+            const int ql = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv.x), ql));
+            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv.y), ql));
+            const uint32_t th = (uint32_t)__builtin_amdgcn_readlane((int)thr, ql);
+            int c = 0;
+            for (int base = 0; base < W; base += VISO_WAVE) {
+                const int w = base + lane;
+                bool in = false;
+                if (w < W) in = __float_as_uint(l1_kp(qx, qy, P.t.skp[lo + w])) < th;
+                c += __popcll(__ballot(in));
+            }
+            if (lane == ql) cnt = c;
+        }
+    }
+    // ---- results
+    unsigned long long scored = 0;
+    if (live) {
+        const bool none = d1 == 0xffffffffu;
+        if (cnt > K || force || (!none && tie)) {
+            // more than K in radius / more survivors than slots / exact tie of the minimum (largest-key rule): overflow kernel
+            P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
+        } else {
+            bool accept = !none;
+            int idx = -1;
+            if (accept) {
+                idx = P.t.sidx[lo + (int)bw];
+                if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
+                    const double bd2 = d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)d2;
+                    accept = (double)d1 < bd2 * mp.ratio;
+                }
+            }
+            P.res[orig] = make_int2(accept ? idx : -1, (int)d1);
+            scored = (unsigned long long)nscored;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < VISO_WAVE; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
+    if (lane == 0 && scored) atomicAdd(P.scored, scored);
+}
+
+int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max) {
+    BatchMatchArgs a = a64;
+    const int tiles = (cap_max + ST_QPW - 1) / ST_QPW;
+    a.bpp = (tiles + ST_WAVES - 1) / ST_WAVES;
+    const int groups = (a.n_probs + 7) / 8;
+    long long blocks = (long long)groups * 8 * a.bpp;
+    if (a.gs == 3) blocks = (long long)((groups + 2) / 3) * a.gc * 8 * a.bpp;
+    if (blocks > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(match_stereo_kernel, dim3((unsigned)blocks), dim3(ST_THREADS), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { viso_set_error("match_stereo_kernel launch: %s", hipGetErrorString(e)); return VISO_ERR_HIP; }
+    return VISO_OK;
+}

@@ -122,6 +122,37 @@ def test_match_desc_float_keypoints(viso, oracle, F):
         assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
 
 
+@pytest.mark.parametrize("tilt", [0.0, 1e-4, 2e-3, 3e-2])
+def test_match_desc_stereo_derectified_pairs(viso, oracle, tilt):
+    """Stereo call with a right camera rotated by `tilt` rad about all axes: the epipolar band of the tile kernel
+    (match_dev.h, epipolar_band) is then a few pixels to unbounded instead of sqrt(2); whatever it is, the set that
+    reaches the exact Sampson gate must give the oracle's matches, at several thresholds."""
+    rng = np.random.default_rng(int(tilt * 1e6) + 5)
+    K = synth.KITTI_P1[:, :3]
+    R, _ = synth.rot_from_tr(np.r_[tilt, -tilt * 0.7, tilt * 0.4, 0, 0, 0])
+    P2 = K @ np.c_[R, np.array([-0.54, 0.002 * (tilt > 0), 0])]
+    F = oracle.F_from_P(synth.KITTI_P1, P2)
+    n = 1500
+    kp1 = np.stack([rng.integers(0, 1241, n), rng.integers(0, 376, n)], 1).astype(np.float32)
+    # right keypoints: the left ones shifted along / near their epipolar lines, plus clutter
+    kp2 = kp1 + np.stack([-rng.integers(0, 70, n), rng.integers(-3, 4, n)], 1).astype(np.float32)
+    kp2[n // 2:] = np.stack([rng.integers(0, 1241, n - n // 2), rng.integers(0, 376, n - n // 2)], 1)
+    if tilt > 0:
+        kp1 += rng.uniform(-0.5, 0.5, kp1.shape).astype(np.float32)
+        kp2 += rng.uniform(-0.5, 0.5, kp2.shape).astype(np.float32)
+    d1 = rng.integers(-300, 301, (n, 121)).astype(np.float32)
+    d2 = (d1 + rng.integers(-8, 9, d1.shape)).astype(np.float32)
+    d2[n // 2:] = rng.integers(-300, 301, (n - n // 2, 121))
+    any_match = 0
+    for thresh in (0.3, 1.0, 4.0, 50.0):
+        mp = MatchParams.stereo(F)
+        mp.sampson_thresh = thresh
+        want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+        assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), want), (tilt, thresh)
+        any_match += len(want)
+    assert any_match > 0
+
+
 # ------------------------------------------------------ circle / geometry
 def test_match_circle_general(viso, oracle):
     rng = np.random.default_rng(2)
