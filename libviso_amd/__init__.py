@@ -127,7 +127,7 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-MATCHER_VARIANTS = (3, 4)   # what this build of libviso_hip.so offers (viso_ctx_set_matcher)
+MATCHER_VARIANTS = (3,)   # what this build of libviso_hip.so offers (viso_ctx_set_matcher)
 DEFAULT_MATCHER = 3
 
 

@@ -20,7 +20,7 @@ struct viso_batch {
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
     float2* kp; float* desc; int* n; uint16_t* packed; int* bad_img; int* bad_any; int* zero;
-    float2* skp; int *sidx, *rank, *bstart; float* xinfo;   // x-sorted view of every image
+    float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // x-sorted view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
@@ -78,7 +78,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->tile_flag};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->tile_flag, b->qord};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -96,8 +96,9 @@ static int build_items(viso_batch* b) {
             ImageView& v = V[i];
             v.kp = b->kp + i * kpi; v.frows = b->desc + i * dfi; v.n = b->n + i;
             v.skp = b->skp + i * kpi; v.sidx = b->sidx + i * kpi; v.rank = b->rank + i * kpi;
-            v.bstart = b->bstart + i * (VISO_NB + 1); v.xinfo = b->xinfo + i * 2;
+            v.bstart = b->bstart + i * (VISO_NB + 1); v.xinfo = b->xinfo + i * 8;
             v.rows = b->packed + i * dsi;
+            v.qord = b->qord + i * (((size_t)cap + 63) & ~(size_t)63);
             v.bad = b->bad_img + i;
         }
     {
@@ -191,7 +192,8 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->zero, 8));
     A(dalloc(&b->probs, (size_t)b->n_probs));
     A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
-    A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 2)); A(dalloc(&b->views, nf * 2 + 1));
+    A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 8)); A(dalloc(&b->views, nf * 2 + 1));
+    A(dalloc(&b->qord, nf * 2 * ((c + 63) & ~(size_t)63)));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
     A(dalloc(&b->m_cnt, 3 * nf));
     b->tiles = (cap + 63) / 64;

@@ -44,7 +44,10 @@ struct ImageView {               // one image's keypoints + descriptors on the d
     int* sidx;                   // [n] sorted position -> original index
     int* rank;                   // [n] original index -> sorted position
     int* bstart;                 // [VISO_NB+1] first sorted position of each column bucket
-    float* xinfo;                // [2] x0, scale of the bucket map
+    float* xinfo;                // [8] x0, scale of the column bucket map; smallest and largest finite keypoint y;
+                                 //     [4] number of keypoints whose x is not NaN (they sort first), as a float
+    uint8_t* qord;               // [n rounded up to 64] y order inside every block of 64 sorted positions: entry B*64 + r =
+                                 //     offset (0..63) in block B of the keypoint with y rank r (positions past n rank last)
     uint16_t* rows;              // [n][128] packed descriptor rows, x-sorted order
     int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
                                  //     every problem that reads the image then takes the general (double) kernel

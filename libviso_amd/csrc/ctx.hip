@@ -67,7 +67,7 @@ extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
 #ifdef VISO_DEBUG_VARIANTS
     const bool known = variant >= 2 && variant <= 4;
 #else
-    const bool known = variant == 3 || variant == 4;
+    const bool known = variant == 3;
 #endif
     if (!known) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
     c->matcher_variant = variant;
@@ -157,8 +157,8 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if ((r = ctx_scratch(c, 8, sizeof(int) * n1, (void**)&dpos)) < 0) return r;
     if ((r = ctx_scratch(c, 9, sizeof(int) * 16, (void**)&dmisc)) < 0) return r;
     if ((r = ctx_scratch(c, 10, sizeof(MatchProblem) + 2 * sizeof(ImageView), (void**)&dprob)) < 0) return r;
-    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (8), 16-B aligned pieces
-    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 8 + 15) / 16) * 16; };
+    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64), 16-B aligned pieces
+    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64; };
     if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
     int* dtile;
     if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
@@ -180,6 +180,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         unsigned char* tail = base + ((16 * n + 15) / 16) * 16;
         v.bstart = (int*)tail;
         v.xinfo = (float*)(tail + 4 * (VISO_NB + 1));
+        v.qord = (uint8_t*)(tail + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16);
         return v;
     };
     MatchProblem P{};

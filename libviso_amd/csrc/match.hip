@@ -49,9 +49,20 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     float* s_x = reinterpret_cast<float*>(keys + npad_alloc);   // [0]=x0 [1]=scale
+    __shared__ float s_y[2][VISO_IMG_THREADS / 64];
     if ((int)blockIdx.x >= n_img) return;
     const ImageView I = imgs[blockIdx.x];
     const int n = *I.n;
+    {   // y range of the image's finite keypoints (the matcher kernels bucket their windows by y over it)
+        float ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
+        for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
+            const float y = I.kp[i].y;
+            if (fabsf(y) < 3.0e38f) { ymn = fminf(ymn, y); ymx = fmaxf(ymx, y); }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { ymn = fminf(ymn, __shfl_xor(ymn, m)); ymx = fmaxf(ymx, __shfl_xor(ymx, m)); }
+        if ((threadIdx.x & 63) == 0) { s_y[0][threadIdx.x >> 6] = ymn; s_y[1][threadIdx.x >> 6] = ymx; }
+    }
     int npad = 64;
     while (npad < n) npad <<= 1;
     for (int i = threadIdx.x; i < npad; i += VISO_IMG_THREADS) {
@@ -80,6 +91,13 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         }
         s_x[0] = x0; s_x[1] = scale;
         I.xinfo[0] = x0; I.xinfo[1] = scale;
+        float ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
+        for (int w = 0; w < VISO_IMG_THREADS / 64; ++w) { ymn = fminf(ymn, s_y[0][w]); ymx = fmaxf(ymx, s_y[1][w]); }
+        if (!(ymn <= ymx)) { ymn = 0.f; ymx = 0.f; }   // no finite y at all
+        I.xinfo[2] = ymn; I.xinfo[3] = ymx;
+        int nvx = n;   // keypoints with a non-NaN x (NaNs sort last)
+        while (nvx > 0 && (uint32_t)(keys[nvx - 1] >> 32) == 0xffffffffu) --nvx;
+        I.xinfo[4] = (float)nvx;
     }
     __syncthreads();
     const float x0 = s_x[0], scale = s_x[1];
@@ -97,6 +115,31 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
             if ((int)keys[mid] >= b) hi = mid; else lo = mid + 1;
         }
         I.bstart[b] = (b == VISO_NB) ? n : lo;
+    }
+    // y order inside every block of 64 sorted positions (the matcher kernels score rounds of four y-adjacent queries
+    // of such a block: their candidate sets overlap by ~2/3).  Any total order is valid; (y, position) is used.
+    __syncthreads();
+    uint32_t* ykey = reinterpret_cast<uint32_t*>(keys);
+    const int n64 = (n + 63) & ~63;
+    for (int j = threadIdx.x; j < n64; j += VISO_IMG_THREADS) {
+        uint32_t k = 0xffffffffu;
+        if (j < n) {
+            const uint32_t yb = __float_as_uint(I.skp[j].y);
+            k = yb ^ ((yb >> 31) ? 0xffffffffu : 0x80000000u);
+            if (k == 0xffffffffu) k = 0xfffffffeu;   // keep "past n" strictly last
+        }
+        ykey[j] = k;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n64; j += VISO_IMG_THREADS) {
+        const int base = j & ~63, me = j & 63;
+        const uint32_t key = ykey[j];
+        int rank = 0;
+        for (int m = 0; m < 64; ++m) {
+            const uint32_t km = ykey[base + m];
+            rank += (km < key || (km == key && m < me)) ? 1 : 0;
+        }
+        I.qord[base + rank] = (uint8_t)me;
     }
 }
 
@@ -752,10 +795,10 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 }
 
 // Which kernel takes the temporal problems of the u16 path (viso_ctx_set_matcher, per context):
-//   4 = match_strip_kernel  (window rows resident in LDS, match_strip.hip)          <- default
-//   3 = match_union_kernel  (rows gathered from L2, one load scored against four queries, match_union.hip)
-//   2 = match_batch_kernel<0> (rows gathered from L2, one pair per 8-lane group, match_batch.hip; built only
-//       with -DVISO_DEBUG_VARIANTS)
+//   3 = match_union_kernel  (rows gathered from L2, one load scored against four queries, match_union.hip)   <- default
+//   4 = match_strip_kernel  (window rows resident in LDS, tools/experiments/match_strip.hip: 0.60 ms against 0.44 ms)
+//   2 = match_batch_kernel<0> (rows gathered from L2, one pair per 8-lane group, match_batch.hip: 0.63 ms)
+// 2 and 4 exist in -DVISO_DEBUG_VARIANTS builds only (make DEBUG_VARIANTS=1).
 // The stereo problems always take match_batch_kernel<1>.  Same results from all of them (parity tests run each).
 const char* matcher_kernel_name(int variant) {
     return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : "match_strip_kernel";

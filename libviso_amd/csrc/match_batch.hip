@@ -476,10 +476,13 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         HIP_TRY(hipGetLastError());
     } else
 #endif
+#ifdef VISO_DEBUG_VARIANTS
     if (variant == 4) {
         const int r = launch_match_strip_temporal(s, at, cap_max);
         if (r < 0) return r;
-    } else {
+    } else
+#endif
+    {
         const int r = launch_match_union_temporal(s, at, bt);
         if (r < 0) return r;
     }

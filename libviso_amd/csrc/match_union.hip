@@ -29,6 +29,7 @@
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
 #define MU_KPCAP 512       // window keypoints staged in LDS
+#define MU_NBY 64          // y buckets of the staged window
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t mu_dpp(uint32_t v) {
@@ -43,35 +44,38 @@ __device__ __forceinline__ uint32_t mu_l1_bits(float qx, float qy, float2 t) {
     return __float_as_uint(d);
 }
 
-// running order statistics of one query's SADs: d1 = min, d2 = second smallest counting multiplicity,
-// w = window position of the (first seen) minimum, tie = the minimum was seen more than once
-struct MuTrack { uint32_t d1, d2, w, tie; };
+// Running order statistics of one query's SADs as two packed keys, key = SAD << 9 | position in the round's union
+// list (< 512; SAD < 2^23 for int16-valued descriptors: 121 * 65535): m1 = smallest key, m2 = second smallest
+// (0xffffffff = none).  A query sees every list position at most once, so keys are distinct and
+//   min SAD = m1 >> 9,  second smallest SAD counting multiplicity = m2 >> 9,  exact tie of the minimum <=> equal SAD fields.
+struct MuTrack { uint32_t m1, m2; };
 
-__device__ __forceinline__ void mu_update(MuTrack& t, uint32_t s, uint32_t w) {
-    const bool lt = s < t.d1, eq = s == t.d1;
-    const uint32_t m2 = min(t.d2, s);
-    t.d2 = (s <= t.d1) ? t.d1 : m2;
-    t.w = lt ? w : t.w;
-    t.tie = lt ? 0u : (eq ? 1u : t.tie);
-    t.d1 = min(t.d1, s);
+__device__ __forceinline__ void mu_update(MuTrack& t, uint32_t key) {
+    uint32_t med;   // m1 <= m2: the median of (m1, m2, key) is the new second smallest
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(t.m1), "v"(t.m2), "v"(key));
+    t.m2 = med;
+    t.m1 = min(t.m1, key);
 }
 
 __device__ __forceinline__ void mu_merge(MuTrack& a, const MuTrack& b) {
-    const bool lt = b.d1 < a.d1, eq = b.d1 == a.d1;
-    // second smallest of the union: the smaller minimum's d2 against the larger minimum
-    const uint32_t d2 = eq ? a.d1 : (lt ? min(b.d2, a.d1) : min(a.d2, b.d1));
-    a.tie = eq ? 1u : (lt ? b.tie : a.tie);
-    a.w = lt ? b.w : a.w;
-    a.d1 = min(a.d1, b.d1);
-    a.d2 = d2;
+    const uint32_t hi = max(a.m1, b.m1);
+    a.m2 = min(hi, min(a.m2, b.m2));
+    a.m1 = min(a.m1, b.m1);
+}
+
+__device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {   // monotone in y
+    if (y != y) return MU_NBY - 1;
+    const float f = floorf((y - y0) * scale);
+    return f <= 0.f ? 0 : (f >= (float)(MU_NBY - 1) ? MU_NBY - 1 : (int)f);
 }
 
 __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][64];
-    __shared__ float2 s_kp[MU_KPCAP];
+    __shared__ float2 s_ykp[MU_KPCAP];       // staged window keypoints in y-bucket order
+    __shared__ uint16_t s_ypos[MU_KPCAP];    // their window positions
+    __shared__ int s_ys[MU_NBY + 1];         // bucket counts, then bucket starts
     __shared__ int s_idx[MU_KPCAP];
-    __shared__ int s_qord[MU_QPB];
     __shared__ float s_xr[2];
     int prob, qblk;
     {
@@ -91,27 +95,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     const MatchParamsDev& mp = a.mp[P.pidx];
     if (mp.epi != 0) return;   // stereo problems: match_batch_kernel<1>
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // ---- tile: x range (window) and y ranks (round composition) of its queries
+    // ---- tile: x range (window) of its queries; their y order (round composition) comes from sort_kp_kernel (ImageView::qord)
     if (wave == 0) {
         const bool live = q0 + lane < q1;
-        const float2 qv = live ? P.q.skp[q0 + lane] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
-        float mn = qv.x, mx = qv.x;
+        const float qx = live ? P.q.skp[q0 + lane].x : __builtin_nanf("");
+        float mn = qx, mx = qx;
 #pragma unroll
         for (int m = 1; m < VISO_WAVE; m <<= 1) {
             mn = fminf(mn, __shfl_xor(mn, m));
             mx = fmaxf(mx, __shfl_xor(mx, m));
         }
         if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
-        // rank by (y, lane): any total order gives a valid permutation, this one puts neighbours in y together
-        const uint32_t yb = __float_as_uint(qv.y);
-        const uint32_t key = live ? (yb ^ ((yb >> 31) ? 0xffffffffu : 0x80000000u)) : 0xffffffffu;
-        int rank = 0;
-        for (int m = 0; m < VISO_WAVE; ++m) {
-            const uint32_t km = (uint32_t)__builtin_amdgcn_readlane((int)key, m);
-            rank += (km < key || (km == key && m < lane)) ? 1 : 0;
-        }
-        s_qord[rank] = lane;
     }
+    if (threadIdx.x <= MU_NBY) s_ys[threadIdx.x] = 0;
     __syncthreads();
     int lo = 0, W = 0;
     {
@@ -128,14 +124,57 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     W = __builtin_amdgcn_readfirstlane(W);
     const int wcap = min(W, MU_KPCAP);
     const int wpad = (wcap + 127) & ~127;   // NaN padded: the scan needs no bounds test
-    for (int w = threadIdx.x; w < wpad; w += MU_THREADS) {
-        float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
-        if (w < wcap) { t2 = P.t.skp[lo + w]; s_idx[w] = P.t.sidx[lo + w]; }
-        s_kp[w] = t2;
+    // ---- y index of the staged window: bucket sort (histogram with returning LDS atomics, scan, scatter) over the
+    // target image's y range, so that a round only scans the buckets its four diamonds can touch
+    float ty0 = P.t.xinfo[2];
+    float yscale = 0.f;
+    {
+        const float ty1 = P.t.xinfo[3];
+        if (ty1 > ty0) yscale = (float)MU_NBY / (ty1 - ty0);
+        if (!(yscale > 0.f) || !(yscale < 3.0e38f)) yscale = 0.f;
+    }
+    static_assert(MU_KPCAP <= 2 * MU_THREADS, "two window entries per thread");
+    float2 e_kp[2];
+    int e_b[2], e_r[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int w = threadIdx.x + i * MU_THREADS;
+        e_b[i] = 0; e_r[i] = 0;
+        if (w < wcap) {
+            e_kp[i] = P.t.skp[lo + w];
+            s_idx[w] = P.t.sidx[lo + w];
+            e_b[i] = mu_ybucket(e_kp[i].y, ty0, yscale);
+            e_r[i] = atomicAdd(&s_ys[e_b[i]], 1);
+        }
     }
     float2 kp0 = make_float2(0.f, 0.f);
     const bool has0 = n2 > 0;
     if (has0) kp0 = P.t.skp[P.t.rank[0]];
+    __syncthreads();
+    if (wave == 0) {
+        const int h = s_ys[lane];
+        int incl = h;
+#pragma unroll
+        for (int d = 1; d < VISO_WAVE; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        s_ys[lane] = incl - h;
+        if (lane == VISO_WAVE - 1) s_ys[MU_NBY] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int w = threadIdx.x + i * MU_THREADS;
+        if (w < wcap) {
+            const int p = s_ys[e_b[i]] + e_r[i];
+            s_ykp[p] = e_kp[i];
+            s_ypos[p] = (uint16_t)w;
+        } else if (w < wpad) {
+            s_ykp[w] = make_float2(__builtin_nanf(""), __builtin_nanf(""));   // entries [wcap, wpad): never in radius
+            s_ypos[w] = 0;
+        }
+    }
     __syncthreads();
     const float radius = mp.radius;
     const int K = mp.K;
@@ -156,7 +195,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
 #define MU_PREFETCH(R)                                                                                    \
     do {                                                                                                  \
         const int base_ = wave * (MU_QPB / MU_WAVES) + (R) * MU_G;                                        \
-        pli = s_qord[base_ + (lane & (MU_G - 1))];                                                        \
+        pli = (int)P.q.qord[q0 + base_ + (lane & (MU_G - 1))];                                            \
         const int j_ = q0 + pli;                                                                          \
         const int jc_ = min(j_, q1 - 1);                                                                  \
         pq = P.q.skp[jc_];                                                                                \
@@ -198,8 +237,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
         // ---------------- phase 1: one scan, membership masks, union list.  entry = mask << 28 | position << 8
         // (mask bit 3 - k = query k)
         int ucnt = 0;
-        for (int base = 0; base < wpad; base += 2 * VISO_WAVE) {
-            const float2 ta = s_kp[base + lane], tb = s_kp[base + VISO_WAVE + lane];
+        int sc0, sc1;   // y-ordered entries the round has to look at: the buckets its diamonds' y extent touches
+        {
+            const float ymn = fminf(fminf(qk[0].y, qk[1].y), fminf(qk[2].y, qk[3].y));
+            const float ymx = fmaxf(fmaxf(qk[0].y, qk[1].y), fmaxf(qk[2].y, qk[3].y));
+            const float ys = (fabsf(ymn) + fabsf(ymx) + fabsf(radius)) * 1e-6f + 1e-6f;   // covers the rounding of dy in the test
+            sc0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)] & ~(2 * VISO_WAVE - 1);
+            sc1 = s_ys[mu_ybucket(ymx + radius + ys, ty0, yscale) + 1];
+        }
+        for (int base = sc0; base < sc1; base += 2 * VISO_WAVE) {
+            const float2 ta = s_ykp[base + lane], tb = s_ykp[base + VISO_WAVE + lane];
+            const uint32_t pa = s_ypos[base + lane], pb = s_ypos[base + VISO_WAVE + lane];
             uint32_t ma = 0, mb = 0;
 #pragma unroll
             for (int k = 0; k < MU_G; ++k) {
@@ -211,9 +259,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
             }
             const unsigned long long ua = __ballot(ma != 0), ub = __ballot(mb != 0);
             const int ca = __popcll(ua);
-            const uint32_t ea = (uint32_t)(base + lane) << 8;
-            if (ma) ul[min(ucnt + mbcnt(ua), MU_UCAP - 1)] = (ma << 28) | ea;
-            if (mb) ul[min(ucnt + ca + mbcnt(ub), MU_UCAP - 1)] = (mb << 28) | (ea + (VISO_WAVE << 8));
+            if (ma) ul[min(ucnt + mbcnt(ua), MU_UCAP - 1)] = (ma << 28) | (pa << 8);
+            if (mb) ul[min(ucnt + ca + mbcnt(ub), MU_UCAP - 1)] = (mb << 28) | (pb << 8);
             ucnt += ca + __popcll(ub);
         }
         for (int base = wcap; base < W; base += VISO_WAVE) {   // windows wider than MU_KPCAP (dense data only)
@@ -244,10 +291,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
         for (int k = 0; k < MU_G; ++k) s_qrow[wave][k][lane] = qw[k];
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2: rolling pipeline over the union list
-        const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
-        const int msh = 31 - (lane & 3);   // membership bit of the query this lane tracks (lanes sub and sub + 4 both track query sub & 3)
+        // which of the four queries the lane tracks after the transposing reduction: lanes 4..7 of a group mirror 3..0
+        const bool sel0 = ((lane ^ (lane >> 2)) & 1) != 0, sel1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+        const int msh = 31 - ((sel0 ? 1 : 0) + (sel1 ? 2 : 0));   // its membership bit in a list entry
         MuTrack tr;
-        tr.d1 = 0xffffffffu; tr.d2 = 0xffffffffu; tr.w = 0; tr.tie = 0;
+        tr.m1 = 0xffffffffu; tr.m2 = 0xffffffffu;
         {
             const int npass = (nu + 7) >> 3;
             u32x4 r0[MU_NP], r1[MU_NP];
@@ -273,18 +321,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
                 s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, qb_.w, s_);                                      \
                 s_;                                                                                        \
             })
-            // four partial SADs per lane, reduced over the 8 lanes of the group together (their DPP steps
-            // interleave), then lane sub = k takes query k's total and its membership bit and updates its tracker
-#define MU_REDUCE(SLOT)                                                                                   \
+            // four partial SADs per lane -> every lane of the 8-lane group holds the total of "its" query: a
+            // transposing reduction (each step halves the number of values a lane carries: 6 selects + 4 DPP adds
+            // instead of 12 DPP adds + 3 selects), then two instructions update the packed-key tracker
+#define MU_REDUCE(SLOT, U)                                                                                \
             do {                                                                                           \
-                uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
-                s0_ += mu_dpp<0xB1>(s0_); s1_ += mu_dpp<0xB1>(s1_); s2_ += mu_dpp<0xB1>(s2_); s3_ += mu_dpp<0xB1>(s3_); \
-                s0_ += mu_dpp<0x4E>(s0_); s1_ += mu_dpp<0x4E>(s1_); s2_ += mu_dpp<0x4E>(s2_); s3_ += mu_dpp<0x4E>(s3_); \
-                s0_ += mu_dpp<0x141>(s0_); s1_ += mu_dpp<0x141>(s1_); s2_ += mu_dpp<0x141>(s2_); s3_ += mu_dpp<0x141>(s3_); \
-                const uint32_t lo_ = lb0 ? s1_ : s0_, hi_ = lb0 ? s3_ : s2_;                               \
-                const uint32_t mine_ = lb1 ? hi_ : lo_;   /* lanes sub and sub + 4 both track query sub & 3 */ \
+                const uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
+                uint32_t a01_ = sel0 ? s1_ : s0_, a23_ = sel0 ? s3_ : s2_;                                 \
+                const uint32_t b01_ = sel0 ? s0_ : s1_, b23_ = sel0 ? s2_ : s3_;                           \
+                a01_ += mu_dpp<0xB1>(b01_);   /* quad_perm 1,0,3,2 */                                      \
+                a23_ += mu_dpp<0xB1>(b23_);                                                                \
+                uint32_t m_ = sel1 ? a23_ : a01_;                                                          \
+                const uint32_t o_ = sel1 ? a01_ : a23_;                                                    \
+                m_ += mu_dpp<0x4E>(o_);       /* quad_perm 2,3,0,1 */                                      \
+                m_ += mu_dpp<0x141>(m_);      /* row_half_mirror: lanes i and 7 - i track the same query */ \
                 const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
-                mu_update(tr, member_ ? mine_ : 0xffffffffu, (ent[SLOT] >> 8) & 0xfffffu);                 \
+                mu_update(tr, member_ ? ((m_ << 9) | (uint32_t)(U)) : 0xffffffffu);                        \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -294,27 +346,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
             for (; t + MU_NP < npass; t += MU_NP) {   // steady state: no branch between reduce and refill (the hardware
 #pragma unroll                                        // counts outstanding loads; a branch would make the compiler drain them)
                 for (int p = 0; p < MU_NP; ++p) {
-                    MU_REDUCE(p);
+                    MU_REDUCE(p, (t + p) * 8 + g8);
+                    // keep the refill of this slot HERE: left alone the scheduler sinks all refills to the end of the
+                    // loop body, where the next iteration waits for them at once (no load is in flight during a reduce)
+                    __builtin_amdgcn_sched_barrier(0);
                     MU_ISSUE(p, t + p + MU_NP);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (npass > 0) {
 #pragma unroll
-                for (int p = 0; p < MU_NP; ++p) MU_REDUCE(p);
+                for (int p = 0; p < MU_NP; ++p) MU_REDUCE(p, (t + p) * 8 + g8);
             }
 #undef MU_REDUCE
 #undef MU_SAD
 #undef MU_ISSUE
         }
-        // ---------------- phase 3: merge the 8 lane groups (lanes with equal sub), lane k of group 0 ends up with
-        // query k; fetch the original target index, ratio test, store
+        // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
+        // query), lane k of group 0 ends up with query k; fetch the original target index, ratio test, store
 #pragma unroll
         for (int m = 8; m < VISO_WAVE; m <<= 1) {
             MuTrack o;
-            o.d1 = (uint32_t)__shfl_xor((int)tr.d1, m);
-            o.d2 = (uint32_t)__shfl_xor((int)tr.d2, m);
-            o.w = (uint32_t)__shfl_xor((int)tr.w, m);
-            o.tie = (uint32_t)__shfl_xor((int)tr.tie, m);
+            o.m1 = (uint32_t)__shfl_xor((int)tr.m1, m);
+            o.m2 = (uint32_t)__shfl_xor((int)tr.m2, m);
             mu_merge(tr, o);
         }
         // lane k (< 4) now holds query k
@@ -325,21 +379,24 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
             for (int k = 0; k < MU_G; ++k)
                 if (lane == k) { my_orig = orig[k]; my_j = jq[k]; my_cnt = cnt[k]; my_flag = (flags >> k) & 1; }
             if (lane < MU_G && my_orig >= 0) {
-                const bool none = tr.d1 == 0xffffffffu;
-                if (my_flag || (!none && tr.tie)) {
+                const bool none = tr.m1 == 0xffffffffu;
+                const uint32_t d1 = tr.m1 >> 9;
+                const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
+                if (my_flag || tie) {
                     // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
                     P.ovf[atomicAdd(P.ovf_cnt, 1)] = my_j;
                 } else {
                     bool accept = !none;
                     int idx = -1;
                     if (accept) {
-                        if ((int)tr.w < wcap) idx = s_idx[tr.w]; else idx = P.t.sidx[lo + (int)tr.w];
+                        const int w = (int)((ul[tr.m1 & 511u] >> 8) & 0xfffffu);   // window position of the winner
+                        if (w < wcap) idx = s_idx[w]; else idx = P.t.sidx[lo + w];
                         if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
-                            const double bd2 = tr.d2 == 0xffffffffu ? 1.7976931348623157e308 : (double)tr.d2;
-                            accept = (double)tr.d1 < bd2 * mp.ratio;
+                            const double bd2 = tr.m2 == 0xffffffffu ? 1.7976931348623157e308 : (double)(tr.m2 >> 9);
+                            accept = (double)d1 < bd2 * mp.ratio;
                         }
                     }
-                    P.res[my_orig] = make_int2(accept ? idx : -1, (int)tr.d1);
+                    P.res[my_orig] = make_int2(accept ? idx : -1, none ? -1 : (int)d1);
                     scored += (unsigned long long)my_cnt;
                 }
             }
