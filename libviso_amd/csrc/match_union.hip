@@ -24,7 +24,7 @@
 #define MU_THREADS 256
 #define MU_WAVES 4
 #define MU_QPB 64          // queries per tile
-#define MU_G 4             // queries per round
+#define MU_G 8             // queries per round
 #define MU_UCAP 256        // union list entries per round
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
@@ -185,10 +185,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
     uint32_t* ul = s_ul[wave];
     const int g8 = lane >> 3, sub = lane & 7;
+    const int half = lane >> 5;          // phase 1: lanes 0..31 test queries 0..3 of the round, lanes 32..63 queries 4..7
     unsigned long long scored = 0;
-    constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 4 rounds per wave
+    constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 2 rounds of 8 queries per wave
+    // which of the round's eight queries the lane tracks after the transposing reduction (phase 2): the partners of
+    // the three exchange steps (lane ^ 1, lane ^ 2, 7 - lane within the 8-lane group) differ in exactly one of these
+    const bool sel0 = ((lane ^ (lane >> 2)) & 1) != 0, sel1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0, sel2 = ((lane >> 2) & 1) != 0;
+    const int myq = (sel0 ? 1 : 0) + (sel1 ? 2 : 0) + (sel2 ? 4 : 0);
+    const int msh = 31 - myq;   // membership bit of query myq in a list entry (bit 7 - k of the mask byte)
 
-    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 3) of the round
+    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 7) of the round
     int pli;
     float2 pq;
     int po;
@@ -204,96 +210,112 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
     MU_PREFETCH(0);
 
     for (int r = 0; r < ROUNDS; ++r) {
-        // ---------------- round setup: scalars of the four queries, their rows into registers
-        float2 qk[MU_G];
-        int orig[MU_G], jq[MU_G], cnt[MU_G];
-        uint32_t thr[MU_G];
-        bool any_live = false;
-#pragma unroll
-        for (int k = 0; k < MU_G; ++k) {
-            qk[k].x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), k));
-            qk[k].y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), k));
-            orig[k] = __builtin_amdgcn_readlane(po, k);
-            jq[k] = q0 + __builtin_amdgcn_readlane(pli, k);
-            cnt[k] = 0;
-            // d = |dx| + |dy| is +0, positive or NaN: its bit pattern orders like the value and NaNs are above +inf,
-            // so (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in radius: Q1,
-            // src/viso.cpp:693) or bits(radius) + 1.  Dead slots (past the tile) get 0: nothing passes.
-            uint32_t t = __float_as_uint(radius) + 1u;
-            if (has0) {
-                const float d0 = l1_kp(qk[k].x, qk[k].y, kp0);
-                if (d0 <= radius) t = __float_as_uint(d0);
-            }
-            thr[k] = orig[k] >= 0 ? t : 0u;
-            any_live = any_live || orig[k] >= 0;
+        // ---------------- round setup.  Lane l holds query (l & 7); phase 1 wants, per lane, the four queries of its
+        // half: query 4 * half + i sits in lane 36 * half + i
+        const int my_orig = po, my_j = q0 + pli;   // lanes 0..7: the round's queries, for phase 3
+        if (!__any(po >= 0)) { if (r + 1 < ROUNDS) MU_PREFETCH(r + 1); continue; }   // wave uniform
+        // d = |dx| + |dy| is +0, positive or NaN: its bit pattern orders like the value and NaNs are above +inf,
+        // so (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in radius: Q1,
+        // src/viso.cpp:693) or bits(radius) + 1.  Dead slots (past the tile) get 0: nothing passes.
+        uint32_t tq = __float_as_uint(radius) + 1u;
+        if (has0) {
+            const float d0 = l1_kp(pq.x, pq.y, kp0);
+            if (d0 <= radius) tq = __float_as_uint(d0);
         }
-        if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
-        if (!any_live) continue;   // wave uniform
-        // query rows: one word per lane and row from global memory (the loads land during the scan), then LDS
+        if (po < 0) tq = 0u;
+        float qx[4], qy[4];
+        uint32_t thr[4];
+        float ymn = pq.y, ymx = pq.y;   // y extent of the round's queries (all lanes hold one of them)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xa_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), i));
+            const float xb_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), 4 + i));
+            const float ya_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), i));
+            const float yb_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), 4 + i));
+            const uint32_t ta_ = (uint32_t)__builtin_amdgcn_readlane((int)tq, i);
+            const uint32_t tb_ = (uint32_t)__builtin_amdgcn_readlane((int)tq, 4 + i);
+            qx[i] = half ? xb_ : xa_;
+            qy[i] = half ? yb_ : ya_;
+            thr[i] = half ? tb_ : ta_;
+            ymn = fminf(ymn, fminf(ya_, yb_));
+            ymx = fmaxf(ymx, fmaxf(ya_, yb_));
+        }
+        // the eight query rows: one word per lane and row from global memory (the loads land during the scan), then LDS
         uint32_t qw[MU_G];
 #pragma unroll
-        for (int k = 0; k < MU_G; ++k)
-            qw[k] = ((const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(P.q.rows))[(size_t)min(jq[k], q1 - 1) * (VISO_ROW / 2) + lane];
-        // ---------------- phase 1: one scan, membership masks, union list.  entry = mask << 28 | position << 8
-        // (mask bit 3 - k = query k)
+        for (int k = 0; k < MU_G; ++k) {
+            const int jk = q0 + __builtin_amdgcn_readlane(pli, k);
+            qw[k] = ((const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(P.q.rows))[(size_t)min(jk, q1 - 1) * (VISO_ROW / 2) + lane];
+        }
+        if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
+        // ---------------- phase 1: one scan over the y buckets the round's diamonds touch, 32 targets per step: both
+        // halves read the same 32 entries, each tests its four queries -> 8-bit membership mask (bit 7 - k = query k),
+        // targets with a non-zero mask go to the union list.  entry = mask << 24 | window position << 8
         int ucnt = 0;
-        int sc0, sc1;   // y-ordered entries the round has to look at: the buckets its diamonds' y extent touches
         {
-            const float ymn = fminf(fminf(qk[0].y, qk[1].y), fminf(qk[2].y, qk[3].y));
-            const float ymx = fmaxf(fmaxf(qk[0].y, qk[1].y), fmaxf(qk[2].y, qk[3].y));
             const float ys = (fabsf(ymn) + fabsf(ymx) + fabsf(radius)) * 1e-6f + 1e-6f;   // covers the rounding of dy in the test
-            sc0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)] & ~(2 * VISO_WAVE - 1);
-            sc1 = s_ys[mu_ybucket(ymx + radius + ys, ty0, yscale) + 1];
-        }
-        for (int base = sc0; base < sc1; base += 2 * VISO_WAVE) {
-            const float2 ta = s_ykp[base + lane], tb = s_ykp[base + VISO_WAVE + lane];
-            const uint32_t pa = s_ypos[base + lane], pb = s_ypos[base + VISO_WAVE + lane];
-            uint32_t ma = 0, mb = 0;
+            int sc0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)] & ~63;   // steps of 64 stay inside the NaN padded array
+            int sc1 = s_ys[mu_ybucket(ymx + radius + ys, ty0, yscale) + 1];
+            sc0 = __builtin_amdgcn_readfirstlane(sc0);
+            sc1 = __builtin_amdgcn_readfirstlane(sc1);
+            const int l31 = lane & 31;
+            for (int base = sc0; base < sc1; base += 64) {
+                // two steps of 32 targets in flight
+                const float2 ta = s_ykp[base + l31], tb = s_ykp[base + 32 + l31];
+                const uint32_t pa = s_ypos[base + l31], pb = s_ypos[base + 32 + l31];
+                uint32_t ma = 0, mb = 0;
 #pragma unroll
-            for (int k = 0; k < MU_G; ++k) {
-                const bool ina = mu_l1_bits(qk[k].x, qk[k].y, ta) < thr[k];
-                const bool inb = mu_l1_bits(qk[k].x, qk[k].y, tb) < thr[k];
-                cnt[k] += __popcll(__ballot(ina)) + __popcll(__ballot(inb));
-                ma = ma + ma + (ina ? 1u : 0u);
-                mb = mb + mb + (inb ? 1u : 0u);
+                for (int i = 0; i < 4; ++i) {
+                    const bool ina = mu_l1_bits(qx[i], qy[i], ta) < thr[i];
+                    const bool inb = mu_l1_bits(qx[i], qy[i], tb) < thr[i];
+                    ma = ma + ma + (ina ? 1u : 0u);
+                    mb = mb + mb + (inb ? 1u : 0u);
+                }
+                // lanes 0..31: own nibble = queries 0..3 (high nibble of the byte), partner's = queries 4..7
+                const uint32_t oa = (uint32_t)__shfl_xor((int)ma, 32), ob = (uint32_t)__shfl_xor((int)mb, 32);
+                const uint32_t m8a = half ? 0u : ((ma << 4) | oa), m8b = half ? 0u : ((mb << 4) | ob);
+                const uint32_t ua = (uint32_t)__ballot(m8a != 0), ub = (uint32_t)__ballot(m8b != 0);
+                const int ca = __popc(ua);
+                if (m8a) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(ua, 0u), MU_UCAP - 1)] = (m8a << 24) | (pa << 8);
+                if (m8b) ul[min(ucnt + ca + (int)__builtin_amdgcn_mbcnt_lo(ub, 0u), MU_UCAP - 1)] = (m8b << 24) | (pb << 8);
+                ucnt += ca + __popc(ub);
             }
-            const unsigned long long ua = __ballot(ma != 0), ub = __ballot(mb != 0);
-            const int ca = __popcll(ua);
-            if (ma) ul[min(ucnt + mbcnt(ua), MU_UCAP - 1)] = (ma << 28) | (pa << 8);
-            if (mb) ul[min(ucnt + ca + mbcnt(ub), MU_UCAP - 1)] = (mb << 28) | (pb << 8);
-            ucnt += ca + __popcll(ub);
-        }
-        for (int base = wcap; base < W; base += VISO_WAVE) {   // windows wider than MU_KPCAP (dense data only)
-            const int w = base + lane;
-            float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
-            if (w < W) t2 = P.t.skp[lo + w];
-            uint32_t m = 0;
+            for (int base = wcap; base < W; base += 32) {   // windows wider than MU_KPCAP (dense data only)
+                const int w = base + l31;
+                float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+                if (w < W) t2 = P.t.skp[lo + w];
+                uint32_t m = 0;
 #pragma unroll
-            for (int k = 0; k < MU_G; ++k) {
-                const bool in = mu_l1_bits(qk[k].x, qk[k].y, t2) < thr[k];
-                cnt[k] += __popcll(__ballot(in));
-                m = m + m + (in ? 1u : 0u);
+                for (int i = 0; i < 4; ++i) m = m + m + ((mu_l1_bits(qx[i], qy[i], t2) < thr[i]) ? 1u : 0u);
+                const uint32_t o = (uint32_t)__shfl_xor((int)m, 32);
+                const uint32_t m8 = half ? 0u : ((m << 4) | o);
+                const uint32_t u = (uint32_t)__ballot(m8 != 0);
+                if (m8) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(u, 0u), MU_UCAP - 1)] = (m8 << 24) | ((uint32_t)w << 8);
+                ucnt += __popc(u);
             }
-            const unsigned long long u = __ballot(m != 0);
-            if (m) ul[min(ucnt + mbcnt(u), MU_UCAP - 1)] = (m << 28) | ((uint32_t)w << 8);
-            ucnt += __popcll(u);
         }
-        int flags = 0;   // bit k: query k is left to the overflow kernel
-#pragma unroll
-        for (int k = 0; k < MU_G; ++k)
-            if (orig[k] >= 0 && (cnt[k] > K || ucnt > MU_UCAP)) flags |= 1 << k;
-        const int nu = ucnt > MU_UCAP ? 0 : ucnt;
-        // padding behind the list: copies of the last entry with an empty mask (scored, never counted)
+        const bool list_ovf = ucnt > MU_UCAP;
+        const int nu = list_ovf ? 0 : ucnt;
         __builtin_amdgcn_wave_barrier();
-        if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] & 0x0fffffffu;
+        // in-radius candidates per query (K cap): bit counts over the list; lane k (< 8) keeps query k's
+        int my_cnt = 0;
+        for (int b = 0; b < nu; b += VISO_WAVE) {
+            const uint32_t e = (b + lane) < nu ? ul[b + lane] : 0u;
+#pragma unroll
+            for (int k = 0; k < MU_G; ++k) {
+                const int c = __popcll(__ballot(((e >> (31 - k)) & 1u) != 0));
+                if (lane == k) my_cnt += c;
+            }
+        }
+        // padding behind the list: copies of the last entry with an empty mask (scored, never counted)
+        if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] & 0x00ffffffu;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < MU_G; ++k) s_qrow[wave][k][lane] = qw[k];
         __builtin_amdgcn_wave_barrier();
-        // ---------------- phase 2: rolling pipeline over the union list
-        // which of the four queries the lane tracks after the transposing reduction: lanes 4..7 of a group mirror 3..0
-        const bool sel0 = ((lane ^ (lane >> 2)) & 1) != 0, sel1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
-        const int msh = 31 - ((sel0 ? 1 : 0) + (sel1 ? 2 : 0));   // its membership bit in a list entry
+        // ---------------- phase 2: rolling pipeline over the union list: load a row once, SAD against the eight query
+        // rows (staged per wave in LDS), transposing reduction (8 partial sums per lane -> every lane of the 8-lane
+        // group holds the total of ITS query: 14 selects + 7 DPP adds), packed-key tracker (2 instructions)
         MuTrack tr;
         tr.m1 = 0xffffffffu; tr.m2 = 0xffffffffu;
         {
@@ -303,7 +325,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
 #define MU_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
                 ent[SLOT] = ul[(T) * 8 + g8];                                                              \
-                const grow_t row_ = (grow_t)(wrows + ((ent[SLOT] & 0x0fffffffu) | (uint32_t)(sub << 4)));  \
+                const grow_t row_ = (grow_t)(wrows + ((ent[SLOT] & 0x00ffffffu) | (uint32_t)(sub << 4)));  \
                 r0[SLOT] = row_[0];                                                                        \
                 r1[SLOT] = row_[8];                                                                        \
             } while (0)
@@ -321,20 +343,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
                 s_ = __builtin_amdgcn_sad_u16(r1[SLOT].w, qb_.w, s_);                                      \
                 s_;                                                                                        \
             })
-            // four partial SADs per lane -> every lane of the 8-lane group holds the total of "its" query: a
-            // transposing reduction (each step halves the number of values a lane carries: 6 selects + 4 DPP adds
-            // instead of 12 DPP adds + 3 selects), then two instructions update the packed-key tracker
+#define MU_X1(A, B) ({ uint32_t k_ = sel0 ? (B) : (A); const uint32_t g_ = sel0 ? (A) : (B); k_ += mu_dpp<0xB1>(g_); k_; })   /* lane ^ 1 */
+#define MU_X2(A, B) ({ uint32_t k_ = sel1 ? (B) : (A); const uint32_t g_ = sel1 ? (A) : (B); k_ += mu_dpp<0x4E>(g_); k_; })   /* lane ^ 2 */
+#define MU_X4(A, B) ({ uint32_t k_ = sel2 ? (B) : (A); const uint32_t g_ = sel2 ? (A) : (B); k_ += mu_dpp<0x141>(g_); k_; })  /* 7 - lane */
 #define MU_REDUCE(SLOT, U)                                                                                \
             do {                                                                                           \
                 const uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
-                uint32_t a01_ = sel0 ? s1_ : s0_, a23_ = sel0 ? s3_ : s2_;                                 \
-                const uint32_t b01_ = sel0 ? s0_ : s1_, b23_ = sel0 ? s2_ : s3_;                           \
-                a01_ += mu_dpp<0xB1>(b01_);   /* quad_perm 1,0,3,2 */                                      \
-                a23_ += mu_dpp<0xB1>(b23_);                                                                \
-                uint32_t m_ = sel1 ? a23_ : a01_;                                                          \
-                const uint32_t o_ = sel1 ? a01_ : a23_;                                                    \
-                m_ += mu_dpp<0x4E>(o_);       /* quad_perm 2,3,0,1 */                                      \
-                m_ += mu_dpp<0x141>(m_);      /* row_half_mirror: lanes i and 7 - i track the same query */ \
+                const uint32_t s4_ = MU_SAD(4, SLOT), s5_ = MU_SAD(5, SLOT), s6_ = MU_SAD(6, SLOT), s7_ = MU_SAD(7, SLOT); \
+                const uint32_t a0_ = MU_X1(s0_, s1_), a1_ = MU_X1(s2_, s3_), a2_ = MU_X1(s4_, s5_), a3_ = MU_X1(s6_, s7_); \
+                const uint32_t c0_ = MU_X2(a0_, a1_), c1_ = MU_X2(a2_, a3_);                               \
+                const uint32_t m_ = MU_X4(c0_, c1_);                                                       \
                 const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
                 mu_update(tr, member_ ? ((m_ << 9) | (uint32_t)(U)) : 0xffffffffu);                        \
             } while (0)
@@ -359,11 +377,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
                 for (int p = 0; p < MU_NP; ++p) MU_REDUCE(p, (t + p) * 8 + g8);
             }
 #undef MU_REDUCE
+#undef MU_X4
+#undef MU_X2
+#undef MU_X1
 #undef MU_SAD
 #undef MU_ISSUE
         }
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
-        // query), lane k of group 0 ends up with query k; fetch the original target index, ratio test, store
+        // query); lane l (< 8) then holds query myq(l): 0 1 2 3 7 6 5 4 -> bring query k to lane k; fetch the original
+        // target index, ratio test, store
 #pragma unroll
         for (int m = 8; m < VISO_WAVE; m <<= 1) {
             MuTrack o;
@@ -371,38 +393,35 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
             o.m2 = (uint32_t)__shfl_xor((int)tr.m2, m);
             mu_merge(tr, o);
         }
-        // lane k (< 4) now holds query k
         {
-            int my_orig = -1, my_j = 0, my_cnt = 0;
-            bool my_flag = false;
-#pragma unroll
-            for (int k = 0; k < MU_G; ++k)
-                if (lane == k) { my_orig = orig[k]; my_j = jq[k]; my_cnt = cnt[k]; my_flag = (flags >> k) & 1; }
-            if (lane < MU_G && my_orig >= 0) {
-                const bool none = tr.m1 == 0xffffffffu;
-                const uint32_t d1 = tr.m1 >> 9;
-                const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
-                if (my_flag || tie) {
-                    // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
-                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = my_j;
-                } else {
-                    bool accept = !none;
-                    int idx = -1;
-                    if (accept) {
-                        const int w = (int)((ul[tr.m1 & 511u] >> 8) & 0xfffffu);   // window position of the winner
-                        if (w < wcap) idx = s_idx[w]; else idx = P.t.sidx[lo + w];
-                        if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
-                            const double bd2 = tr.m2 == 0xffffffffu ? 1.7976931348623157e308 : (double)(tr.m2 >> 9);
-                            accept = (double)d1 < bd2 * mp.ratio;
-                        }
+            const int src = (lane & 7) < 4 ? (lane & 7) : 11 - (lane & 7);
+            tr.m1 = (uint32_t)__shfl((int)tr.m1, src);
+            tr.m2 = (uint32_t)__shfl((int)tr.m2, src);
+        }
+        if (lane < MU_G && my_orig >= 0) {
+            const bool none = tr.m1 == 0xffffffffu;
+            const uint32_t d1 = tr.m1 >> 9;
+            const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
+            if (list_ovf || my_cnt > K || tie) {
+                // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
+                P.ovf[atomicAdd(P.ovf_cnt, 1)] = my_j;
+            } else {
+                bool accept = !none;
+                int idx = -1;
+                if (accept) {
+                    const int w = (int)((ul[tr.m1 & 511u] >> 8) & 0xffffu);   // window position of the winner
+                    if (w < wcap) idx = s_idx[w]; else idx = P.t.sidx[lo + w];
+                    if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
+                        const double bd2 = tr.m2 == 0xffffffffu ? 1.7976931348623157e308 : (double)(tr.m2 >> 9);
+                        accept = (double)d1 < bd2 * mp.ratio;
                     }
-                    P.res[my_orig] = make_int2(accept ? idx : -1, none ? -1 : (int)d1);
-                    scored += (unsigned long long)my_cnt;
                 }
+                P.res[my_orig] = make_int2(accept ? idx : -1, none ? -1 : (int)d1);
+                scored += (unsigned long long)my_cnt;
             }
         }
     }
-    // scored pairs of the tile's queries whose result stands (lanes 0..3 of every wave hold partial sums)
+    // scored pairs of the tile's queries whose result stands (lanes 0..7 of every wave hold partial sums)
 #pragma unroll
     for (int m = 1; m < MU_G; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
