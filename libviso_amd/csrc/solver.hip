@@ -86,29 +86,18 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     }
     int ok = 0;
     for (int it = VISO_GN_SPLIT; it < 100; ++it) {
-        // rotation: one sincos per lane (lanes 0..2 matter), then the same products as make_rot
+        // rotation: one sincos per lane (lanes 0..2 matter), then the table of solver_dev.h
         double sv, cv;
         const int l3 = lane % 3;
         sincos(l3 == 0 ? tr[0] : l3 == 1 ? tr[1] : tr[2], &sv, &cv);
         const double sx = __shfl(sv, 0), cx = __shfl(cv, 0), sy = __shfl(sv, 1), cy = __shfl(cv, 1), sz = __shfl(sv, 2), cz = __shfl(cv, 2);
         RotDev R;
-        R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
-        R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
-        R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
-        R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
-        R.rdrx10 = +cx * sy * cz - sx * sz; R.rdrx11 = -cx * sy * sz - sx * cz; R.rdrx12 = -cx * cy;
-        R.rdrx20 = +sx * sy * cz + cx * sz; R.rdrx21 = -sx * sy * sz + cx * cz; R.rdrx22 = -sx * cy;
-        R.rdry00 = -sy * cz;      R.rdry01 = +sy * sz;      R.rdry02 = +cy;
-        R.rdry10 = +sx * cy * cz; R.rdry11 = -sx * cy * sz; R.rdry12 = +sx * sy;
-        R.rdry20 = -cx * cy * cz; R.rdry21 = +cx * cy * sz; R.rdry22 = -cx * sy;
-        R.rdrz00 = -cy * sz;                R.rdrz01 = -cy * cz;
-        R.rdrz10 = -sx * sy * sz + cx * cz; R.rdrz11 = -sx * sy * cz - cx * sz;
-        R.rdrz20 = +cx * sy * sz + sx * cz; R.rdrz21 = +cx * sy * cz - sx * sz;
+        rot_from_sincos(sx, cx, sy, cy, sz, cz, tr, R);
         // column j of point p (the switch of accumulate_point, evaluated for all three rotation parameters and
         // selected: the selected value is the one the switch would have computed)
         double pred[4], X1c, Y1c, Z1c, X2c;
         predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
-        const double wf = weight * sp.f, iz2 = 1.0 / (Z1c * Z1c);
+        const double wf = weight * sp.f, zz = Z1c * Z1c;   // divisions as the reference has them, src/viso.cpp:1478-1481
         const double y0 = R.rdrx10 * X1p + R.rdrx11 * Y1p + R.rdrx12 * Z1p, z0 = R.rdrx20 * X1p + R.rdrx21 * Y1p + R.rdrx22 * Z1p;
         const double x1 = R.rdry00 * X1p + R.rdry01 * Y1p + R.rdry02 * Z1p, y1 = R.rdry10 * X1p + R.rdry11 * Y1p + R.rdry12 * Z1p,
                      z1 = R.rdry20 * X1p + R.rdry21 * Y1p + R.rdry22 * Z1p;
@@ -117,9 +106,9 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
         const double Y1cd = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : j == 4 ? 1.0 : 0.0;
         const double Z1cd = j == 0 ? z0 : j == 1 ? z1 : j == 2 ? z2 : j == 5 ? 1.0 : 0.0;
         if (lane < 18) {
-            s_J[wv][p][0][j] = wf * (X1cd * Z1c - X1c * Z1cd) * iz2;
-            s_J[wv][p][1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) * iz2;
-            s_J[wv][p][2][j] = wf * (X1cd * Z1c - X2c * Z1cd) * iz2;
+            s_J[wv][p][0][j] = wf * (X1cd * Z1c - X1c * Z1cd) / zz;
+            s_J[wv][p][1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) / zz;
+            s_J[wv][p][2][j] = wf * (X1cd * Z1c - X2c * Z1cd) / zz;
             if (j == 0) {
                 s_res[wv][p][0] = weight * (o0 - pred[0]);
                 s_res[wv][p][1] = weight * (o1 - pred[1]);

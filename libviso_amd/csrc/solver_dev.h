@@ -18,14 +18,11 @@ struct RotDev {
     double tx, ty, tz;
 };
 
-// src/viso.cpp:1405-1424
-__device__ __forceinline__ void make_rot(const double* tr, RotDev& R) {
-    const double rx = tr[0], ry = tr[1], rz = tr[2];
+// The rotation entries and their derivatives from the six sines / cosines (src/viso.cpp:1410-1424) — the ONE place
+// this table exists in the library (make_rot and ransac_coop_kernel both call it).
+__device__ __forceinline__ void rot_from_sincos(double sx, double cx, double sy, double cy, double sz, double cz,
+                                                const double* tr, RotDev& R) {
     R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
-    double sx, cx, sy, cy, sz, cz;   // sincos shares the argument reduction of sin and cos
-    sincos(rx, &sx, &cx);
-    sincos(ry, &sy, &cy);
-    sincos(rz, &sz, &cz);
     R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
     R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
     R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
@@ -37,6 +34,15 @@ __device__ __forceinline__ void make_rot(const double* tr, RotDev& R) {
     R.rdrz00 = -cy * sz;                R.rdrz01 = -cy * cz;
     R.rdrz10 = -sx * sy * sz + cx * cz; R.rdrz11 = -sx * sy * cz - cx * sz;
     R.rdrz20 = +cx * sy * sz + sx * cz; R.rdrz21 = +cx * sy * cz - sx * sz;
+}
+
+// src/viso.cpp:1405-1424
+__device__ __forceinline__ void make_rot(const double* tr, RotDev& R) {
+    double sx, cx, sy, cy, sz, cz;   // sincos shares the argument reduction of sin and cos
+    sincos(tr[0], &sx, &cx);
+    sincos(tr[1], &sy, &cy);
+    sincos(tr[2], &sz, &cz);
+    rot_from_sincos(sx, cx, sy, cy, sz, cz, tr, R);
 }
 
 // prediction of one point (src/viso.cpp:1441-1443, 1452, 1486-1489)
@@ -79,7 +85,7 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
     double pred[4], X1c, Y1c, Z1c, X2c;
     predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
     const double weight = 1.0 / (fabs(obs[0 * ld + pos] - sp.cu) / fabs(sp.cu) + 0.05);
-    const double wf = weight * sp.f, iz2 = 1.0 / (Z1c * Z1c);
+    const double wf = weight * sp.f, z2 = Z1c * Z1c;
     double Jr[3][6];   // rows u_left, v_left, u_right
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -101,12 +107,12 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
         case 4: X1cd = 0; Y1cd = 1; Z1cd = 0; break;
         default: X1cd = 0; Y1cd = 0; Z1cd = 1; break;
         }
-        // reference: weight*f*(..)/(Z1c*Z1c) (src/viso.cpp:1478-1481).  The 18 divisions per point are
-        // replaced by one reciprocal (<= 1 ulp per entry; J only steers the Gauss-Newton step, the
-        // inlier decisions use predict_point's exact divisions).
-        Jr[0][j] = wf * (X1cd * Z1c - X1c * Z1cd) * iz2;
-        Jr[1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) * iz2;
-        Jr[2][j] = wf * (X1cd * Z1c - X2c * Z1cd) * iz2;
+        // weight*f*(..)/(Z1c*Z1c), src/viso.cpp:1478-1481: the reference's operand order, divisions included
+        // (round 1 multiplied by one reciprocal of Z1c^2 instead: <= 1 ulp per entry, but the convergence test of
+        // :1610 is a threshold on values derived from these)
+        Jr[0][j] = wf * (X1cd * Z1c - X1c * Z1cd) / z2;
+        Jr[1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) / z2;
+        Jr[2][j] = wf * (X1cd * Z1c - X2c * Z1cd) / z2;
     }
     double res[4];
     res[0] = weight * (obs[0 * ld + a] - pred[0]);
