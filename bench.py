@@ -41,8 +41,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
 L2_GATHER_PEAK_GBS = 18800.0   # "Indexed rows: gather": rows shared by every workgroup, served by the XCD's L2, chip-wide
 L2_STREAM_PEAK_GBS = 34500.0   # "L2 (per XCD)": aggregate
-N_SIMD = 1024                  # 256 CUs x 4 SIMD-32
-CLK_GHZ = 2.4                  # max clock: a wave64 VALU instruction occupies its SIMD for 2 cycles
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+CLK_GHZ = 2.4                  # max clock
+# Cycles a wave64 VALU instruction occupies its SIMD.  gfx950's SIMDs are 16 lanes wide for non-packed VALU work: the
+# 157.3 TFLOP/s FP32 vector spec is 1024 SIMDs x 16 lanes x 2 (packed v_pk_fma_f32) x 2 flop x 2.4 GHz, and
+# tools/valu_rate.hip (8 waves per SIMD, independent chains; profiles/r02_valu_rate.txt) measures 3.96 cycles per
+# v_fma_f32, 4.58 per v_sad_u16, 4.48 per DPP add, 4.57 per v_med3_u32.  4 is the optimistic figure: the ceiling
+# below is the hardware's, the matcher's instruction mix is slightly slower than it.
+VALU_CYCLES = 4
 L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
 PROFILE_ROUND = "r02"
 
@@ -294,11 +300,11 @@ def main():
     pmc = load_pmc(kname, default_workload)
     ceilings = {}
     # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
-    # elements = one (query, candidate) pair; a SIMD-32 issues one per 2 cycles
-    sad_peak = N_SIMD * CLK_GHZ * 1e9 / 2
+    # elements = one (query, candidate) pair; a SIMD issues one VALU wave-instruction per VALU_CYCLES
+    sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES
     ceilings["sad_valu"] = {"achieved": pairs / t_k, "peak": sad_peak, "unit": "scored pairs/s",
                             "frac": pairs / t_k / sad_peak,
-                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each, 2 cycles per instruction per SIMD-32, 1024 SIMDs at 2.4 GHz"}
+                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each, 4 cycles per wave-instruction per SIMD (16 lanes wide; tools/valu_rate.hip measures 4.58), 1024 SIMDs at 2.4 GHz"}
     if pmc["hbm_bytes"] is not None:
         a = pmc["hbm_bytes"] / t_k / 1e9
         ceilings["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -306,9 +312,10 @@ def main():
     if pmc["sq"] is not None:
         sq = pmc["sq"]
         if "SQ_INSTS_VALU" in sq:
-            v = sq["SQ_INSTS_VALU"] * 2 / (N_SIMD * CLK_GHZ * 1e9) / t_k
+            v = sq["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * CLK_GHZ * 1e9) / t_k
             ceilings["valu_issue"] = {"achieved": sq["SQ_INSTS_VALU"] / t_k, "peak": sad_peak, "unit": "VALU wave-instructions/s",
-                                      "frac": v, "what": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"}
+                                      "frac": v, "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
+                                                         "v_sad_u16 share of the instructions: see profiles/README.md"}
         if "TCP_TCC_READ_REQ_sum" in sq:
             l2b = sq["TCP_TCC_READ_REQ_sum"] * L2_REQ_BYTES
             peak = L2_GATHER_PEAK_GBS if kname == "match_union_kernel" else L2_STREAM_PEAK_GBS

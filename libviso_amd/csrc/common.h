@@ -94,10 +94,11 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
 int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any);
+// bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], const int* bad, int variant);
+                 const MatchParamsDev mp[2], int* bad, int variant);
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                       const MatchParamsDev mp[2], const int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant);
+                       const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 3
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
@@ -148,11 +149,12 @@ int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_it
 struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_kernel (tiles of 64 queries)
     const MatchProblem* probs;
     int n_probs, bpp, gs, gf, gc, _pad;
-    const int* bad;              // "some image of this run is flagged": lets the (normally idle) general kernels leave at once
+    int* bad;                    // [0] "some image of this run is flagged": lets the (normally idle) general kernels leave at once
+                                 // [1] tiles match_stereo_kernel left to match_batch_kernel<1> (0: that kernel leaves at once)
     MatchParamsDev mp[2];
 };
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int variant);
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);

@@ -169,7 +169,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         HIP_TRY(hipMemcpyAsync(df2, d2, sizeof(float) * (size_t)n2 * dlen, hipMemcpyHostToDevice, s));
     }
     // dmisc: [0]=n1 [1]=n2 [2]=bad (both images share one flag) [3]=m_cnt [4..5]=scored (u64) [6]=ovf_cnt [7]=bad_any
-    int hm[8] = {n1, n2, 0, 0, 0, 0, 0, 0};
+    int hm[10] = {n1, n2, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = tiles match_stereo_kernel declines (follows bad_any)
     HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, s));
     auto view = [&](unsigned char* base, size_t n, const float2* kp, const float* f, const int* np, uint16_t* rows) {
         ImageView v{};

@@ -808,7 +808,7 @@ const char* matcher_kernel_name(int variant) {
 // layout 1: the batch order [8 stereo][8 temporal-left][8 temporal-right] per 8 frames.
 // e0/e1 (may be null) bracket the kernel that takes the temporal problems: the dominant kernel.
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       int dlen, const MatchParamsDev mp[2], const int* bad,
+                       int dlen, const MatchParamsDev mp[2], int* bad,
                        hipEvent_t e0, hipEvent_t e1, int layout, int variant) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
@@ -844,7 +844,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
 }
 
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], const int* bad, int variant) {
+                 const MatchParamsDev mp[2], int* bad, int variant) {
     return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant);
 }
 

@@ -59,6 +59,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     __shared__ float2 s_kp[MB_KPCAP];
     __shared__ int s_idx[MB_KPCAP];
     __shared__ float s_xr[4];
+    if (EPI && a.bad[1] == 0) return;   // match_stereo_kernel has done every stereo tile (rectified pairs: always)
     int prob, qblk;
     {
         const int b = blockIdx.x;
@@ -452,7 +453,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], const int* bad, int layout, hipEvent_t e_mid, int variant) {
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant) {
     BatchMatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;

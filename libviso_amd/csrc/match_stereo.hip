@@ -103,7 +103,10 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
     if (!ynan) band = epipolar_band(mp.F, mp.sampson_thresh, xa, xb, ya, yb, radius);
     band = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(band)));
     const bool mine = band <= ST_BAND_MAX;
-    if (lane == 0) P.tile_flag[tile] = mine ? 0 : 1;   // 1: match_batch_kernel<1> walks the full radius for this tile
+    if (lane == 0) {
+        P.tile_flag[tile] = mine ? 0 : 1;   // 1: match_batch_kernel<1> walks the full radius for this tile
+        if (!mine) atomicAdd(&a.bad[1], 1);
+    }
     if (!mine) return;
     int lo = 0, W = 0;
     if (n2 > 0 && xa == xa && radius >= 0.f) {

@@ -3,7 +3,9 @@
 // (src/viso.h:92-93): 8-bit, non-interlaced; grayscale (colour type 0) as is,
 // RGB / RGBA / gray+alpha reduced to gray with OpenCV's integer BGR2GRAY
 // weights.  Own RFC 1950/1951 inflate (stored, fixed and dynamic Huffman
-// blocks); CRCs are not verified.  Host-side file I/O only.
+// blocks); CRCs are not verified.  Host-side file I/O only.  The file is NOT trusted: IHDR must be the first chunk
+// and 13 bytes long, images above PNG_MAX_PIXELS are refused before anything is reserved, inflate stops as soon as
+// the output exceeds the size the header implies, stored blocks check LEN against NLEN.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -12,6 +14,8 @@
 
 namespace viso {
 namespace png_detail {
+
+constexpr size_t PNG_MAX_PIXELS = (size_t)64 << 20;   // 64 Mpx: far above any KITTI frame (1241 x 376)
 
 struct BitReader {
     const uint8_t* p; size_t n, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0; bool fail = false;
@@ -47,7 +51,8 @@ struct Huff {   // canonical Huffman decoding table (counts per length + symbols
     }
 };
 
-inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
+// max_out: the decoder fails once it would produce more than that many bytes (a small IDAT cannot blow up memory)
+inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t max_out) {
     static const uint16_t lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     static const uint16_t lext[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
     static const uint16_t dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
@@ -62,8 +67,10 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
             br.align();
             if (br.pos + 4 > br.n) return false;
             const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8);
+            const uint32_t nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            if ((len ^ nlen) != 0xffffu) return false;
             br.pos += 4;
-            if (br.pos + len > br.n) return false;
+            if (br.pos + len > br.n || out.size() + len > max_out) return false;
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -105,7 +112,7 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0 || br.fail) return false;
-                if (sym < 256) out.push_back((uint8_t)sym);
+                if (sym < 256) { if (out.size() >= max_out) return false; out.push_back((uint8_t)sym); }
                 else if (sym == 256) break;
                 else {
                     const int s = sym - 257;
@@ -114,7 +121,7 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
                     const int ds = dist.decode(br);
                     if (ds < 0 || ds >= 30) return false;
                     const size_t d = dbase[ds] + br.bits(dext[ds]);
-                    if (d > out.size()) return false;
+                    if (d > out.size() || out.size() + (size_t)len > max_out) return false;
                     const size_t from = out.size() - d;
                     for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
                 }
@@ -150,22 +157,28 @@ inline bool read_png_gray(const std::string& file_name, int& rows, int& cols, st
     uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> z;
     size_t o = 8;
+    bool have_ihdr = false;
     while (o + 12 <= f.size()) {
         const uint32_t len = be32(o);
         const std::string type((const char*)&f[o + 4], 4);
-        if (o + 12 + len > f.size()) return false;
-        if (type == "IHDR") { w = be32(o + 8); h = be32(o + 12); depth = f[o + 16]; ctype = f[o + 17]; interlace = f[o + 20]; }
+        if ((size_t)len > f.size() || o + 12 + (size_t)len > f.size()) return false;
+        if (!have_ihdr) {   // the first chunk must be a 13-byte IHDR
+            if (type != "IHDR" || len != 13) return false;
+            w = be32(o + 8); h = be32(o + 12); depth = f[o + 16]; ctype = f[o + 17]; interlace = f[o + 20];
+            have_ihdr = true;
+        }
+        else if (type == "IHDR") return false;
         else if (type == "IDAT") z.insert(z.end(), f.begin() + (long)(o + 8), f.begin() + (long)(o + 8 + len));
         else if (type == "IEND") break;
         o += 12 + len;
     }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!w || !h || depth != 8 || !ch || interlace || w > 65535 || h > 65535) return false;
+    if (!w || !h || depth != 8 || !ch || interlace || w > 65535 || h > 65535 || (size_t)w * h > PNG_MAX_PIXELS) return false;
+    const size_t stride = (size_t)w * ch, raw_size = (size_t)h * (stride + 1);
     std::vector<uint8_t> raw;
-    raw.reserve((size_t)h * (w * ch + 1));
-    if (!inflate(z.data(), z.size(), raw)) return false;
-    const size_t stride = (size_t)w * ch;
-    if (raw.size() < (size_t)h * (stride + 1)) return false;
+    raw.reserve(raw_size);
+    if (!inflate(z.data(), z.size(), raw, raw_size)) return false;
+    if (raw.size() < raw_size) return false;
     std::vector<uint8_t> img((size_t)h * stride), zero(stride, 0);
     for (uint32_t y = 0; y < h; ++y) {
         const uint8_t* s = &raw[(size_t)y * (stride + 1)];

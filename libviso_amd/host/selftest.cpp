@@ -93,9 +93,15 @@ int main(int argc, char** argv) {
         CHECK(std::fgets(line, sizeof line, fp) && std::string(line).substr(0, 37) == "1.000000 0.000000 0.000000 1.234568 0");
         std::fclose(fp);
     }
-    for (int i = 2; i + 1 < argc; i += 2) {   // pairs (png, pgm) that must decode to the same pixels
+    int i = 2;
+    for (; i + 1 < argc && std::string(argv[i]) != "--bad"; i += 2) {   // pairs (png, pgm) that must decode to the same pixels
         Image a = imread_gray(argv[i]), b = imread_gray(argv[i + 1]);
         CHECK(!a.empty() && !b.empty() && a.rows == b.rows && a.cols == b.cols && a.data == b.data);
+    }
+    for (++i; i < argc; ++i) {   // behind "--bad": malformed / hostile files that must be refused (and must not exhaust memory)
+        Image a = imread_gray(argv[i]);
+        if (!a.empty()) std::printf("accepted a malformed file: %s\n", argv[i]);
+        CHECK(a.empty());
     }
     CHECK(imread_gray("/nonexistent/file.png").empty());
     std::printf(fails ? "selftest: %d failure(s)\n" : "selftest ok\n", fails);

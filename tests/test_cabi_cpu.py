@@ -153,5 +153,29 @@ def test_cpp_host_mirror_selftest(tmp_path):
     g = ((r64[..., 0] * 4899 + r64[..., 1] * 9617 + r64[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
     write_pgm(str(tmp_path / "c.pgm"), g)
     args += [str(tmp_path / "c.png"), str(tmp_path / "c.pgm")]
+    # hostile files: every one must be refused, quickly and without a large allocation
+    sig = b"\x89PNG\r\n\x1a\n"
+    good_ihdr = struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 0)
+    z44 = zlib.compress(bytes(4 * 5))
+    bad = {
+        "short_ihdr.png": sig + chunk(b"IHDR", good_ihdr[:5]) + chunk(b"IDAT", z44) + chunk(b"IEND", b""),
+        "ihdr_not_first.png": sig + chunk(b"tEXt", b"x") + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", z44) + chunk(b"IEND", b""),
+        "two_ihdr.png": sig + chunk(b"IHDR", good_ihdr) + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", z44) + chunk(b"IEND", b""),
+        "huge_header.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 65535, 65535, 8, 6, 0, 0, 0)) + chunk(b"IDAT", z44) + chunk(b"IEND", b""),
+        "bomb.png": sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", zlib.compress(bytes(32 << 20), 9)) + chunk(b"IEND", b""),
+        "bad_nlen.png": sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", b"\x78\x01\x01\x14\x00\x00\x00" + bytes(20)) + chunk(b"IEND", b""),
+        "truncated.png": (sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", z44))[:-6],
+        "len_overflow.png": sig + chunk(b"IHDR", good_ihdr) + struct.pack(">I", 0xfffffff0) + b"IDAT" + z44,
+    }
+    args.append("--bad")
+    for name, data in bad.items():
+        with open(str(tmp_path / name), "wb") as fo:
+            fo.write(data)
+        args.append(str(tmp_path / name))
+    # a VALID 4x4 file built the same way, so that the refusals above are not an artefact of the construction
+    with open(str(tmp_path / "ok44.png"), "wb") as fo:
+        fo.write(sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", z44) + chunk(b"IEND", b""))
+    write_pgm(str(tmp_path / "ok44.pgm"), np.zeros((4, 4), np.uint8))
+    args = [str(tmp_path / "ok44.png"), str(tmp_path / "ok44.pgm")] + args
     r = subprocess.run([exe, str(tmp_path)] + args, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
