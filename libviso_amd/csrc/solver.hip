@@ -25,6 +25,9 @@ struct SolverArgs {
 __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= a.n_items * a.iters) return;
+    // a few hundred waves on a serial fp64 chain, usually beside another batch's matcher kernels: win the
+    // instruction-issue arbitration on the SIMD (the chain's latency is what the batch waits for)
+    __builtin_amdgcn_s_setprio(3);
     const int item = gid / a.iters, h = gid % a.iters;
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     const int item = (int)(wave / a.iters), h = (int)(wave % a.iters);
     const SolverItem S = a.items[item];
     if (S.ok_h[h] != 2) return;                      // wave uniform
+    __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
     const int m = *S.m_ptr;
     int sample[3];
     if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
     __shared__ int scratch[8];
     const int item = blockIdx.x;
     if (item >= a.n_items) return;
+    __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
