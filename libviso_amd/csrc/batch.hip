@@ -30,13 +30,20 @@ struct viso_batch {
     double *x, *X, *x_c, *Xp_c;
     TriItem* tri; JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
-    double* tr_h; int *ok_h, *cnt_h;
+    double* tr_h; int *ok_h, *cnt_h, *hq;   // hq: list of undecided hypotheses (launch_ransac)
     double* tr; int *ok, *n_inl, *inl;
     MatchParamsDev mp[2];
     SolverParamsDev sp;
     unsigned long long seed, first_frame;
     bool params_set;
     bool timing;
+    // The RANSAC stage of run k (latency bound: a few hundred waves on serial fp64 chains for ~1 ms) runs on a
+    // stream of its own, so that the matcher of run k+1 — which touches none of its buffers — fills the GPU beside
+    // it: stream (matcher, triangulation, circle join) --ev_join--> solver_stream (RANSAC) --ev_ransac--> the next
+    // run's circle join (which rewrites the RANSAC inputs).
+    hipStream_t solver_stream;
+    hipEvent_t ev_join, ev_ransac;
+    bool ransac_pending;
     // matcher-kernel timing: event pairs of the runs not yet read back (bounded: the oldest pair is folded into
     // the running sum and reused once VISO_EVENT_POOL pairs are outstanding)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -47,6 +54,12 @@ struct viso_batch {
 
 static int enter(viso_batch* b) {   // every entry point that allocates, copies or launches
     HIP_TRY(hipSetDevice(b->ctx->device));
+    return VISO_OK;
+}
+
+static int batch_sync(viso_batch* b) {   // everything the batch has in flight: matcher stream, then its RANSAC stream
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (b->solver_stream) HIP_TRY(hipStreamSynchronize(b->solver_stream));
     return VISO_OK;
 }
 
@@ -63,7 +76,8 @@ static void free_solver_bufs(viso_batch* b) {
     if (b->tr_h) hipFree(b->tr_h);
     if (b->ok_h) hipFree(b->ok_h);
     if (b->cnt_h) hipFree(b->cnt_h);
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
+    if (b->hq) hipFree(b->hq);
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr;
 }
 
 // Frees everything it can; the first HIP error met is recorded (viso_last_error) and returned.  Like
@@ -74,11 +88,20 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     note(hipSetDevice(b->ctx->device));
     note(hipStreamSynchronize(b->ctx->stream));
+    if (b->solver_stream) {
+        note(hipStreamSynchronize(b->solver_stream));
+        viso_ctx* c = b->ctx;
+        for (int i = 0; i < c->n_aux; ++i)
+            if (c->aux[i] == b->solver_stream) { c->aux[i] = c->aux[--c->n_aux]; break; }
+        note(hipStreamDestroy(b->solver_stream));
+    }
+    if (b->ev_join) note(hipEventDestroy(b->ev_join));
+    if (b->ev_ransac) note(hipEventDestroy(b->ev_ransac));
     for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->tile_flag, b->qord};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->tile_flag, b->qord};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -182,9 +205,25 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->n_probs = ((n_frames + 7) / 8) * 24;
     b->params_set = false; b->timing = false;
     b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
+    b->solver_stream = nullptr; b->ev_join = nullptr; b->ev_ransac = nullptr; b->ransac_pending = false;
+    if (ctx->n_aux < (int)(sizeof(ctx->aux) / sizeof(ctx->aux[0]))) {
+        int lo_p = 0, hi_p = 0;   // numerically lowest value = highest priority
+        if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }
+        if (hipStreamCreateWithPriority(&b->solver_stream, hipStreamNonBlocking, hi_p) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_ransac, hipEventDisableTiming) != hipSuccess) {
+            viso_set_error("viso_batch_create: stream / event creation failed");
+            if (b->solver_stream) hipStreamDestroy(b->solver_stream);
+            if (b->ev_join) hipEventDestroy(b->ev_join);
+            if (b->ev_ransac) hipEventDestroy(b->ev_ransac);
+            delete b;
+            return nullptr;
+        }
+        ctx->aux[ctx->n_aux++] = b->solver_stream;
+    }   // else (more than 32 batches on one context): the RANSAC stage stays on the context's stream
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = nullptr;
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr;
     const size_t nf = (size_t)n_frames, c = (size_t)cap;
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
@@ -315,7 +354,7 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
     if ((r0 = enter(b)) < 0) return r0;
     // kernels of a run still in flight read the solver items rewritten below (null-stream copies do not order
     // against the context's non-blocking stream)
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     fill_match_params(&b->mp[0], stereo);
     fill_match_params(&b->mp[1], temporal);
     fill_solver_params(&b->sp, p);
@@ -325,7 +364,8 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         b->iters = p->ransac_iter;
         const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
         int r;
-        if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0) return r;
+        if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0 ||
+            (r = dalloc(&b->hq, k + 1)) < 0) return r;
     }
     int r = build_solver_items(b);
     if (r < 0) return r;
@@ -459,7 +499,7 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
 // Keypoints of frame t, image side (after viso_batch_detect or an upload).
 extern "C" int viso_batch_get_keypoints(viso_batch* b, int t, int side, float* kp, int* n_out) {
     if (!b || t < 0 || t >= b->nf || side < 0 || side > 1 || !n_out) { viso_set_error("viso_batch_get_keypoints: bad argument"); return VISO_ERR_ARG; }
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     int n = 0;
     HIP_TRY(hipMemcpy(&n, b->n + (size_t)t * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
     if (n > 0 && kp) HIP_TRY(hipMemcpy(kp, b->kp + ((size_t)t * 2 + side) * b->cap, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
@@ -471,18 +511,31 @@ static int run_rest(viso_batch* b) {
     int r;
     if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
-    HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, s));            // vector<double> tr(6,0), :1312
+    hipStream_t ss = b->solver_stream ? b->solver_stream : s;
+    // the circle join rewrites what the previous run's RANSAC reads (x_c, Xp_c, mc)
+    if (ss != s && b->ransac_pending) HIP_TRY(hipStreamWaitEvent(s, b->ev_ransac, 0));
     if ((r = launch_collect_triangulate(s, b->tri, b->nf, b->sp, b->cap)) < 0) return r;   // :1245-1247
     if (b->nf > 1) {
         if ((r = launch_circle_join(s, b->join, b->nf - 1)) < 0) return r;                // :1282, 1292-1305
-        if ((r = launch_ransac(s, b->sitems, b->nf - 1, b->iters, b->seed, b->sp)) < 0) return r;   // :1313
+        if (ss != s) {
+            HIP_TRY(hipEventRecord(b->ev_join, s));
+            HIP_TRY(hipStreamWaitEvent(ss, b->ev_join, 0));
+        }
+    }
+    HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, ss));           // vector<double> tr(6,0), :1312
+    if (b->nf > 1) {
+        if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq)) < 0) return r;   // :1313
+    }
+    if (ss != s) {
+        HIP_TRY(hipEventRecord(b->ev_ransac, ss));
+        b->ransac_pending = true;
     }
     return VISO_OK;
 }
 
 extern "C" int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches) {
     if (!b) return VISO_ERR_ARG;
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     double tot = b->ev_ms_sum;
     int n = b->ev_n;
     for (auto& e : b->events) {
@@ -501,7 +554,7 @@ static bool slot_ok(viso_batch* b, int which, int t) { return b && which >= 0 &&
 
 extern "C" int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* out_match, int* out_n) {
     if (!slot_ok(b, which, t) || !out_n) { viso_set_error("viso_batch_get_matches: bad argument"); return VISO_ERR_ARG; }
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     const size_t o = (size_t)which * b->nf + t;
     int m = 0;
     HIP_TRY(hipMemcpy(&m, b->m_cnt + o, sizeof(int), hipMemcpyDeviceToHost));
@@ -512,7 +565,7 @@ extern "C" int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* 
 
 extern "C" int viso_batch_get_circle(viso_batch* b, int t, int32_t* circ, int32_t* pcl, int* out_n) {
     if (!slot_ok(b, 0, t) || !out_n) { viso_set_error("viso_batch_get_circle: bad argument"); return VISO_ERR_ARG; }
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     int m = 0;
     HIP_TRY(hipMemcpy(&m, b->mc + t, sizeof(int), hipMemcpyDeviceToHost));
     if (m > 0 && circ) HIP_TRY(hipMemcpy(circ, b->circ + (size_t)t * b->cap * 4, sizeof(int) * 4 * (size_t)m, hipMemcpyDeviceToHost));
@@ -523,7 +576,7 @@ extern "C" int viso_batch_get_circle(viso_batch* b, int t, int32_t* circ, int32_
 
 extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, int32_t* inliers, int* n_inl) {
     if (!slot_ok(b, 0, t)) { viso_set_error("viso_batch_get_pose: bad argument"); return VISO_ERR_ARG; }
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     int o = 0, n = 0;
     if (tr) HIP_TRY(hipMemcpy(tr, b->tr + (size_t)t * 6, sizeof(double) * 6, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&o, b->ok + t, sizeof(int), hipMemcpyDeviceToHost));
@@ -536,7 +589,7 @@ extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, 
 
 extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl) {
     if (!b) return VISO_ERR_ARG;
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     if (tr) HIP_TRY(hipMemcpy(tr, b->tr, sizeof(double) * 6 * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (ok) HIP_TRY(hipMemcpy(ok, b->ok, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (n_inl) HIP_TRY(hipMemcpy(n_inl, b->n_inl, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
@@ -547,14 +600,14 @@ extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int3
 // [-32768, 32767]): the problems reading them took the general (double) kernel, all others the u16 kernels.
 extern "C" int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags) {
     if (!b || !flags) return VISO_ERR_ARG;
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     HIP_TRY(hipMemcpy(flags, b->bad_img, sizeof(int) * 2 * (size_t)b->nf, hipMemcpyDeviceToHost));
     return VISO_OK;
 }
 
 extern "C" int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out) {
     if (!b) return VISO_ERR_ARG;
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     const size_t k = 3 * (size_t)b->nf;
     if (scored) HIP_TRY(hipMemcpy(scored, b->scored, sizeof(int64_t) * k, hipMemcpyDeviceToHost));
     if (m_out) {

@@ -78,6 +78,10 @@ struct viso_ctx {
     hipStream_t stream;
     bool own_stream;
     int matcher_variant;         // viso_ctx_set_matcher
+    // streams owned by the context's batches (their RANSAC stages run beside the next run's matcher):
+    // viso_ctx_synchronize waits for these too
+    hipStream_t aux[32];
+    int n_aux;
     // grow-only scratch for the plain (host-pointer) family
     void* scratch[16];
     size_t scratch_bytes[16];
@@ -141,8 +145,9 @@ struct TriItem {
     double* x; double* X; int ld;         // 4 x ld, 3 x ld (X may be NULL)
 };
 
+// queue: device scratch of 1 + n_items * iters ints (list of the hypotheses stage 1 leaves undecided)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp);
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue);
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);

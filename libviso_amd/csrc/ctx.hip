@@ -84,6 +84,7 @@ extern "C" void* viso_ctx_stream(viso_ctx* c) { return c ? (void*)c->stream : nu
 extern "C" int viso_ctx_synchronize(viso_ctx* c) {
     if (!c) return VISO_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n_aux; ++i) HIP_TRY(hipStreamSynchronize(c->aux[i]));   // solver streams of its batches
     return VISO_OK;
 }
 

@@ -13,6 +13,7 @@ struct SolverArgs {
     int iters;
     unsigned long long seed;
     SolverParamsDev sp;
+    int* queue;   // [0] = number of undecided hypotheses, [1..] = item * iters + h of each (any order)
 };
 
 // ---- stage 1: one lane per (frame, hypothesis): 3-point GN from zero -------
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];
     S.ok_h[h] = ok;
+    if (ok == 2) a.queue[1 + atomicAdd(&a.queue[0], 1)] = gid;   // ransac_coop_kernel continues it
 }
 
 // ---- stage 1b: one WAVE per unfinished hypothesis: iterations VISO_GN_SPLIT..99, same arithmetic ------------
@@ -58,12 +60,15 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     __shared__ double s_res[4][3][4];
     __shared__ double s_S[4][27];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + wv;
-    if (wave >= (long long)a.n_items * a.iters) return;
-    const int item = (int)(wave / a.iters), h = (int)(wave % a.iters);
-    const SolverItem S = a.items[item];
-    if (S.ok_h[h] != 2) return;                      // wave uniform
     __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
+    // a SMALL grid walks the list of undecided hypotheses (a launch with one wave per hypothesis would push
+    // thousands of 200-register workgroups, nearly all of which leave at once, through a GPU that is busy with
+    // another batch's matcher)
+    const int n_undecided = a.queue[0];
+    for (int qi = (int)blockIdx.x * 4 + wv; qi < n_undecided; qi += (int)gridDim.x * 4) {
+    const int gid = a.queue[1 + qi];
+    const int item = gid / a.iters, h = gid % a.iters;
+    const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     int sample[3];
     if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
@@ -162,6 +167,8 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) S.tr_h[6 * h + jj] = tr[jj];
         S.ok_h[h] = ok;
+    }
+    __builtin_amdgcn_wave_barrier();   // the wave's LDS slices are reused by its next hypothesis
     }
 }
 
@@ -351,15 +358,18 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
 }
 
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp) {
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue) {
     if (n_items <= 0) return VISO_OK;
     SolverArgs a;
-    a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp;
+    a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
     const long long nh = (long long)n_items * iters;
+    if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
+        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), s));
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
+        const long long cb = (nh + 3) / 4;
+        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)(cb < 128 ? cb : 128)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
@@ -525,7 +535,9 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp)) < 0) return r;
+    int* dqueue;
+    if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + (size_t)iters), (void**)&dqueue)) < 0) return r;
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue)) < 0) return r;
     int res[4];
     HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(best_tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
