@@ -414,7 +414,7 @@ def main():
         bytes_step = seq["kp"].nbytes + seq["desc"].nbytes + seq["n"].nbytes
         streaming = {"feature_in": {"fps_matcher": args.frames * s_steps * world / dts,
                                     "fps_end_to_end": args.frames * s_steps * world / dte if dte else None,
-                                    "host_bytes_per_step": bytes_step, "pcie_GBps": bytes_step * s_steps / dts / 1e9,
+                                    "host_bytes_per_step_per_gpu": bytes_step, "pcie_GBps_per_gpu": bytes_step * s_steps / dts / 1e9,
                                     "workload": "every step: viso_batch_upload_async of N x 121 f32 descriptors + keypoints from pinned "
                                                 "host memory, then the resident pipeline; alternating between two different sequences"}}
         for pk, pd, _ in hosts:
@@ -445,7 +445,7 @@ def main():
         dti = timed(img_step, i_steps, n_streams, objs=ibs)
         ibytes = iseq["images"].nbytes + iseq["kp"].nbytes + iseq["n"].nbytes
         streaming["image_in"] = {"fps_end_to_end": (nfi - 1) * i_steps * world / dti, "frames_per_step": nfi - 1,
-                                 "host_bytes_per_step": ibytes, "pcie_GBps": ibytes * i_steps / dti / 1e9,
+                                 "host_bytes_per_step_per_gpu": ibytes, "pcie_GBps_per_gpu": ibytes * i_steps / dti / 1e9,
                                  "workload": "every step: uint8 stereo images + keypoints uploaded asynchronously from pinned memory -> "
                                              "Sobel descriptor windows on device -> matcher + circle + RANSAC/GN"}
         for pi, pk, _ in ihosts:

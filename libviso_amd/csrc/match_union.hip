@@ -69,7 +69,7 @@ __device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {   //
     return f <= 0.f ? 0 : (f >= (float)(MU_NBY - 1) ? MU_NBY - 1 : (int)f);
 }
 
-__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][64];
     __shared__ float2 s_ykp[MU_KPCAP];       // staged window keypoints in y-bucket order
@@ -349,6 +349,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(MU_THREA
 #define MU_REDUCE(SLOT, U)                                                                                \
             do {                                                                                           \
                 const uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
+                __builtin_amdgcn_sched_barrier(0);   /* two halves: all sixteen query-row reads in flight at once cost 64 VGPRs */ \
                 const uint32_t s4_ = MU_SAD(4, SLOT), s5_ = MU_SAD(5, SLOT), s6_ = MU_SAD(6, SLOT), s7_ = MU_SAD(7, SLOT); \
                 const uint32_t a0_ = MU_X1(s0_, s1_), a1_ = MU_X1(s2_, s3_), a2_ = MU_X1(s4_, s5_), a3_ = MU_X1(s6_, s7_); \
                 const uint32_t c0_ = MU_X2(a0_, a1_), c1_ = MU_X2(a2_, a3_);                               \
