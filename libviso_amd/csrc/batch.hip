@@ -410,7 +410,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
             b->ev_next = (b->ev_next + 1) % VISO_EVENT_POOL;
         }
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, from_images ? 0 : 1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     return VISO_OK;
 }

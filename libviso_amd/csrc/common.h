@@ -101,8 +101,11 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], int* bad, int variant);
+// general_possible = 0: the rows cannot be flagged (descriptors extracted on the device from uint8 images), the
+// kernels of the general (double) path are not even launched
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                       const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant);
+                       const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant,
+                       int general_possible = 1);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 3
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);

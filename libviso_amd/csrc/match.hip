@@ -32,105 +32,95 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// ------------------------------------------------------------------ x-sort
-// One workgroup per image.  Keys (sortable(x) << 32 | index) in LDS, bitonic
-// network; NaN x sorts last.  Also builds a 256-bucket column index so that a
-// query tile finds its target window with two independent loads.
+// ------------------------------------------------------------------ column index
+// One workgroup per image: the keypoints grouped by a 256-bucket column map of their x (counting sort: histogram,
+// scan, scatter with LDS atomics), NOT fully sorted — nothing downstream needs more: a tile is any 64 consecutive
+// entries (its x extent is taken by a reduction), its target window is the range of whole buckets that covers that
+// extent +- radius (bstart), and every matcher result is independent of the order in which candidates are visited.
+// Which entry lands where inside a bucket depends on the atomics' order; results do not.  NaN x goes to the last
+// bucket.  Also: the image's y range (the matchers bucket their windows by y), the number of non-NaN x, and the y
+// order inside every block of 64 consecutive entries (ImageView::qord).
 #define VISO_IMG_THREADS 512
 
-__device__ __forceinline__ uint32_t sortable_f32(float x) {
-    if (x != x) return 0xffffffffu;
-    const uint32_t u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img,
-                                                                   int npad_alloc) {
+__global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    float* s_x = reinterpret_cast<float*>(keys + npad_alloc);   // [0]=x0 [1]=scale
-    __shared__ float s_y[2][VISO_IMG_THREADS / 64];
+    uint32_t* ykey = reinterpret_cast<uint32_t*>(smem);   // [n rounded up to 64] sortable y of the entry at each position
+    __shared__ int s_cnt[VISO_NB + 1];                    // bucket counts -> starts -> running offsets
+    __shared__ float s_red[5][VISO_IMG_THREADS / 64];
+    __shared__ float s_x[2];
     if ((int)blockIdx.x >= n_img) return;
     const ImageView I = imgs[blockIdx.x];
     const int n = *I.n;
-    {   // y range of the image's finite keypoints (the matcher kernels bucket their windows by y over it)
-        float ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
-        for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
-            const float y = I.kp[i].y;
-            if (fabsf(y) < 3.0e38f) { ymn = fminf(ymn, y); ymx = fmaxf(ymx, y); }
-        }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- x extent (x0 = smallest x, x1 = largest non-NaN x: the bucket map), finite y extent, number of non-NaN x
+    float xmn = __builtin_huge_valf(), xmx = -__builtin_huge_valf(), ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
+    float nvx = 0.f;
+    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
+        const float2 k = I.kp[i];
+        if (k.x == k.x) { xmn = fminf(xmn, k.x); xmx = fmaxf(xmx, k.x); nvx += 1.f; }
+        if (fabsf(k.y) < 3.0e38f) { ymn = fminf(ymn, k.y); ymx = fmaxf(ymx, k.y); }
+    }
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { ymn = fminf(ymn, __shfl_xor(ymn, m)); ymx = fmaxf(ymx, __shfl_xor(ymx, m)); }
-        if ((threadIdx.x & 63) == 0) { s_y[0][threadIdx.x >> 6] = ymn; s_y[1][threadIdx.x >> 6] = ymx; }
+    for (int m = 1; m < 64; m <<= 1) {
+        xmn = fminf(xmn, __shfl_xor(xmn, m)); xmx = fmaxf(xmx, __shfl_xor(xmx, m));
+        ymn = fminf(ymn, __shfl_xor(ymn, m)); ymx = fmaxf(ymx, __shfl_xor(ymx, m));
+        nvx += __shfl_xor(nvx, m);
     }
-    int npad = 64;
-    while (npad < n) npad <<= 1;
-    for (int i = threadIdx.x; i < npad; i += VISO_IMG_THREADS) {
-        unsigned long long k = ~0ull;
-        if (i < n) k = ((unsigned long long)sortable_f32(I.kp[i].x) << 32) | (uint32_t)i;
-        keys[i] = k;
-    }
+    if (lane == 0) { s_red[0][wv] = xmn; s_red[1][wv] = xmx; s_red[2][wv] = ymn; s_red[3][wv] = ymx; s_red[4][wv] = nvx; }
+    for (int b = threadIdx.x; b <= VISO_NB; b += VISO_IMG_THREADS) s_cnt[b] = 0;
     __syncthreads();
-    bitonic_sort_lds<VISO_IMG_THREADS>(keys, npad);
-    for (int j = threadIdx.x; j < n; j += VISO_IMG_THREADS) {
-        const int idx = (int)(uint32_t)keys[j];
-        I.skp[j] = I.kp[idx];
-        I.sidx[j] = idx;
-        I.rank[idx] = j;
-    }
     if (threadIdx.x == 0) {
-        float x0 = 0.f, scale = 0.f;
-        if (n > 0) {
-            x0 = I.kp[(int)(uint32_t)keys[0]].x;
-            int last = n - 1;   // last non-NaN x (NaNs sort to the end)
-            while (last > 0 && (uint32_t)(keys[last] >> 32) == 0xffffffffu) --last;
-            const float x1 = I.kp[(int)(uint32_t)keys[last]].x;
-            if (x1 > x0) scale = (float)VISO_NB / (x1 - x0);
-            if (!(scale > 0.f) || !(scale < 3.0e38f)) scale = 0.f;
-            if (x0 != x0) { x0 = 0.f; scale = 0.f; }
+        float a = __builtin_huge_valf(), b = -__builtin_huge_valf(), c = __builtin_huge_valf(), d = -__builtin_huge_valf(), e = 0.f;
+        for (int w = 0; w < VISO_IMG_THREADS / 64; ++w) {
+            a = fminf(a, s_red[0][w]); b = fmaxf(b, s_red[1][w]); c = fminf(c, s_red[2][w]); d = fmaxf(d, s_red[3][w]); e += s_red[4][w];
         }
+        float x0 = 0.f, scale = 0.f;
+        if (e > 0.f) {
+            x0 = a;
+            if (b > a) scale = (float)VISO_NB / (b - a);
+            if (!(scale > 0.f) || !(scale < 3.0e38f)) scale = 0.f;
+        }
+        if (!(c <= d)) { c = 0.f; d = 0.f; }   // no finite y at all
         s_x[0] = x0; s_x[1] = scale;
-        I.xinfo[0] = x0; I.xinfo[1] = scale;
-        float ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
-        for (int w = 0; w < VISO_IMG_THREADS / 64; ++w) { ymn = fminf(ymn, s_y[0][w]); ymx = fmaxf(ymx, s_y[1][w]); }
-        if (!(ymn <= ymx)) { ymn = 0.f; ymx = 0.f; }   // no finite y at all
-        I.xinfo[2] = ymn; I.xinfo[3] = ymx;
-        int nvx = n;   // keypoints with a non-NaN x (NaNs sort last)
-        while (nvx > 0 && (uint32_t)(keys[nvx - 1] >> 32) == 0xffffffffu) --nvx;
-        I.xinfo[4] = (float)nvx;
+        I.xinfo[0] = x0; I.xinfo[1] = scale; I.xinfo[2] = c; I.xinfo[3] = d; I.xinfo[4] = e;
     }
     __syncthreads();
     const float x0 = s_x[0], scale = s_x[1];
-    // replace each key by its bucket (monotone in j), then bstart[b] = first j with bucket >= b
-    for (int j = threadIdx.x; j < n; j += VISO_IMG_THREADS) {
-        const int idx = (int)(uint32_t)keys[j];
-        const int bk = bucket_of(I.kp[idx].x, x0, scale);
-        keys[j] = (unsigned long long)bk;
-    }
+    // ---- counting sort by column bucket
+    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) atomicAdd(&s_cnt[bucket_of(I.kp[i].x, x0, scale)], 1);
     __syncthreads();
-    for (int b = threadIdx.x; b <= VISO_NB; b += VISO_IMG_THREADS) {
-        int lo = 0, hi = n;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)keys[mid] >= b) hi = mid; else lo = mid + 1;
+    if (wv == 0) {   // exclusive scan of the 256 counts: 4 per lane + wave scan
+        int c[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_cnt[lane * 4 + k]; tot += c[k]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
-        I.bstart[b] = (b == VISO_NB) ? n : lo;
+        int run = incl - tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_cnt[lane * 4 + k] = run; I.bstart[lane * 4 + k] = run; run += c[k]; }
+        if (lane == 63) { s_cnt[VISO_NB] = run; I.bstart[VISO_NB] = n; }
     }
-    // y order inside every block of 64 sorted positions (the matcher kernels score rounds of four y-adjacent queries
-    // of such a block: their candidate sets overlap by ~2/3).  Any total order is valid; (y, position) is used.
     __syncthreads();
-    uint32_t* ykey = reinterpret_cast<uint32_t*>(keys);
     const int n64 = (n + 63) & ~63;
-    for (int j = threadIdx.x; j < n64; j += VISO_IMG_THREADS) {
-        uint32_t k = 0xffffffffu;
-        if (j < n) {
-            const uint32_t yb = __float_as_uint(I.skp[j].y);
-            k = yb ^ ((yb >> 31) ? 0xffffffffu : 0x80000000u);
-            if (k == 0xffffffffu) k = 0xfffffffeu;   // keep "past n" strictly last
-        }
-        ykey[j] = k;
+    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
+        const float2 k = I.kp[i];
+        const int p = atomicAdd(&s_cnt[bucket_of(k.x, x0, scale)], 1);   // running offset of the bucket
+        I.skp[p] = k;
+        I.sidx[p] = i;
+        I.rank[i] = p;
+        const uint32_t yb = __float_as_uint(k.y);
+        uint32_t yk = yb ^ ((yb >> 31) ? 0xffffffffu : 0x80000000u);
+        if (yk == 0xffffffffu) yk = 0xfffffffeu;   // keep "past n" strictly last
+        ykey[p] = yk;
     }
+    for (int j = n + threadIdx.x; j < n64; j += VISO_IMG_THREADS) ykey[j] = 0xffffffffu;
     __syncthreads();
+    // ---- y order inside every block of 64 positions (the matcher kernels score rounds of y-adjacent queries of such
+    // a block: their candidate sets overlap by ~2/3).  Any total order is valid; (y, position) is used.
     for (int j = threadIdx.x; j < n64; j += VISO_IMG_THREADS) {
         const int base = j & ~63, me = j & 63;
         const uint32_t key = ykey[j];
@@ -149,12 +139,11 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
         viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
         return VISO_ERR_UNSUPPORTED;
     }
-    int npad = 64;
-    while (npad < cap_max) npad <<= 1;
-    const size_t lds = (size_t)npad * sizeof(unsigned long long) + 16;
-    if (lds > 48 * 1024)
+    const int n64 = (cap_max + 63) & ~63;
+    const size_t lds = (size_t)n64 * sizeof(uint32_t) + 16;
+    if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_kp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, npad);
+    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -809,7 +798,7 @@ const char* matcher_kernel_name(int variant) {
 // e0/e1 (may be null) bracket the kernel that takes the temporal problems: the dominant kernel.
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], int* bad,
-                       hipEvent_t e0, hipEvent_t e1, int layout, int variant) {
+                       hipEvent_t e0, hipEvent_t e1, int layout, int variant, int general_possible) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
     a.probs = probs_dev;
@@ -832,14 +821,18 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     // general (non-u16) path: normally idle (no image is flagged and every block leaves at once), so
     // it gets a small grid that strides over the (problem, tile) slots when it does have work
     const unsigned gblocks = (unsigned)(blocks < 2048 ? blocks : 2048);
-    hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    if (general_possible) {
+        hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(match_overflow_kernel<false>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(match_overflow_kernel<true>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    if (general_possible) {
+        hipLaunchKernelGGL(match_overflow_kernel<true>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     return VISO_OK;
 }
 
@@ -865,39 +858,43 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     if (prob >= n_probs) return;
     const MatchProblem P = probs[prob];
     const int n1 = *P.q.n;
-    int npad = 64;
-    while (npad < n1) npad <<= 1;
-    for (int i = threadIdx.x; i < npad; i += VISO_SORT_THREADS) {
+    // compaction first: only the accepted queries carry a key (the ratio test rejects about half of the temporal
+    // ones), so the network usually sorts half as many keys through fewer stages
+    int* s_cnt = reinterpret_cast<int*>(keys + npad_alloc);   // tail words of the dynamic LDS area
+    if (threadIdx.x == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int base = 0; base < n1; base += VISO_SORT_THREADS) {
+        const int i = base + threadIdx.x;
         unsigned long long k = ~0ull;
         if (i < n1) {
             const int2 r = P.res[i];
             if (r.x >= 0) k = ((unsigned long long)(uint32_t)r.y << 32) | (uint32_t)i;
             P.pos[i] = -1;
         }
-        keys[i] = k;
+        const bool valid = k != ~0ull;
+        const unsigned long long m = __ballot(valid);
+        int wbase = 0;
+        if ((threadIdx.x & 63) == 0 && m) wbase = atomicAdd(s_cnt, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (valid) keys[wbase + mbcnt(m)] = k;
     }
+    __syncthreads();
+    const int mv = *s_cnt;
+    int npad = 64;
+    while (npad < mv) npad <<= 1;
+    for (int i = mv + threadIdx.x; i < npad; i += VISO_SORT_THREADS) keys[i] = ~0ull;
     __syncthreads();
     bitonic_sort_lds<VISO_SORT_THREADS>(keys, npad);
-    int local = 0;
-    for (int r = threadIdx.x; r < n1; r += VISO_SORT_THREADS) {
+    for (int r = threadIdx.x; r < mv; r += VISO_SORT_THREADS) {
         const unsigned long long k = keys[r];
-        if (k != ~0ull) {
-            const int i1 = (int)(uint32_t)k;
-            const int2 rr = P.res[i1];
-            P.sorted[3 * r + 0] = i1;
-            P.sorted[3 * r + 1] = rr.x;
-            P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
-            P.pos[i1] = r;
-            ++local;
-        }
+        const int i1 = (int)(uint32_t)k;
+        const int2 rr = P.res[i1];
+        P.sorted[3 * r + 0] = i1;
+        P.sorted[3 * r + 1] = rr.x;
+        P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
+        P.pos[i1] = r;
     }
-    // count = number of valid keys (tail word of the dynamic LDS area)
-    int* s_cnt = reinterpret_cast<int*>(keys + npad_alloc);
-    if (threadIdx.x == 0) *s_cnt = 0;
-    __syncthreads();
-    if (local) atomicAdd(s_cnt, local);
-    __syncthreads();
-    if (threadIdx.x == 0) *P.m_cnt = *s_cnt;
+    if (threadIdx.x == 0) *P.m_cnt = mv;
 }
 
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max) {
