@@ -89,8 +89,10 @@ def b_min_bytes(n, m_out, dlen=121, elem=4):
 
 def workload_name(args):
     geo = f"synthetic {args.width}x{args.height} stereo pairs, {args.kp} features/image"
+    if args.clustered > 0:
+        geo += f" ({args.clustered:.0%} of them clustered in blobs)"
     if (args.width, args.height, args.kp) == (1241, 376, 2000):
-        tag = "configs[1]"
+        tag = "configs[1]" if args.clustered == 0 else "configs[1] geometry, clustered features"
     elif (args.width, args.height, args.kp) == (2048, 1024, 8000):
         tag = "configs[4] geometry, matcher only, this rank's share"
     else:
@@ -172,6 +174,8 @@ def main():
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--clustered", type=float, default=0.0,
+                    help="share of the synthetic features drawn around a few blobs instead of uniformly (0.7: real-image-like clustering; exercises the K cap and the overflow kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline samples (all of them)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -212,7 +216,7 @@ def main():
 
     variant = args.matcher if args.matcher is not None else libviso_amd.DEFAULT_MATCHER
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
-    seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height)
+    seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height, cluster_frac=args.clustered)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
     # S independent batches per GPU, each on its own context / HIP stream: consecutive steps go to
     # different streams, so one batch's latency-bound stages (sorts, RANSAC) overlap the next one's matcher
@@ -290,13 +294,14 @@ def main():
     batch.kernel_timing(False)
 
     scored, m_out = batch.counters()
+    n_overflow = batch.overflow_count()
     balg_stereo, balg_temporal = b_alg_bytes(seq["n"], scored, m_out)
     bmin32_s, bmin32_t = b_min_bytes(seq["n"], m_out, elem=4)
     bmin16_s, bmin16_t = b_min_bytes(seq["n"], m_out, elem=2)
     kname = libviso_amd.matcher_kernel_name(ctx)
     pairs = int(scored[1:].sum())              # the timed kernel takes the temporal problems (2 of 3 calls, ~97 % of the pairs)
     t_k = kern_ms * 1e-3
-    default_workload = (args.frames, args.kp, args.width, args.height) == (256, 2000, 1241, 376)
+    default_workload = (args.frames, args.kp, args.width, args.height, args.clustered) == (256, 2000, 1241, 376, 0.0)
     pmc = load_pmc(kname, default_workload)
     ceilings = {}
     # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
@@ -334,6 +339,8 @@ def main():
         "kernel_ms_in_timed_region_note": f"{n_streams} batches in flight share the CUs: not a per-step cost, may exceed ms_per_step",
         "ceilings": ceilings,
         "scored_pairs_per_launch": pairs,
+        "overflow_queries_per_step": n_overflow,
+        "overflow_note": "queries of one step (all three calls) handed to match_overflow_kernel: K cap, exact SAD tie, LDS list overflow",
         "effective_bandwidth": {"algorithmic_bytes_per_launch": balg_temporal, "GB/s": balg_temporal / t_k / 1e9,
                                 "note": "SURVEY 8(d) B_alg (every scored pair counted as a fresh 484-B f32 row) / kernel time: an "
                                         "effective figure served by L2/LDS, not comparable with the HBM peak"},

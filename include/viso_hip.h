@@ -263,6 +263,10 @@ int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out);
  * the general kernel (float differences summed in double, the arithmetic of cv::norm at src/viso.cpp:702); all
  * other calls of the batch stay on the u16 kernels.  Same results either way. */
 int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags);
+/* Number of queries of the last run that took match_overflow_kernel (exact K-cap selection / largest-key tie rule
+ * / candidate lists beyond the tile kernels' LDS slots): a few for sparse features, a sizeable share where keypoints
+ * cluster densely.  Same results either way; this is the data-dependent cost to watch. */
+int viso_batch_get_overflow_count(viso_batch* b, int32_t* n);
 /* Duration of the kernel that takes the temporal calls (viso_ctx_matcher_kernel_name), measured with hipEvents
  * on the context's stream: average in ms over the runs since the last viso_batch_kernel_ms call. */
 int viso_batch_kernel_timing(viso_batch* b, int enable);

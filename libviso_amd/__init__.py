@@ -96,6 +96,7 @@ def load():
     L.viso_batch_get_poses.argtypes = [C.c_void_p, f64p, i32p, i32p]
     L.viso_batch_get_counters.argtypes = [C.c_void_p, i64p, i64p]
     L.viso_batch_get_general_path_flags.argtypes = [C.c_void_p, i32p]
+    L.viso_batch_get_overflow_count.argtypes = [C.c_void_p, i32p]
     L.viso_batch_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.viso_batch_kernel_ms.argtypes = [C.c_void_p, f64p, intp]
     L.viso_batch_upload_images.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
@@ -494,6 +495,11 @@ class Batch:
         f = np.zeros((self.nf, 2), np.int32)
         self._chk("viso_batch_get_general_path_flags", self.L.viso_batch_get_general_path_flags(self.h, ptr(f, C.c_int32)))
         return f
+
+    def overflow_count(self):
+        n = C.c_int32(0)
+        self._chk("viso_batch_get_overflow_count", self.L.viso_batch_get_overflow_count(self.h, C.byref(n)))
+        return n.value
 
     def kernel_timing(self, enable):
         self._chk("viso_batch_kernel_timing", self.L.viso_batch_kernel_timing(self.h, int(enable)))

@@ -25,6 +25,7 @@ struct viso_batch {
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
+    int2* ovf_q;                 // the launch's overflow queue: up to one entry per query of the batch
     int* tile_flag; int tiles;   // [3][nf][tiles] per-64-query-tile scratch of the stereo kernels
     int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored; size_t zeroed_bytes;
     double *x, *X, *x_c, *Xp_c;
@@ -101,7 +102,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->tile_flag, b->qord};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -132,7 +133,7 @@ static int build_items(viso_batch* b) {
     }
     HIP_TRY(hipMemcpy(b->views, V.data(), sizeof(ImageView) * V.size(), hipMemcpyHostToDevice));
     std::vector<MatchProblem> P((size_t)b->n_probs);
-    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.tile_flag = b->tile_flag; p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.ovf = b->pos; p.ovf_cnt = b->zero + 4; p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
+    for (auto& p : P) { memset(&p, 0, sizeof(p)); p.tile_flag = b->tile_flag; p.q = V[(size_t)nf * 2]; p.t = V[(size_t)nf * 2]; p.m_cnt = b->zero + 1; p.scored = (unsigned long long*)(b->zero + 2); p.ovf = b->ovf_q; p.ovf_cnt = b->ovf_cnt; p.res = b->res; p.sorted = b->sorted; p.pos = b->pos; }
     auto img_kp = [&](int t, int side) { return b->kp + ((size_t)t * 2 + side) * kpi; };
     for (int t = 0; t < nf; ++t) {
         for (int which = 0; which < 3; ++which) {
@@ -147,7 +148,7 @@ static int build_items(viso_batch* b) {
             const size_t o = (size_t)which * nf + t;
             p.res = b->res + o * cap; p.sorted = b->sorted + o * cap * 3; p.pos = b->pos + o * cap;
             p.m_cnt = b->m_cnt + o; p.scored = b->scored + o;
-            p.ovf = p.pos; p.ovf_cnt = b->ovf_cnt + o;   // pos is rewritten by the final sort
+            p.ovf = b->ovf_q; p.ovf_cnt = b->ovf_cnt;   // one queue and one counter for the whole launch
             p.tile_flag = b->tile_flag + o * b->tiles;
             p.pidx = which == 0 ? 0 : 1; p.cap = cap;
         }
@@ -235,6 +236,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->qord, nf * 2 * ((c + 63) & ~(size_t)63)));
     A(dalloc(&b->res, 3 * nf * c)); A(dalloc(&b->sorted, 3 * nf * c * 3)); A(dalloc(&b->pos, 3 * nf * c));
     A(dalloc(&b->m_cnt, 3 * nf));
+    A(dalloc(&b->ovf_q, 3 * nf * c));
     b->tiles = (cap + 63) / 64;
     A(dalloc(&b->tile_flag, 3 * nf * (size_t)b->tiles));
     // per-run counters zeroed by ONE memset: scored[3nf] (u64) | ovf_cnt[3nf] (int) | bad_img[2nf] (int) | bad_any (int)
@@ -410,7 +412,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
             b->ev_next = (b->ev_next + 1) % VISO_EVENT_POOL;
         }
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, from_images ? 0 : 1)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, b->ovf_q, b->ovf_cnt, from_images ? 0 : 1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     return VISO_OK;
 }
@@ -602,6 +604,15 @@ extern "C" int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags) 
     if (!b || !flags) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     HIP_TRY(hipMemcpy(flags, b->bad_img, sizeof(int) * 2 * (size_t)b->nf, hipMemcpyDeviceToHost));
+    return VISO_OK;
+}
+
+// How many queries of the last run the tile kernels handed to match_overflow_kernel (more than K in-radius
+// candidates, a candidate list that outgrew its LDS slot, an exact tie of the minimum): the data-dependent slow path.
+extern "C" int viso_batch_get_overflow_count(viso_batch* b, int32_t* n) {
+    if (!b || !n) return VISO_ERR_ARG;
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
+    HIP_TRY(hipMemcpy(n, b->ovf_cnt, sizeof(int), hipMemcpyDeviceToHost));
     return VISO_OK;
 }
 

@@ -60,8 +60,10 @@ struct MatchProblem {            // one match_desc call (reference src/viso.cpp:
     int* pos;                    // out: per query, row in `sorted` or -1
     int* m_cnt;                  // out: M
     unsigned long long* scored;  // out: number of SAD evaluations (C of SURVEY 8(d))
-    int* ovf;                    // scratch: sorted positions of queries left to the overflow kernel
-    int* ovf_cnt;                // scratch: their count (zeroed before every run)
+    int2* ovf;                   // scratch shared by ALL problems of a launch: (problem, sorted position) of every query
+    int* ovf_cnt;                //     left to the overflow kernel, and their count (zeroed before every run) — one
+                                 //     queue, so that the overflow kernel's waves share the work evenly whatever
+                                 //     problem it comes from (dense keypoint clusters concentrate it in a few problems)
     int* tile_flag;              // scratch, stereo call: per 64-query tile, 1 = match_batch_kernel<1> does the tile
                                  //     (written by match_stereo_kernel for every tile, read by the kernel behind it)
     int pidx;                    // 0 = stereo params, 1 = temporal params
@@ -100,12 +102,12 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any);
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], int* bad, int variant);
+                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt);
 // general_possible = 0: the rows cannot be flagged (descriptors extracted on the device from uint8 images), the
 // kernels of the general (double) path are not even launched
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                        const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant,
-                       int general_possible = 1);
+                       const int2* ovf_q, const int* ovf_cnt, int general_possible = 1);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 3
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);

@@ -190,7 +190,9 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     P.res = dres; P.sorted = dsorted; P.pos = dpos;
     P.m_cnt = dmisc + 3; P.scored = (unsigned long long*)(dmisc + 4); P.pidx = 0; P.cap = n1;
     P.tile_flag = dtile;
-    P.ovf = dpos; P.ovf_cnt = dmisc + 6;   // pos is written by the final sort, after the overflow pass
+    int2* dovf;
+    if ((r = ctx_scratch(c, 13, sizeof(int2) * (size_t)n1, (void**)&dovf)) < 0) return r;
+    P.ovf = dovf; P.ovf_cnt = dmisc + 6;
     struct { MatchProblem p; ImageView v[2]; } up;
     up.p = P; up.v[0] = P.q; up.v[1] = P.t;
     HIP_TRY(hipMemcpyAsync(dprob, &up, sizeof(up), hipMemcpyHostToDevice, s));
@@ -205,7 +207,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];
-    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant)) < 0) return r;
+    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant, dovf, dmisc + 6)) < 0) return r;
     if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
     int m = 0;
     HIP_TRY(hipMemcpyAsync(&m, dmisc + 3, sizeof(int), hipMemcpyDeviceToHost, s));

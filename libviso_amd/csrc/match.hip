@@ -461,7 +461,7 @@ struct QueryResult { int idx; int dist; double bd1, bd2; };
 template <bool GENERAL, bool SLOW, int EPI>
 __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int j, const Window& win,
                             float2 kp0, bool has0, uint2* queue, int lane, int dlen,
-                            unsigned long long& scored, QueryResult& out) {
+                            unsigned long long& scored, QueryResult& out, uint4* stage = nullptr, int stage_cap = 0) {
     const float2 q = P.q.skp[j];
     const float qx = q.x, qy = q.y;
     const float radius = mp.radius;
@@ -486,6 +486,9 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
         if (m) {
             const int pos = cnt + mbcnt(m);
             if (!SLOW && in && pos < VISO_QCAP) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));
+            // slow path: the in-radius set (position, distance bits, original index) is staged in LDS once, so that
+            // the 64 selection steps and the final pass below do not walk the window in global memory 65 times
+            if (SLOW && in && pos < stage_cap) stage[pos] = make_uint4((uint32_t)(win.lo + w), __float_as_uint(d), (uint32_t)win.idx(w), 0u);
             cnt += __popcll(m);
         }
     }
@@ -543,7 +546,24 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
     } else {
         // ---- slow path (dense clusters): apply the K cap, then stream in batches
         uint32_t tkd = 0xffffffffu, tki = 0xffffffffu;   // threshold key (exclusive)
-        if (cnt > K) {
+        const bool staged = cnt <= stage_cap;
+        if (cnt > K && staged) {
+            // key_K = largest v with |{key < v}| <= K, built bit by bit (64-bit key) over the staged set
+            unsigned long long v = 0;
+            for (int bit = 63; bit >= 0; --bit) {
+                const unsigned long long trial = v | (1ull << bit);
+                const uint32_t kd = (uint32_t)(trial >> 32), ki = (uint32_t)trial;
+                int c = 0;
+                for (int base = 0; base < cnt; base += VISO_WAVE) {
+                    const int i = base + lane;
+                    bool in = false;
+                    if (i < cnt) { const uint4 e = stage[i]; in = key_less(e.y, e.z, kd, ki); }
+                    c += __popcll(__ballot(in));
+                }
+                if (c <= K) v = trial;
+            }
+            tkd = (uint32_t)(v >> 32); tki = (uint32_t)v;
+        } else if (cnt > K) {
             // key_K = largest v with |{key < v}| <= K, built bit by bit (64-bit key)
             unsigned long long v = 0;
             for (int bit = 63; bit >= 0; --bit) {
@@ -565,15 +585,25 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
             tkd = (uint32_t)(v >> 32); tki = (uint32_t)v;
         }
         int qn = 0;
-        for (int base = 0; base < win.W; base += VISO_WAVE) {
+        const int n_walk = staged ? cnt : win.W;   // staged: the in-radius set in LDS; otherwise the window in global memory
+        for (int base = 0; base < n_walk; base += VISO_WAVE) {
             const int w = base + lane;
             bool in = false;
-            float d = 0.f;
-            if (w < win.W) {
-                const float2 t2 = win.kp(w);
-                d = l1_kp(qx, qy, t2);
-                in = (d <= radius) && (d < d0cut) &&
-                     key_less(__float_as_uint(d), (uint32_t)win.idx(w), tkd, tki);
+            uint32_t e_pos = 0, e_d = 0;
+            if (w < n_walk) {
+                float2 t2;
+                if (staged) {
+                    const uint4 e = stage[w];
+                    e_pos = e.x; e_d = e.y;
+                    in = key_less(e.y, e.z, tkd, tki);
+                    if (in && mp.epi) t2 = win.gkp[e.x];
+                } else {
+                    t2 = win.kp(w);
+                    const float d = l1_kp(qx, qy, t2);
+                    e_pos = (uint32_t)(win.lo + w); e_d = __float_as_uint(d);
+                    in = (d <= radius) && (d < d0cut) &&
+                         key_less(__float_as_uint(d), (uint32_t)win.idx(w), tkd, tki);
+                }
                 if (in && mp.epi) {
                     const double s = sampson_dev(F, qx, qy, t2.x, t2.y);
                     in = isfinite(s) && !(s > mp.sampson_thresh);
@@ -581,7 +611,7 @@ __device__ bool match_query(const MatchProblem& P, const MatchParamsDev& mp, int
             }
             const unsigned long long m = __ballot(in);
             const int pos = qn + mbcnt(m);
-            if (in) queue[pos] = make_uint2((uint32_t)(win.lo + w), __float_as_uint(d));   // qn < 64 => pos < 128
+            if (in) queue[pos] = make_uint2(e_pos, e_d);   // qn < 64 => pos < 128
             qn += __popcll(m);
             __builtin_amdgcn_wave_barrier();
             if (qn >= VISO_WAVE) {
@@ -637,6 +667,8 @@ struct MatchArgs {
     int n_probs, bpp, dlen, gs, gf, gc;
     int vblocks;   // number of (problem, tile) slots; the grid may be smaller (blocks stride over the slots)
     const int* bad;
+    const int2* ovf_q;   // the launch's overflow queue and its count (MatchProblem::ovf / ovf_cnt)
+    const int* ovf_cnt;
     MatchParamsDev mp[2];
 };
 
@@ -709,7 +741,7 @@ __device__ __forceinline__ void match_tile_slot(const MatchArgs& a, int vb, uint
                 if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
                 P.res[P.q.sidx[j]] = make_int2(accept ? r.idx : -1, r.dist);
             } else {
-                P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // dense cluster: overflow kernel
+                P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);   // dense cluster: overflow kernel
             }
         }
     }
@@ -734,30 +766,31 @@ __global__ __attribute__((amdgpu_waves_per_eu(GENERAL ? 4 : 8, 8))) __launch_bou
     }
 }
 
-// Queries whose in-radius set exceeds K or the LDS queue (dense keypoint
-// clusters): exact K-cap selection + streaming, reading the window from global
-// memory.  A few waves per problem; empty for ordinary data.
-#define VISO_OVF_BLOCKS 2
+// Queries whose in-radius set exceeds K or an LDS list (dense keypoint clusters), or whose minimum is an exact tie:
+// exact K-cap selection + streaming, reading the window from global memory.  ONE queue for the whole launch
+// (MatchProblem::ovf): a fixed grid of waves strides over it, so the work is shared evenly whichever problems it comes
+// from; a handful of entries for ordinary data.
+#define VISO_OVF_GRID 1024
+#define VISO_OVF_STAGE 768   // in-radius targets of one query staged in LDS (12 KB per wave); more: the window is re-walked
 
 template <bool GENERAL>
 __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(MatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
+    __shared__ __attribute__((aligned(16))) uint4 s_stage[VISO_MATCH_WAVES][VISO_OVF_STAGE];
     if (GENERAL && *a.bad == 0) return;
-    const int prob = blockIdx.x / VISO_OVF_BLOCKS, sub = blockIdx.x % VISO_OVF_BLOCKS;
-    if (prob >= a.n_probs) return;
-    const MatchProblem P = a.probs[prob];
-    if (((*P.q.bad | *P.t.bad) != 0) != GENERAL) return;
-    const int n_ovf = *P.ovf_cnt;
-    if (n_ovf == 0) return;
-    const int n2 = *P.t.n;
-    const MatchParamsDev& mp = a.mp[P.pidx];
+    const int n_ovf = *a.ovf_cnt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float2 kp0 = make_float2(0.f, 0.f);
-    const bool has0 = n2 > 0;
-    if (has0) kp0 = P.t.skp[P.t.rank[0]];
-    unsigned long long scored = 0;
-    for (int k = sub * VISO_MATCH_WAVES + wave; k < n_ovf; k += VISO_OVF_BLOCKS * VISO_MATCH_WAVES) {
-        const int j = P.ovf[k];
+    for (int k = (int)blockIdx.x * VISO_MATCH_WAVES + wave; k < n_ovf; k += (int)gridDim.x * VISO_MATCH_WAVES) {
+        const int2 e = a.ovf_q[k];
+        const MatchProblem P = a.probs[e.x];
+        if (((*P.q.bad | *P.t.bad) != 0) != GENERAL) continue;   // the other instantiation's
+        const int j = e.y;
+        const int n2 = *P.t.n;
+        const MatchParamsDev& mp = a.mp[P.pidx];
+        float2 kp0 = make_float2(0.f, 0.f);
+        const bool has0 = n2 > 0;
+        if (has0) kp0 = P.t.skp[P.t.rank[0]];
+        unsigned long long scored = 0;
         Window win;
         win.gkp = P.t.skp; win.gidx = P.t.sidx; win.skp = nullptr; win.sidx = nullptr;
         win.lo = 0; win.W = 0; win.cap = 0;   // the query's own +-radius column window, global reads
@@ -773,14 +806,15 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
             }
         }
         QueryResult r;
-        match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r);
+        match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r, s_stage[wave], VISO_OVF_STAGE);
         if (lane == 0) {
             bool accept = r.idx >= 0;
             if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
             P.res[P.q.sidx[j]] = make_int2(accept ? r.idx : -1, r.dist);
+            if (scored) atomicAdd(P.scored, scored);
         }
+        __builtin_amdgcn_wave_barrier();   // the wave's LDS queue is reused by its next entry
     }
-    if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
 // Which kernel takes the temporal problems of the u16 path (viso_ctx_set_matcher, per context):
@@ -798,7 +832,8 @@ const char* matcher_kernel_name(int variant) {
 // e0/e1 (may be null) bracket the kernel that takes the temporal problems: the dominant kernel.
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], int* bad,
-                       hipEvent_t e0, hipEvent_t e1, int layout, int variant, int general_possible) {
+                       hipEvent_t e0, hipEvent_t e1, int layout, int variant,
+                       const int2* ovf_q, const int* ovf_cnt, int general_possible) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     MatchArgs a;
     a.probs = probs_dev;
@@ -807,6 +842,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     a.dlen = dlen;
     a.gs = 1; a.gf = 0; a.gc = 1;
     a.bad = bad;
+    a.ovf_q = ovf_q; a.ovf_cnt = ovf_cnt;
     a.mp[0] = mp[0];
     a.mp[1] = mp[1];
     const int groups = (n_probs + 7) / 8;
@@ -827,18 +863,18 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
+    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3(VISO_OVF_GRID), dim3(VISO_MATCH_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (general_possible) {
-        hipLaunchKernelGGL(match_overflow_kernel<true>, dim3((unsigned)(n_probs * VISO_OVF_BLOCKS)), dim3(VISO_MATCH_THREADS), 0, s, a);
+        hipLaunchKernelGGL(match_overflow_kernel<true>, dim3(VISO_OVF_GRID), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     return VISO_OK;
 }
 
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], int* bad, int variant) {
-    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant);
+                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt) {
+    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant, ovf_q, ovf_cnt);
 }
 
 

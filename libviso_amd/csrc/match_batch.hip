@@ -384,7 +384,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
             if (i16 == 0 && my_orig >= 0) {
                 const int j = jg + row * MB_WAVES;
                 if (((flags >> row) & 1) || (m1 != 0xffffffffu && c > 1)) {
-                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // K cap / exact tie: overflow kernel
+                    P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);   // K cap / exact tie: overflow kernel
                 } else {
                     bool accept = m1 != 0xffffffffu;
                     int idx = -1;
@@ -406,7 +406,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
                 if (orig[k] < 0) continue;
                 const int j = jg + k * MB_WAVES;
                 if (flags & (1 << k)) {
-                    if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
+                    if (lane == 0) P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);
                     continue;
                 }
                 const int n = seg_n[k], st = k == 0 ? 0 : k == 1 ? c1 : k == 2 ? c2 : c3;
@@ -427,7 +427,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
                 }
                 if (lane == 0) {
                     if (r_tie) {
-                        P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;   // exact tie: the largest-key rule is applied by the overflow kernel
+                        P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);   // exact tie: the largest-key rule is applied by the overflow kernel
                     } else {
                         bool accept = r_d1 != 0xffffffffu;
                         int idx = -1;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
         const bool none = d1 == 0xffffffffu;
         if (cnt > K || force || (!none && tie)) {
             // more than K in radius / more survivors than slots / exact tie of the minimum (largest-key rule): overflow kernel
-            P.ovf[atomicAdd(P.ovf_cnt, 1)] = j;
+            P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);
         } else {
             bool accept = !none;
             int idx = -1;

@@ -405,7 +405,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
             if (list_ovf || my_cnt > K || tie) {
                 // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
-                P.ovf[atomicAdd(P.ovf_cnt, 1)] = my_j;
+                P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, my_j);
             } else {
                 bool accept = !none;
                 int idx = -1;

@@ -36,9 +36,18 @@ def rot_from_tr(tr):
     return R, np.array([tx, ty, tz])
 
 
-def _new_points(rng, k, width, height, zmin, zmax, f, cu, cv):
+def _new_points(rng, k, width, height, zmin, zmax, f, cu, cv, blobs=None, cluster_frac=0.0):
     u = rng.uniform(0, width - 1, k)
     v = rng.uniform(0, height - 1, k)
+    if blobs is not None and cluster_frac > 0 and k > 0:
+        # clustered features (what a corner detector finds on real images: texture comes in patches): a share of the
+        # points is drawn around a few blob centres instead of uniformly
+        pick = rng.random(k) < cluster_frac
+        c = blobs[rng.integers(0, len(blobs), k)]
+        uc = np.clip(c[:, 0] + rng.normal(0, c[:, 2], k), 0, width - 1)
+        vc = np.clip(c[:, 1] + rng.normal(0, c[:, 2], k), 0, height - 1)
+        u = np.where(pick, uc, u)
+        v = np.where(pick, vc, v)
     z = rng.uniform(zmin, zmax, k)
     P = np.stack([(u - cu) * z / f, (v - cv) * z / f, z], 1)
     return P
@@ -52,7 +61,7 @@ def _new_desc(rng, k):
 
 def make_sequence(seed, n_frames, n_kp=2000, width=1241, height=376, outlier_frac=0.2,
                   noise_sigma=6.0, dup_frac=0.0, cap=None, ragged=False,
-                  zmin=4.0, zmax=60.0):
+                  zmin=4.0, zmax=60.0, cluster_frac=0.0, n_blobs=14):
     """Returns dict(kp, desc, n, tr_gt, param, F, P1, P2, width, height).
 
     tr_gt[t] maps 3-D points of frame t-1 (left camera) into frame t, the
@@ -65,7 +74,11 @@ def make_sequence(seed, n_frames, n_kp=2000, width=1241, height=376, outlier_fra
     desc = np.zeros((n_frames, 2, cap, DESC_LEN), np.float32)
     n = np.zeros((n_frames, 2), np.int32)
     tr_gt = np.zeros((n_frames, 6))
-    P = _new_points(rng, n_in, width, height, zmin, zmax, f, cu, cv)
+    blobs = None
+    if cluster_frac > 0:   # blob centres (u, v) and radii (sigma, px) in the image
+        blobs = np.stack([rng.uniform(0, width - 1, n_blobs), rng.uniform(0, height - 1, n_blobs),
+                          rng.uniform(12, 45, n_blobs)], 1)
+    P = _new_points(rng, n_in, width, height, zmin, zmax, f, cu, cv, blobs, cluster_frac)
     D = _new_desc(rng, n_in)
     for t in range(n_frames):
         if t > 0:
@@ -80,7 +93,7 @@ def make_sequence(seed, n_frames, n_kp=2000, width=1241, height=376, outlier_fra
             P, D = P[keep], D[keep]
             k_new = n_in - len(P)
             if k_new > 0:
-                P = np.concatenate([P, _new_points(rng, k_new, width, height, zmin, zmax, f, cu, cv)])
+                P = np.concatenate([P, _new_points(rng, k_new, width, height, zmin, zmax, f, cu, cv, blobs, cluster_frac)])
                 D = np.concatenate([D, _new_desc(rng, k_new)])
         uL = np.rint(f * P[:, 0] / P[:, 2] + cu)
         vL = np.rint(f * P[:, 1] / P[:, 2] + cv)

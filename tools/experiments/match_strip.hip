@@ -463,7 +463,7 @@ __global__ __launch_bounds__(MS_THREADS) void match_strip_kernel(StripArgs sa) {
                             const bool none = d1 == 0xffffffffu;
                             if (my_cnt > K || force || tie) {
                                 // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
-                                P.ovf[atomicAdd(P.ovf_cnt, 1)] = my_j;
+                                P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, my_j);
                             } else {
                                 bool accept = !none;
                                 int idx = -1;
