@@ -134,7 +134,6 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
     // per-query state, carried over the chunks
     uint32_t d1 = 0xffffffffu, d2 = 0xffffffffu, bw = 0, tie = 0;
     int cnt_ub = 0, nscored = 0;
-    bool force = false;   // more survivors than slots: the overflow kernel redoes the query
 
     for (int cb = 0; cb < W; cb += ST_WCAP) {
         const int cw = min(W - cb, ST_WCAP);
@@ -183,24 +182,25 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- walk: the buckets the lane's band touches
-        int n = 0;
-        {
-            // the bucket map is monotone in y; `ys` covers the rounding of the float differences the tests below take
-            const float ys = (fabsf(qv.y) + fabsf(radius)) * 1e-6f + 1e-6f;
-            const int s0 = L.hist[st_bucket(qv.y - band - ys, y0, yscale)];
-            const int s1 = L.hist[st_bucket(qv.y + band + ys, y0, yscale) + 1];
-            // upper bound of the in-radius count (K cap): entries with |dy| <= radius
-            cnt_ub += L.hist[st_bucket(qv.y + radius + ys, y0, yscale) + 1] - L.hist[st_bucket(qv.y - radius - ys, y0, yscale)];
-            for (int i = s0; __any(i < s1); ++i) {
-                if (i < s1) {
-                    const float2 t = L.ykp[i];
-                    const float dx = qv.x - t.x, dy = qv.y - t.y;
-                    const bool in = __float_as_uint(fabsf(dx) + fabsf(dy)) < thr && fabsf(dy) <= band;
-                    if (in) {
-                        if (n < ST_SLOTS) L.slot[n][lane] = (uint16_t)i; else force = true;
-                        n = min(n + 1, ST_SLOTS);
-                    }
+        // ---- walk: the buckets the lane's band touches.  A lane keeps ST_SLOTS candidates per pass; where keypoints
+        // are dense and a band holds more, the walk / gate / score / reduce sequence below repeats for the next
+        // ST_SLOTS of them (`skip`): sparse data makes one pass
+        // the bucket map is monotone in y; `ys` covers the rounding of the float differences the tests below take
+        const float ys = (fabsf(qv.y) + fabsf(radius)) * 1e-6f + 1e-6f;
+        const int s0 = L.hist[st_bucket(qv.y - band - ys, y0, yscale)];
+        const int s1 = L.hist[st_bucket(qv.y + band + ys, y0, yscale) + 1];
+        // upper bound of the in-radius count (K cap): entries with |dy| <= radius
+        cnt_ub += L.hist[st_bucket(qv.y + radius + ys, y0, yscale) + 1] - L.hist[st_bucket(qv.y - radius - ys, y0, yscale)];
+        for (int skip = 0;; skip += ST_SLOTS) {
+        int n = 0, seen = 0;
+        for (int i = s0; __any(i < s1); ++i) {
+            if (i < s1) {
+                const float2 t = L.ykp[i];
+                const float dx = qv.x - t.x, dy = qv.y - t.y;
+                const bool in = __float_as_uint(fabsf(dx) + fabsf(dy)) < thr && fabsf(dy) <= band;
+                if (in) {
+                    if (seen >= skip && n < ST_SLOTS) { L.slot[n][lane] = (uint16_t)i; ++n; }
+                    ++seen;
                 }
             }
         }
@@ -276,6 +276,8 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
         }
         nscored += n2g;
         __builtin_amdgcn_wave_barrier();
+        if (!__any(seen > skip + ST_SLOTS)) break;
+        }   // skip
     }
     // ---- K cap: exact in-radius count where the bound does not settle it (dense clusters only)
     int cnt = cnt_ub;
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
     unsigned long long scored = 0;
     if (live) {
         const bool none = d1 == 0xffffffffu;
-        if (cnt > K || force || (!none && tie)) {
-            // more than K in radius / more survivors than slots / exact tie of the minimum (largest-key rule): overflow kernel
+        if (cnt > K || (!none && tie)) {
+            // more than K in radius / exact tie of the minimum (largest-key rule): overflow kernel
             P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, j);
         } else {
             bool accept = !none;

@@ -25,7 +25,7 @@
 #define MU_WAVES 4
 #define MU_QPB 64          // queries per tile
 #define MU_G 8             // queries per round
-#define MU_UCAP 256        // union list entries per round
+#define MU_UCAP 448        // union list entries per round (+ MU_PAD < 512: a list position fits the 9 low bits of a tracker key)
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
 #define MU_KPCAP 512       // window keypoints staged in LDS
@@ -75,7 +75,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     __shared__ float2 s_ykp[MU_KPCAP];       // staged window keypoints in y-bucket order
     __shared__ uint16_t s_ypos[MU_KPCAP];    // their window positions
     __shared__ int s_ys[MU_NBY + 1];         // bucket counts, then bucket starts
-    __shared__ int s_idx[MU_KPCAP];
     __shared__ float s_xr[2];
     int prob, qblk;
     {
@@ -142,7 +141,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         e_b[i] = 0; e_r[i] = 0;
         if (w < wcap) {
             e_kp[i] = P.t.skp[lo + w];
-            s_idx[w] = P.t.sidx[lo + w];
             e_b[i] = mu_ybucket(e_kp[i].y, ty0, yscale);
             e_r[i] = atomicAdd(&s_ys[e_b[i]], 1);
         }
@@ -411,7 +409,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 int idx = -1;
                 if (accept) {
                     const int w = (int)((ul[tr.m1 & 511u] >> 8) & 0xffffu);   // window position of the winner
-                    if (w < wcap) idx = s_idx[w]; else idx = P.t.sidx[lo + w];
+                    idx = P.t.sidx[lo + w];
                     if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
                         const double bd2 = tr.m2 == 0xffffffffu ? 1.7976931348623157e308 : (double)(tr.m2 >> 9);
                         accept = (double)d1 < bd2 * mp.ratio;
