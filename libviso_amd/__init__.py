@@ -180,8 +180,8 @@ class PinnedArray:
             self.L.viso_host_free(self.p)
             self.p = None
 
-    def __del__(self):
-        if not sys.is_finalizing():
+    def __del__(self, _finalizing=sys.is_finalizing):   # bound at definition: module globals are None late in shutdown
+        if not _finalizing():
             try:
                 self.close()
             except Exception:
@@ -373,8 +373,8 @@ class Context:
             if r != 1:
                 _err("viso_ctx_destroy", r)
 
-    def __del__(self):
-        if sys.is_finalizing():   # the atexit hook has closed everything that was still open
+    def __del__(self, _finalizing=sys.is_finalizing):   # bound at definition: module globals are None late in shutdown
+        if _finalizing():   # the atexit hook has closed everything that was still open
             return
         try:
             self.close()
@@ -522,8 +522,8 @@ class Batch:
             if r != 1:
                 _err("viso_batch_destroy", r)
 
-    def __del__(self):
-        if sys.is_finalizing():   # the atexit hook has closed everything that was still open
+    def __del__(self, _finalizing=sys.is_finalizing):   # bound at definition: module globals are None late in shutdown
+        if _finalizing():   # the atexit hook has closed everything that was still open
             return
         try:
             self.close()

@@ -39,8 +39,8 @@ struct viso_batch {
     bool params_set;
     bool timing;
     // The RANSAC stage of run k (latency bound: a few hundred waves on serial fp64 chains for ~1 ms) runs on a
-    // stream of its own, so that the matcher of run k+1 — which touches none of its buffers — fills the GPU beside
-    // it: stream (matcher, triangulation, circle join) --ev_join--> solver_stream (RANSAC) --ev_ransac--> the next
+    // stream of its own (the context's second stream), so that the matcher of run k+1 — which touches none of its
+    // buffers — fills the GPU beside it: stream (matcher, triangulation, circle join) --ev_join--> solver_stream (RANSAC) --ev_ransac--> the next
     // run's circle join (which rewrites the RANSAC inputs).
     hipStream_t solver_stream;
     hipEvent_t ev_join, ev_ransac;
@@ -89,13 +89,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     note(hipSetDevice(b->ctx->device));
     note(hipStreamSynchronize(b->ctx->stream));
-    if (b->solver_stream) {
-        note(hipStreamSynchronize(b->solver_stream));
-        viso_ctx* c = b->ctx;
-        for (int i = 0; i < c->n_aux; ++i)
-            if (c->aux[i] == b->solver_stream) { c->aux[i] = c->aux[--c->n_aux]; break; }
-        note(hipStreamDestroy(b->solver_stream));
-    }
+    if (b->solver_stream) note(hipStreamSynchronize(b->solver_stream));   // the context's: not destroyed here
     if (b->ev_join) note(hipEventDestroy(b->ev_join));
     if (b->ev_ransac) note(hipEventDestroy(b->ev_ransac));
     for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
@@ -207,21 +201,17 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->params_set = false; b->timing = false;
     b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     b->solver_stream = nullptr; b->ev_join = nullptr; b->ev_ransac = nullptr; b->ransac_pending = false;
-    if (ctx->n_aux < (int)(sizeof(ctx->aux) / sizeof(ctx->aux[0]))) {
-        int lo_p = 0, hi_p = 0;   // numerically lowest value = highest priority
-        if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }
-        if (hipStreamCreateWithPriority(&b->solver_stream, hipStreamNonBlocking, hi_p) != hipSuccess ||
-            hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess ||
+    if (ctx->solver_stream) {
+        if (hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_ransac, hipEventDisableTiming) != hipSuccess) {
-            viso_set_error("viso_batch_create: stream / event creation failed");
-            if (b->solver_stream) hipStreamDestroy(b->solver_stream);
+            viso_set_error("viso_batch_create: event creation failed");
             if (b->ev_join) hipEventDestroy(b->ev_join);
             if (b->ev_ransac) hipEventDestroy(b->ev_ransac);
             delete b;
             return nullptr;
         }
-        ctx->aux[ctx->n_aux++] = b->solver_stream;
-    }   // else (more than 32 batches on one context): the RANSAC stage stays on the context's stream
+        b->solver_stream = ctx->solver_stream;
+    }
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
     b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr;

@@ -40,6 +40,14 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
         }
         c->own_stream = true;
     }
+    int lo_p = 0, hi_p = 0;   // numerically lowest value = highest priority
+    if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }
+    if ((e = hipStreamCreateWithPriority(&c->solver_stream, hipStreamNonBlocking, hi_p)) != hipSuccess) {
+        viso_set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+        if (c->own_stream) hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -52,6 +60,7 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     note(hipSetDevice(c->device));
     note(hipStreamSynchronize(c->stream));
+    if (c->solver_stream) { note(hipStreamSynchronize(c->solver_stream)); note(hipStreamDestroy(c->solver_stream)); }
     for (int i = 0; i < 16; ++i) if (c->scratch[i]) note(hipFree(c->scratch[i]));
     if (c->own_stream) note(hipStreamDestroy(c->stream));
     delete c;
@@ -84,7 +93,7 @@ extern "C" void* viso_ctx_stream(viso_ctx* c) { return c ? (void*)c->stream : nu
 extern "C" int viso_ctx_synchronize(viso_ctx* c) {
     if (!c) return VISO_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < c->n_aux; ++i) HIP_TRY(hipStreamSynchronize(c->aux[i]));   // solver streams of its batches
+    if (c->solver_stream) HIP_TRY(hipStreamSynchronize(c->solver_stream));   // RANSAC stages of its batches
     return VISO_OK;
 }
 
