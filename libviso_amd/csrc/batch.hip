@@ -32,6 +32,7 @@ struct viso_batch {
     TriItem* tri; JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
     double* tr_h; int *ok_h, *cnt_h, *hq;   // hq: list of undecided hypotheses (launch_ransac)
+    int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_sample_kernel)
     double* tr; int *ok, *n_inl, *inl;
     MatchParamsDev mp[2];
     SolverParamsDev sp;
@@ -78,7 +79,8 @@ static void free_solver_bufs(viso_batch* b) {
     if (b->ok_h) hipFree(b->ok_h);
     if (b->cnt_h) hipFree(b->cnt_h);
     if (b->hq) hipFree(b->hq);
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr;
+    if (b->samp_h) hipFree(b->samp_h);
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr;
 }
 
 // Frees everything it can; the first HIP error met is recorded (viso_last_error) and returned.  Like
@@ -183,7 +185,7 @@ static int build_solver_items(viso_batch* b) {
         SolverItem& s = S[(size_t)t - 1];
         memset(&s, 0, sizeof(s));
         s.X = b->Xp_c + (size_t)t * 3 * cap; s.obs = b->x_c + (size_t)t * 4 * cap;
-        s.m_ptr = b->mc + t; s.ld = cap; s.samples = nullptr;
+        s.m_ptr = b->mc + t; s.ld = cap; s.samples = nullptr; s.samp_h = b->samp_h + (size_t)t * iters * 3;
         s.frame = b->first_frame + (unsigned long long)t;
         s.tr_h = b->tr_h + (size_t)t * iters * 6; s.ok_h = b->ok_h + (size_t)t * iters; s.cnt_h = b->cnt_h + (size_t)t * iters;
         s.tr = b->tr + (size_t)t * 6; s.ok = b->ok + t; s.n_inl = b->n_inl + t; s.inl = b->inl + (size_t)t * cap;
@@ -214,7 +216,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     }
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr;
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr;
     const size_t nf = (size_t)n_frames, c = (size_t)cap;
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
@@ -357,7 +359,7 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
         int r;
         if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0 ||
-            (r = dalloc(&b->hq, k + 1)) < 0) return r;
+            (r = dalloc(&b->hq, k + 1)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0) return r;
     }
     int r = build_solver_items(b);
     if (r < 0) return r;

@@ -124,6 +124,7 @@ struct SolverItem {            // one ransac_minimize_reproj problem (one frame)
     int ld;
     int _pad;
     const int* samples;        // iters x 3, or NULL -> splitmix64 stream
+    int* samp_h;               // iters x 3   the triples in use (ransac_sample_kernel: drawn, or copied from `samples`)
     unsigned long long frame;  // stream key
     double* tr_h;              // iters x 6   hypothesis transforms
     int* ok_h;                 // iters

@@ -16,6 +16,51 @@ struct SolverArgs {
     int* queue;   // [0] = number of undecided hypotheses, [1..] = item * iters + h of each (any order)
 };
 
+// ---- stage 0: the sample triples ------------------------------------------------------------------------------
+// randomsample (src/viso.cpp:88-107) is selection sampling: one uniform draw per candidate index t, index t is
+// taken when (N - t) * u_t < 3 - m.  The draws come from a splitmix64 stream keyed on (seed, frame, hypothesis)
+// (viso_sample3); splitmix64 is counter based — draw t is a function of s0 + (t + 1) * gamma — so a wave tests 64
+// consecutive t at once and walks its hits in order: the same triples as the serial loop (which costs ~50 k
+// instructions per hypothesis: three quarters of what ransac_hyp_kernel used to execute), in ~600.
+__global__ __launch_bounds__(256) void ransac_sample_kernel(SolverArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= (long long)a.n_items * a.iters) return;
+    const int item = (int)(gid / a.iters), h = (int)(gid % a.iters);
+    const SolverItem S = a.items[item];
+    int* out = S.samp_h + 3 * h;
+    if (S.samples) {   // explicit triples: copied, so that the later stages read one place
+        if (lane < 3) out[lane] = S.samples[3 * h + lane];
+        return;
+    }
+    const int N = *S.m_ptr;
+    int m = 0, mine = 0;   // lane k keeps the k-th index
+    if (N >= 3) {
+        const unsigned long long s0 = a.seed ^ (0xD1B54A32D192ED03ULL * (S.frame + 1)) ^
+                                      (0x8CB92BA72F3D8DD7ULL * ((unsigned long long)h + 1));
+        for (int base = 0; m < 3 && base < N; base += 64) {
+            const int t = base + lane;
+            unsigned long long z = s0 + 0x9E3779B97F4A7C15ULL * ((unsigned long long)t + 1);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+            const double x = (double)(N - t) * u;
+            int lo = 0;
+            while (m < 3) {
+                const bool sel = t < N && lane >= lo && !(x >= (double)(3 - m));
+                const unsigned long long mask = __ballot(sel);
+                if (!mask) break;
+                const int l = __ffsll((long long)mask) - 1;
+                if (lane == m) mine = base + l;
+                ++m;
+                lo = l + 1;
+            }
+        }
+    }
+    if (lane < 3) out[lane] = mine;   // N < 3: zeros, as viso_sample3
+}
+
 // ---- stage 1: one lane per (frame, hypothesis): 3-point GN from zero -------
 // Almost every hypothesis converges (or turns singular) within a few iterations; the ~1-2 % that do not run all 100
 // (src/viso.cpp:1622) and would keep their whole wave (and the kernel: a 0.7 ms serial fp64 chain) waiting.  Stage 1
@@ -23,8 +68,8 @@ struct SolverArgs {
 // ransac_coop_kernel continues each of them with a whole wave per hypothesis.
 #define VISO_GN_SPLIT 10
 
-__global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.n_items * a.iters) return;
     // a few hundred waves on a serial fp64 chain, usually beside another batch's matcher kernels: win the
     // instruction-issue arbitration on the SIMD (the chain's latency is what the batch waits for)
@@ -35,9 +80,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(SolverArgs a) {
     int ok = 0;
     double tr[6] = {0, 0, 0, 0, 0, 0};        // "start search from 0", :1557
     if (m >= 3) {
-        int sample[3];
-        if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
-        else viso_sample3(a.seed, S.frame, h, m, sample);
+        const int sample[3] = {S.samp_h[3 * h], S.samp_h[3 * h + 1], S.samp_h[3 * h + 2]};   // ransac_sample_kernel
         bool valid = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
@@ -69,10 +112,7 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     const int gid = a.queue[1 + qi];
     const int item = gid / a.iters, h = gid % a.iters;
     const SolverItem S = a.items[item];
-    const int m = *S.m_ptr;
-    int sample[3];
-    if (S.samples) { sample[0] = S.samples[3 * h]; sample[1] = S.samples[3 * h + 1]; sample[2] = S.samples[3 * h + 2]; }
-    else viso_sample3(a.seed, S.frame, h, m, sample);
+    const int sample[3] = {S.samp_h[3 * h], S.samp_h[3 * h + 1], S.samp_h[3 * h + 2]};   // ransac_sample_kernel
     const SolverParamsDev& sp = a.sp;
     const double* X = S.X;
     const double* obs = S.obs;
@@ -366,7 +406,11 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), s));
-        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(ransac_sample_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
+        // 200 waves go to 50 CUs instead of one to each of 200
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         const long long cb = (nh + 3) / 4;
         hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)(cb < 128 ? cb : 128)), dim3(256), 0, s, a);
@@ -528,15 +572,16 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     HIP_TRY(hipMemcpyAsync(dtr, best_tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
     int hm[4] = {m, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, c->stream));
+    int* dqueue;   // undecided-hypothesis list, then the triples in use
+    if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&dqueue)) < 0) return r;
     SolverItem it{};
     it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.samples = dsamp; it.frame = frame;
+    it.samp_h = dqueue + 2 + iters;
     it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + iters;
     it.tr = dtr; it.ok = dmisc + 1; it.n_inl = dmisc + 2; it.inl = dinl;
     HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    int* dqueue;
-    if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + (size_t)iters), (void**)&dqueue)) < 0) return r;
     if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue)) < 0) return r;
     int res[4];
     HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));

@@ -146,12 +146,17 @@ __device__ __forceinline__ int lu_solve6(double A[6][6], double b[6]) {
         }
         if (best < DBL_EPSILON) return 0;
 #pragma unroll
-        for (int j = i + 1; j < 6; ++j) {
-            if (k == j) {
+        for (int j = i + 1; j < 6; ++j) {   // selects, not a branch: the compiler turns a predicated swap into a
+            const bool sw = k == j;         // dynamically indexed row access, i.e. the matrix into scratch memory
 #pragma unroll
-                for (int c = i; c < 6; ++c) { const double t = A[i][c]; A[i][c] = A[j][c]; A[j][c] = t; }
-                const double t = b[i]; b[i] = b[j]; b[j] = t;
+            for (int c = i; c < 6; ++c) {
+                const double ti = A[i][c], tj = A[j][c];
+                A[i][c] = sw ? tj : ti;
+                A[j][c] = sw ? ti : tj;
             }
+            const double ti = b[i], tj = b[j];
+            b[i] = sw ? tj : ti;
+            b[j] = sw ? ti : tj;
         }
         const double d = -1 / A[i][i];
 #pragma unroll
