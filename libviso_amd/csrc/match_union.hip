@@ -182,7 +182,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     // window base (scalar) + 32-bit byte offset per lane: (window position << 8) | (sub << 4)
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
     uint32_t* ul = s_ul[wave];
-    const int g8 = lane >> 3, sub = lane & 7;
+    const int sub = lane & 7;
     const int half = lane >> 5;          // phase 1: lanes 0..31 test queries 0..3 of the round, lanes 32..63 queries 4..7
     unsigned long long scored = 0;
     constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 2 rounds of 8 queries per wave
@@ -318,6 +318,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         tr.m1 = 0xffffffffu; tr.m2 = 0xffffffffu;
         {
             const int npass = (nu + 7) >> 3;
+            // the lane group's list position, derived HERE: as a loop invariant of the round loop its LDS address stays
+            // live across phase 1 and is the one register too many (a spill: scratch memory for every wave of the launch)
+            int g8 = lane;
+            asm volatile("" : "+v"(g8));
+            g8 >>= 3;
             u32x4 r0[MU_NP], r1[MU_NP];
             uint32_t ent[MU_NP];
 #define MU_ISSUE(SLOT, T)                                                                                  \

@@ -13,6 +13,7 @@ struct SolverArgs {
     int iters;
     unsigned long long seed;
     SolverParamsDev sp;
+    int split;    // iterations done by ransac_hyp_kernel (VISO_GN_SPLIT)
     int* queue;   // [0] = number of undecided hypotheses, [1..] = item * iters + h of each (any order)
 };
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
         bool valid = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
-        if (valid) ok = gn_serial<3>(S.X, S.obs, S.ld, sample, tr, a.sp, 0, VISO_GN_SPLIT);
+        if (valid) ok = gn_serial<3>(S.X, S.obs, S.ld, sample, tr, a.sp, 0, a.split);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
         if (lane < 21) { ep = row; eq = row + e; } else { ep = min(lane - 21, 5); eq = 0; }
     }
     int ok = 0;
-    for (int it = VISO_GN_SPLIT; it < 100; ++it) {
+    for (int it = a.split; it < 100; ++it) {
         // rotation: one sincos per lane (lanes 0..2 matter), then the table of solver_dev.h
         double sv, cv;
         const int l3 = lane % 3;
@@ -402,6 +403,7 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     if (n_items <= 0) return VISO_OK;
     SolverArgs a;
     a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
+    a.split = VISO_GN_SPLIT;
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
