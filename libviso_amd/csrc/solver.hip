@@ -213,27 +213,56 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     }
 }
 
-// ---- stage 2: one wave per (frame, hypothesis): support set size -----------
-__global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a) {
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= a.n_items * a.iters) return;
-    const int item = wave / a.iters, h = wave % a.iters;
+// ---- stage 2: support set sizes (get_inliers per hypothesis, src/viso.cpp:1561-1562) -------------------------
+// Workgroup = one frame x INL_H hypotheses.  Lanes 0..INL_H-1 build the rotations (make_rot once per hypothesis, not
+// once per lane of a wave per hypothesis) into LDS; then every thread keeps one point of the frame in registers and
+// walks the hypotheses, reading R as LDS broadcasts: ballot + popcount per wave, one LDS atomic per (wave, hypothesis).
+#define INL_H 10
+__global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a, int groups) {
+    __shared__ double s_R[INL_H][12];
+    __shared__ int s_ok[INL_H];
+    __shared__ int s_cnt[INL_H];
+    const int item = blockIdx.x / groups, h0 = (blockIdx.x % groups) * INL_H;
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
-    int cnt = 0;
-    if (S.ok_h[h]) {
-        double tr[6];
+    const int nh = min(INL_H, a.iters - h0);
+    const int lane = threadIdx.x & 63;
+    if ((int)threadIdx.x < nh) {
+        const int h = h0 + threadIdx.x;
+        const int ok = S.ok_h[h];
+        s_ok[threadIdx.x] = ok;
+        s_cnt[threadIdx.x] = 0;
+        if (ok) {
+            double tr[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * h + j];
-        RotDev R;
-        make_rot(tr, R);
-        for (int base = 0; base < m; base += 64) {
-            const int i = base + lane;
-            const bool in = (i < m) && is_inlier(R, a.sp, S.X, S.obs, S.ld, i, nullptr);
-            cnt += __popcll(__ballot(in));
+            for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * h + j];
+            RotDev R;
+            make_rot(tr, R);
+            double* o = s_R[threadIdx.x];
+            o[0] = R.r00; o[1] = R.r01; o[2] = R.r02; o[3] = R.r10; o[4] = R.r11; o[5] = R.r12;
+            o[6] = R.r20; o[7] = R.r21; o[8] = R.r22; o[9] = R.tx; o[10] = R.ty; o[11] = R.tz;
         }
     }
-    if (lane == 0) S.cnt_h[h] = cnt;
+    __syncthreads();
+    for (int base = 0; base < m; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool have = i < m;
+        const int ii = have ? i : 0;
+        const double X0 = S.X[0 * S.ld + ii], X1 = S.X[1 * S.ld + ii], X2 = S.X[2 * S.ld + ii];
+        const double o0 = S.obs[0 * S.ld + ii], o1 = S.obs[1 * S.ld + ii], o2 = S.obs[2 * S.ld + ii], o3 = S.obs[3 * S.ld + ii];
+        for (int k = 0; k < nh; ++k) {
+            if (!s_ok[k]) continue;   // uniform
+            RotDev R;                 // only the entries predict_point reads
+            const double* r = s_R[k];
+            R.r00 = r[0]; R.r01 = r[1]; R.r02 = r[2]; R.r10 = r[3]; R.r11 = r[4]; R.r12 = r[5];
+            R.r20 = r[6]; R.r21 = r[7]; R.r22 = r[8]; R.tx = r[9]; R.ty = r[10]; R.tz = r[11];
+            const bool in = have && is_inlier_pt(R, a.sp, X0, X1, X2, o0, o1, o2, o3, nullptr);
+            const int c = __popcll(__ballot(in));
+            if (lane == 0 && c) atomicAdd(&s_cnt[k], c);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nh) S.cnt_h[h0 + threadIdx.x] = s_cnt[threadIdx.x];   // 0 for failed hypotheses
 }
 
 // ---- workgroup helpers ------------------------------------------------------
@@ -398,6 +427,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
     }
 }
 
+
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
                   unsigned long long seed, const SolverParamsDev& sp, int* queue) {
     if (n_items <= 0) return VISO_OK;
@@ -417,7 +447,8 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
         const long long cb = (nh + 3) / 4;
         hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)(cb < 128 ? cb : 128)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
+        const int groups = (iters + INL_H - 1) / INL_H;
+        hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(n_items * groups)), dim3(256), 0, s, a, groups);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(n_items), dim3(REFIT_THREADS), 0, s, a);

@@ -60,17 +60,22 @@ __device__ __forceinline__ void predict_point(const RotDev& R, const SolverParam
 }
 
 // squared reprojection error test of get_inliers (src/viso.cpp:1524-1533)
-__device__ __forceinline__ bool is_inlier(const RotDev& R, const SolverParamsDev& sp, const double* X,
-                                          const double* obs, int ld, int i, double* err2_out) {
+__device__ __forceinline__ bool is_inlier_pt(const RotDev& R, const SolverParamsDev& sp, double X0, double X1, double X2,
+                                             double o0, double o1, double o2, double o3, double* err2_out) {
     double pred[4], X1c, Y1c, Z1c, X2c;
-    predict_point(R, sp, X[0 * ld + i], X[1 * ld + i], X[2 * ld + i], pred, X1c, Y1c, Z1c, X2c);
-    const double e0 = obs[0 * ld + i] - pred[0];
-    const double e1 = obs[1 * ld + i] - pred[1];
-    const double e2 = obs[2 * ld + i] - pred[2];
-    const double e3 = obs[3 * ld + i] - pred[3];
+    predict_point(R, sp, X0, X1, X2, pred, X1c, Y1c, Z1c, X2c);
+    const double e0 = o0 - pred[0];
+    const double e1 = o1 - pred[1];
+    const double e2 = o2 - pred[2];
+    const double e3 = o3 - pred[3];
     const double err2 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
     if (err2_out) *err2_out = err2;
     return err2 < sp.inlier_threshold * sp.inlier_threshold;
+}
+__device__ __forceinline__ bool is_inlier(const RotDev& R, const SolverParamsDev& sp, const double* X,
+                                          const double* obs, int ld, int i, double* err2_out) {
+    return is_inlier_pt(R, sp, X[0 * ld + i], X[1 * ld + i], X[2 * ld + i],
+                        obs[0 * ld + i], obs[1 * ld + i], obs[2 * ld + i], obs[3 * ld + i], err2_out);
 }
 
 // Adds the 4 Jacobian rows and residuals of one active point to the normal
