@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames", type=int, default=256, help="frame pairs per batch (per GPU)")
+    ap.add_argument("--frames", type=int, default=512, help="frame pairs per batch (per GPU)")
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
@@ -301,7 +301,7 @@ def main():
     kname = libviso_amd.matcher_kernel_name(ctx)
     pairs = int(scored[1:].sum())              # the timed kernel takes the temporal problems (2 of 3 calls, ~97 % of the pairs)
     t_k = kern_ms * 1e-3
-    default_workload = (args.frames, args.kp, args.width, args.height, args.clustered) == (256, 2000, 1241, 376, 0.0)
+    default_workload = (args.frames, args.kp, args.width, args.height, args.clustered) == (512, 2000, 1241, 376, 0.0)
     pmc = load_pmc(kname, default_workload)
     ceilings = {}
     # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
@@ -397,7 +397,7 @@ def main():
     # lanes' kernels.
     streaming = None
     iseq = None
-    nfi = min(nf, 65)
+    nfi = min(nf, 129)
     if not args.no_streaming:
         hosts = []
         for rev in (False, True):

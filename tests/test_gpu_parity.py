@@ -225,6 +225,22 @@ def test_ransac_minimize_reproj(viso, oracle, seed):
     assert ok0 == ok1 and np.array_equal(inl0, inl1) and rel_fro(libviso_amd.tr2mat(tr1), oracle.tr2mat(tr0)) < POSE_TOL
 
 
+@pytest.mark.parametrize("m", [3, 4, 5, 63, 64, 65, 127, 129, 700, 3000])
+def test_ransac_device_drawn_triples_equal_the_host_stream(viso, oracle, m):
+    """ransac_sample_kernel walks the splitmix64 selection-sampling stream 64 candidates at a time (src/viso.cpp:88-107
+    restated); its triples must be the ones viso_ransac_samples / the oracle draw one candidate at a time: a run that
+    draws on the device equals, bit for bit, a run that is handed the host's triples."""
+    X, obs, tr_gt, param = synth.make_solver_case(77 + m, m=m, outlier_frac=0.25 if m > 8 else 0.0, noise=0.2)
+    for seed, frame in ((0, 0), (5, 17), (2**40 + 3, 2**33)):
+        s_host = libviso_amd.ransac_samples(seed, frame, param.ransac_iter, m)
+        assert np.array_equal(s_host, oracle.ransac_samples(seed, frame, param.ransac_iter, m).reshape(-1, 3))
+        ok_d, tr_d, inl_d = libviso_amd.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame)
+        ok_h, tr_h, inl_h = libviso_amd.ransac_minimize_reproj(X, obs, param, samples=s_host)
+        assert ok_d == ok_h and np.array_equal(inl_d, inl_h) and np.array_equal(tr_d, tr_h)
+        ok_o, tr_o, inl_o = oracle.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame)
+        assert ok_d == ok_o and np.array_equal(inl_d, inl_o)
+
+
 def test_ransac_failure_modes(viso, oracle):
     X, obs, tr_gt, param = synth.make_solver_case(5, m=40, outlier_frac=0.0, noise=0.1)
     assert libviso_amd.ransac_minimize_reproj(X[:, :2].copy(), obs[:, :2].copy(), param)[0] == 0   # m < 3
