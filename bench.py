@@ -43,12 +43,14 @@ L2_GATHER_PEAK_GBS = 18800.0   # "Indexed rows: gather": rows shared by every wo
 L2_STREAM_PEAK_GBS = 34500.0   # "L2 (per XCD)": aggregate
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 CLK_GHZ = 2.4                  # max clock
-# Cycles a wave64 VALU instruction occupies its SIMD.  gfx950's SIMDs are 16 lanes wide for non-packed VALU work: the
-# 157.3 TFLOP/s FP32 vector spec is 1024 SIMDs x 16 lanes x 2 (packed v_pk_fma_f32) x 2 flop x 2.4 GHz, and
-# tools/valu_rate.hip (8 waves per SIMD, independent chains; profiles/r02_valu_rate.txt) measures 3.96 cycles per
-# v_fma_f32, 4.58 per v_sad_u16, 4.48 per DPP add, 4.57 per v_med3_u32.  4 is the optimistic figure: the ceiling
-# below is the hardware's, the matcher's instruction mix is slightly slower than it.
-VALU_CYCLES = 4
+# VALU issue on gfx950 (tools/valu_rate.hip, 8 waves per SIMD of independent chains; profiles/r02_valu_rate.txt):
+# plain 32-bit add / sub / logic / mov / v_fma_f32 issue at the FULL rate, one wave64 instruction per 2 cycles per SIMD
+# (the guide's figure, the 157.3 TFLOP/s FP32 spec; measured 2.4-2.7); every other opcode the matcher's loop is made
+# of is a HALF-rate opcode, 4 cycles (measured: v_sad_u16 4.56, DPP adds 4.47, v_med3_u32 4.43, v_min_u32 4.27,
+# v_cndmask_b32 4.26, v_lshl_or_b32 4.42, v_cmp 4.58).  The VALU-issue ceiling below is the nominal full rate; the
+# v_sad_u16 ceiling is that opcode's own (half) rate.
+VALU_CYCLES_FULL = 2
+VALU_CYCLES_SAD = 4
 L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
 PROFILE_ROUND = "r02"
 
@@ -305,11 +307,13 @@ def main():
     pmc = load_pmc(kname, default_workload)
     ceilings = {}
     # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
-    # elements = one (query, candidate) pair; a SIMD issues one VALU wave-instruction per VALU_CYCLES
-    sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES
+    # elements = one (query, candidate) pair; v_sad_u16 is a half-rate opcode (one per 4 cycles per SIMD)
+    sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_SAD
+    valu_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_FULL
     ceilings["sad_valu"] = {"achieved": pairs / t_k, "peak": sad_peak, "unit": "scored pairs/s",
                             "frac": pairs / t_k / sad_peak,
-                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each, 4 cycles per wave-instruction per SIMD (16 lanes wide; tools/valu_rate.hip measures 4.58), 1024 SIMDs at 2.4 GHz"}
+                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each; a half-rate opcode: 4 cycles per wave-instruction per SIMD (tools/valu_rate.hip measures 4.56), 1024 SIMDs at 2.4 GHz"}
+    valu_busy = None
     if pmc["hbm_bytes"] is not None:
         a = pmc["hbm_bytes"] / t_k / 1e9
         ceilings["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -317,10 +321,19 @@ def main():
     if pmc["sq"] is not None:
         sq = pmc["sq"]
         if "SQ_INSTS_VALU" in sq:
-            v = sq["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * CLK_GHZ * 1e9) / t_k
-            ceilings["valu_issue"] = {"achieved": sq["SQ_INSTS_VALU"] / t_k, "peak": sad_peak, "unit": "VALU wave-instructions/s",
-                                      "frac": v, "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
-                                                         "v_sad_u16 share of the instructions: see profiles/README.md"}
+            a = sq["SQ_INSTS_VALU"] / t_k
+            ceilings["valu_issue"] = {"achieved": a, "peak": valu_peak, "unit": "VALU wave-instructions/s", "frac": a / valu_peak,
+                                      "what": "SQ_INSTS_VALU / kernel time against the NOMINAL issue rate (every opcode at the full rate: "
+                                              "one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz). ~90 % of the kernel's "
+                                              "instructions are half-rate opcodes (v_sad_u16, DPP adds, selects, v_med3/v_min): see valu_busy"}
+            if "SQ_ACTIVE_INST_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
+                cyc = sq["GRBM_GUI_ACTIVE"] / 8.0            # rocprofv3 sums the 8 XCDs: shader cycles of one launch
+                valu_busy = {"rocprof_VALUBusy": sq["SQ_ACTIVE_INST_VALU"] / 256.0 / cyc,
+                             "cycles_per_valu_instruction_per_simd": cyc * N_SIMD / sq["SQ_INSTS_VALU"],
+                             "note": "rocprofv3's VALUBusy formula (SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE per XCD; the counter books "
+                                     "one quad-cycle per instruction, so the ~10 % full-rate instructions push it past 1): the vector ALUs "
+                                     "never idle. A SIMD issues one VALU instruction every ~3.85 shader cycles, the mix of 4-cycle and "
+                                     "2-cycle opcodes above: what is left to gain is fewer instructions, not a higher issue rate"}
         if "TCP_TCC_READ_REQ_sum" in sq:
             l2b = sq["TCP_TCC_READ_REQ_sum"] * L2_REQ_BYTES
             peak = L2_GATHER_PEAK_GBS if kname == "match_union_kernel" else L2_STREAM_PEAK_GBS
@@ -338,6 +351,7 @@ def main():
         "kernel_ms_in_timed_region_overlapped": kern_ms_region,
         "kernel_ms_in_timed_region_note": f"{n_streams} batches in flight share the CUs: not a per-step cost, may exceed ms_per_step",
         "ceilings": ceilings,
+        "valu_busy": valu_busy,
         "scored_pairs_per_launch": pairs,
         "overflow_queries_per_step": n_overflow,
         "overflow_note": "queries of one step (all three calls) handed to match_overflow_kernel: K cap, exact SAD tie, LDS list overflow",

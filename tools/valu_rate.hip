@@ -1,6 +1,7 @@
 // valu_rate.hip — what one SIMD of gfx950 sustains for the instructions the matcher's scoring loop is made of.
-// Every wave runs ITERS iterations of UNROLL independent chains of one instruction kind; 8 waves per SIMD; the
-// figure printed is cycles per wave-instruction per SIMD (wall time x clock x SIMDs / instructions).
+// Every wave runs ITERS iterations of CHAINS independent chains of one instruction kind; 8 waves per SIMD.  Two
+// figures per kind: cycles per wave-instruction per SIMD from the wall time at the nominal clock, and from the
+// shader-cycle counter read inside the kernel (s_memtime ticks = shader cycles: no clock assumption, no launch ramp).
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_rate.hip -o tools/valu_rate && tools/valu_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -10,13 +11,15 @@
 #define CHAINS 8
 
 template <int KIND>
-__global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed) {
+__global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed, unsigned long long* cyc) {
     uint32_t a[CHAINS], b = seed ^ threadIdx.x, c = seed * 3u + blockIdx.x;
     double d[CHAINS], db = 1.0 + 1e-9 * threadIdx.x, dc = 1e-12 * seed;
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) d[i] = 1.0 + i * 0.001;
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) a[i] = seed + i * 77u + threadIdx.x;
+    const unsigned long long sel = seed * 0x9E3779B97F4A7C15ULL;   // a lane mask for v_cndmask
+    const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < CHAINS; ++i) {
@@ -33,8 +36,33 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed)
             if (KIND == 11) asm volatile("v_add_f64 %0, %1, %0" : "+v"(d[i]) : "v"(db));
             if (KIND == 12) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(d[i]) : "v"(db));
             if (KIND == 13) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+            if (KIND == 14) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(sel));
+            if (KIND == 15) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 16) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));
+            if (KIND == 17) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 18) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+            if (KIND == 19) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));
+            if (KIND == 20) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (KIND == 21) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(a[i]));
+            if (KIND == 22) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (KIND == 23) asm volatile("v_max_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 24) asm volatile("v_or_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 25) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 26) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 27) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (KIND == 28) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+            if (KIND == 29) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+            if (KIND == 30) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (KIND == 31) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (KIND == 32) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 33) asm volatile("v_add_u32_dpp %0, %1, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+            if (KIND == 34) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(a[i]) : "v"(b));
+            if (KIND == 35) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (KIND == 36) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         }
     }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;   // wave 0 of the workgroup
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) s += a[i] + (uint32_t)d[i];
@@ -42,21 +70,30 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed)
 }
 
 template <int KIND>
-static void run(const char* name, uint32_t* d, double clk_ghz) {
+static void run(const char* name, uint32_t* d, double clk_ghz, int per_iter = 1) {
     const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU: 8 waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d, 1u);
+    static unsigned long long* dc = nullptr;
+    if (!dc) hipMalloc(&dc, sizeof(unsigned long long) * blocks);
+    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d, 1u, dc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d, 2u);
+    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d, 2u, dc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double insts = (double)blocks * 4 * ITERS * CHAINS;   // wave-instructions
+    const double insts = (double)blocks * 4 * ITERS * CHAINS * per_iter;   // wave-instructions
     const double cyc = ms * 1e-3 * clk_ghz * 1e9 * 1024 / insts;
-    printf("%-28s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at %.2f GHz)\n", name, ms, cyc, clk_ghz);
+    static unsigned long long hc[256 * 8];
+    hipMemcpy(hc, dc, sizeof(hc), hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (int i = 0; i < blocks; ++i) sum += (double)hc[i];
+    // a wave's loop lasts `ticks` shader cycles while its SIMD issues the streams of 8 waves
+    const double true_cyc = sum / blocks / (8.0 * ITERS * CHAINS * per_iter);
+    printf("%-28s %8.3f ms  %6.2f cycles per wave-instruction per SIMD at the nominal %.2f GHz, %6.2f by the shader-cycle counter\n",
+           name, ms, cyc, clk_ghz, true_cyc);
 }
 
 int main() {
@@ -78,5 +115,28 @@ int main() {
     run<11>("v_add_f64", d, ghz);
     run<12>("v_mul_f64", d, ghz);
     run<13>("v_rcp_f64", d, ghz);
+    run<14>("v_cndmask_b32 (sgpr mask)", d, ghz);
+    run<22>("v_cmp_lt_u32 + v_cndmask", d, ghz, 2);
+    run<15>("v_and_b32", d, ghz);
+    run<24>("v_or_b32", d, ghz);
+    run<16>("v_lshlrev_b32", d, ghz);
+    run<17>("v_sub_u32", d, ghz);
+    run<23>("v_max_u32", d, ghz);
+    run<18>("v_mov_b32", d, ghz);
+    run<19>("v_lshl_add_u32", d, ghz);
+    run<20>("v_add3_u32", d, ghz);
+    run<21>("v_bfe_u32", d, ghz);
+    run<25>("v_add_f32", d, ghz);
+    run<26>("v_mul_lo_u32", d, ghz);
+    run<27>("v_cndmask_b32_e32 (vcc)", d, ghz);
+    run<28>("v_cmp_lt_u32_e32", d, ghz);
+    run<29>("v_mov_b32 dpp quad_perm", d, ghz);
+    run<33>("v_add_u32 dpp half_mirror", d, ghz);
+    run<30>("v_pk_sub_u16", d, ghz);
+    run<31>("v_pk_max_u16", d, ghz);
+    run<32>("v_xor_b32", d, ghz);
+    run<34>("v_alignbit_b32", d, ghz);
+    run<35>("v_perm_b32", d, ghz);
+    run<36>("v_bfi_b32", d, ghz);
     return 0;
 }
