@@ -403,6 +403,21 @@ def main():
                "workload": "configs[2]: matcher + circle join + RANSAC/Gauss-Newton",
                "poses_ok": int(ok[1:].sum()), "frames": int(args.frames),
                "max_abs_tr_err_vs_ground_truth": err}
+        # the per-frame use of the reference's loop (one new frame pair at a time, pose needed before the next frame):
+        # a 1-pair batch, host buffers in, pose out, synchronous -- latency, not throughput
+        lb = libviso_amd.Batch(ctx, 2, args.kp)
+        lb.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
+        lat = []
+        for i in range(24):
+            t0 = time.perf_counter()
+            lb.upload(seq["kp"][i:i + 2], seq["desc"][i:i + 2], seq["n"][i:i + 2])
+            lb.run()
+            lb.poses()
+            lat.append(time.perf_counter() - t0)
+        lb.close()
+        e2e["latency_one_pair"] = {"ms_median": float(np.median(lat[4:]) * 1e3), "ms_min": float(np.min(lat[4:]) * 1e3),
+                                   "what": "viso_batch_upload (pageable host memory, 2 frames) + viso_batch_run + viso_batch_get_poses of a "
+                                           "1-pair batch, wall time per call sequence; the oracle needs ~35 ms for the same frame on one core"}
 
     # ---- streaming: every step consumes fresh host frames (pinned, asynchronous, stream ordered) -------------
     # sequence_odometry reads new images every frame (src/viso.cpp:1205-1231); the resident figures above never
