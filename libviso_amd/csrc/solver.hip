@@ -1,10 +1,13 @@
 // solver.hip — RANSAC + Gauss-Newton stereo reprojection pose solver kernels
 // (reference src/viso.cpp:1543-1580 ransac_minimize_reproj, :1583-1623
-// minimize_reproj, :1509-1537 get_inliers).  Latency-bound fp64 work: all
-// hypotheses of all frames run concurrently (one lane per 3-point hypothesis),
-// support sets are counted one wave per hypothesis, and the all-inlier refit
-// builds J^T J / J^T r per iteration as a workgroup reduction with the 6x6 LU
-// solve on one lane — the whole loop stays on the device.
+// minimize_reproj, :1509-1537 get_inliers).  Latency-bound fp64 work: the sample
+// triples of all hypotheses are drawn by one wave each, all hypotheses of all
+// frames then run concurrently (one lane per 3-point hypothesis; the few that
+// need more than VISO_GN_SPLIT iterations continue one wave each), support sets
+// are counted per frame x 10 hypotheses, and the all-inlier refit builds
+// J^T J / J^T r per iteration as a workgroup reduction with the 6x6 LU solve on
+// one lane — the whole loop stays on the device.  No kernel here uses scratch
+// memory (check with -Rpass-analysis=kernel-resource-usage after any change).
 #include "solver_dev.h"
 
 struct SolverArgs {
