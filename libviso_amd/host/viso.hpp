@@ -103,6 +103,13 @@ Matd F_from_P(const Matd& P1, const Matd& P2);
 // src/estimation.h:7-9 — Procrustes; dead on the stereo path, kept for the header surface.
 // A, B: 3 x n.  T: 4 x 4 with [R|t] minimising sum |R b_i + t - a_i|^2 (the reference's argument order).
 void solveRigidMotion(const Matf& A, const Matf& B, Matf& T);
+// solveRigidMotion as a closed-form start for the Gauss-Newton solve (optional: the reference starts every solve
+// from 0, src/viso.cpp:1557, and never calls its Procrustes).  procrustes_tr triangulates the current observations
+// (:1137-1162), aligns them with the previous frame's points X over `active` and returns the motion in tr2mat's
+// parametrisation (rx, ry, rz, tx, ty, tz); minimize_reproj_from_procrustes runs minimize_reproj from there.
+std::vector<double> procrustes_tr(const Matd& X, const Matd& observe, const param& param, const std::vector<int>& active);
+bool minimize_reproj_from_procrustes(const Matd& X, const Matd& observe, std::vector<double>& tr, const param& param,
+                                     const std::vector<int>& active);
 
 // One stereo frame as the front-end hands it to the hot path: what
 // detector.detect + extractor.compute produce at src/viso.cpp:1226-1231.

@@ -233,6 +233,43 @@ void solveRigidMotion(const Matf& A, const Matf& B, Matf& T) {
     T.at(3, 3) = 1.f;
 }
 
+// Procrustes start for the GN solve (see viso.hpp).  Points whose disparity is not positive are left out.
+std::vector<double> procrustes_tr(const Matd& X, const Matd& observe, const param& p, const std::vector<int>& active) {
+    if (X.rows != 3 || observe.rows != 4 || X.cols != observe.cols)
+        throw std::invalid_argument("procrustes_tr: X 3xM, observe 4xM expected");
+    std::vector<int> use;
+    for (int i : active) {
+        if (i < 0 || i >= X.cols) throw std::invalid_argument("procrustes_tr: active index out of range");
+        if (observe.at(0, i) - observe.at(2, i) > 0) use.push_back(i);
+    }
+    if (use.size() < 3) return std::vector<double>(6, 0.0);
+    const int n = (int)use.size();
+    Matf A(3, n), B(3, n), T;
+    for (int k = 0; k < n; ++k) {
+        const int i = use[k];
+        const double d = observe.at(0, i) - observe.at(2, i);                      // triangulate_rectified, :1137-1162
+        A.at(0, k) = (float)(p.base * (observe.at(0, i) - p.calib.cu) / d);
+        A.at(1, k) = (float)(p.base * (observe.at(1, i) - p.calib.cv) / d);
+        A.at(2, k) = (float)(p.calib.f * p.base / d);
+        for (int r = 0; r < 3; ++r) B.at(r, k) = (float)X.at(r, i);
+    }
+    solveRigidMotion(A, B, T);                                                     // T * X_prev = X_cur
+    // tr2mat's rotation (src/viso.cpp:109-133): r02 = sy, r12 = -sx cy, r22 = cx cy, r01 = -cy sz, r00 = cy cz
+    const double r02 = std::min(1.0, std::max(-1.0, (double)T.at(0, 2)));
+    std::vector<double> tr(6);
+    tr[1] = std::asin(r02);
+    tr[0] = std::atan2(-(double)T.at(1, 2), (double)T.at(2, 2));
+    tr[2] = std::atan2(-(double)T.at(0, 1), (double)T.at(0, 0));
+    for (int r = 0; r < 3; ++r) tr[3 + r] = T.at(r, 3);
+    return tr;
+}
+
+bool minimize_reproj_from_procrustes(const Matd& X, const Matd& observe, std::vector<double>& tr, const param& p,
+                                     const std::vector<int>& active) {
+    tr = procrustes_tr(X, observe, p, active);
+    return minimize_reproj(X, observe, tr, p, active);
+}
+
 // ---- sequence_odometry ------------------------------------------------------
 namespace {
 struct Ctx {

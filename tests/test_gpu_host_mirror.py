@@ -94,3 +94,13 @@ def test_kitti_driver_on_images(oracle, tmp_path):
     r = subprocess.run([exe, "sub", "07", "2", "4"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert np.loadtxt(os.path.join(home, "results", "07", "sub", "data", "07.txt")).reshape(-1, 12).shape[0] == 3
+
+
+def test_procrustes_start_for_the_gn_solve():
+    """solveRigidMotion (reference src/estimation.cpp:29-51, dead on the reference's stereo path) wired as the optional
+    closed-form start of minimize_reproj (viso.hpp: procrustes_tr / minimize_reproj_from_procrustes): close to the true
+    motion, converges near the true pose, and to the pose the reference's zero start reaches whenever that start moves at
+    all (Q7, src/viso.cpp:1610: a first step with only negative components ends the reference's solve at zero)."""
+    exe = os.path.join(os.path.dirname(libviso_amd.SO_PATH), "viso_host_gputest")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "gputest ok" in r.stdout, r.stdout + r.stderr
