@@ -880,42 +880,160 @@ int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int 
 
 // ------------------------------------------------------------------ sort
 // std::sort(match, by [2]) of src/viso.cpp:724 with the documented total order
-// (dist asc, i1 asc).  One workgroup per problem; keys (dist<<32 | i1) in LDS,
-// bitonic network; rejected queries carry ~0 and sink to the end, so the sort
-// is also the compaction.  Also emits pos[i1] (row of query i1, or -1) for the
-// circle join, and the match count.
+// (dist asc, i1 asc).  One workgroup per problem; keys (dist<<32 | i1) of the accepted queries in LDS (compacted:
+// rejected queries carry no key).  Also emits pos[i1] (row of query i1, or -1) for the circle join, and the match
+// count.
 #define VISO_SORT_THREADS 512
+#define VISO_SORT_NB 2048          // distance buckets of the fast path:
+#define VISO_SORT_FINE 1024        //   equal-width ones over the bulk, then 32 x 32 log-linear ones for the tail
+#define VISO_SORT_BMAX 128         // a fuller bucket sends the problem to the bitonic network
+#define VISO_SORT_FAST_MAX 8192    // keys the fast path's LDS arrays are sized for
 
+// Fast path: the keys are (dist << 32 | i1) with distinct i1.  Bucket the distances (power-of-two bucket width over
+// the bulk of the distribution, log-linear buckets for the tail; LDS histogram with returning atomics, scan, scatter of 16-bit indices), then every
+// key counts the smaller keys of ITS bucket (a handful): final row = bucket start + that count.  Five LDS round
+// trips instead of the 66 stages of a 2048-key bitonic network.  Distances piled into one bucket (all equal, say)
+// would make the counting quadratic: such problems (and those beyond VISO_SORT_FAST_MAX keys) take the network.
 __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const MatchProblem* probs,
-                                                                         int n_probs, int npad_alloc) {
+                                                                         int n_probs, int npad_alloc, int fast) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ int s_cnt;
+    __shared__ int s_start[VISO_SORT_NB + 1];
+    __shared__ uint32_t s_red[2][VISO_SORT_THREADS / 64];
+    __shared__ unsigned long long s_sum[VISO_SORT_THREADS / 64];
+    __shared__ int s_maxb;
     const int prob = blockIdx.x;
     if (prob >= n_probs) return;
     const MatchProblem P = probs[prob];
     const int n1 = *P.q.n;
-    // compaction first: only the accepted queries carry a key (the ratio test rejects about half of the temporal
-    // ones), so the network usually sorts half as many keys through fewer stages
-    int* s_cnt = reinterpret_cast<int*>(keys + npad_alloc);   // tail words of the dynamic LDS area
-    if (threadIdx.x == 0) *s_cnt = 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // compaction first: only the accepted queries carry a key (the ratio test rejects about half of the temporal ones)
+    if (threadIdx.x == 0) s_cnt = 0;
+    for (int b = threadIdx.x; b <= VISO_SORT_NB; b += VISO_SORT_THREADS) s_start[b] = 0;
     __syncthreads();
-    for (int base = 0; base < n1; base += VISO_SORT_THREADS) {
-        const int i = base + threadIdx.x;
-        unsigned long long k = ~0ull;
-        if (i < n1) {
-            const int2 r = P.res[i];
-            if (r.x >= 0) k = ((unsigned long long)(uint32_t)r.y << 32) | (uint32_t)i;
-            P.pos[i] = -1;
+    uint32_t dmn = 0xffffffffu, dmx = 0u;
+    unsigned long long dsum = 0;
+    for (int base0 = 0; base0 < n1; base0 += 4 * VISO_SORT_THREADS) {
+        int2 rv[4];   // four result loads in flight before the (serialising) LDS counter is touched
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base0 + u * VISO_SORT_THREADS + threadIdx.x;
+            rv[u] = i < n1 ? P.res[i] : make_int2(-1, 0);
         }
-        const bool valid = k != ~0ull;
-        const unsigned long long m = __ballot(valid);
-        int wbase = 0;
-        if ((threadIdx.x & 63) == 0 && m) wbase = atomicAdd(s_cnt, __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (valid) keys[wbase + mbcnt(m)] = k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base0 + u * VISO_SORT_THREADS + threadIdx.x;
+            if (base0 + u * VISO_SORT_THREADS >= n1) break;   // uniform
+            unsigned long long k = ~0ull;
+            if (i < n1) {
+                if (rv[u].x >= 0) k = ((unsigned long long)(uint32_t)rv[u].y << 32) | (uint32_t)i;
+                else P.pos[i] = -1;   // accepted queries get their row below
+            }
+            const bool valid = k != ~0ull;
+            if (valid) { dmn = min(dmn, (uint32_t)(k >> 32)); dmx = max(dmx, (uint32_t)(k >> 32)); dsum += k >> 32; }
+            const unsigned long long m = __ballot(valid);
+            int wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&s_cnt, __popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (valid) keys[wbase + mbcnt(m)] = k;
+        }
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        dmn = min(dmn, (uint32_t)__shfl_xor((int)dmn, o)); dmx = max(dmx, (uint32_t)__shfl_xor((int)dmx, o));
+        dsum += (unsigned long long)__shfl_xor((long long)dsum, o);
+    }
+    if (lane == 0) { s_red[0][wv] = dmn; s_red[1][wv] = dmx; s_sum[wv] = dsum; }
     __syncthreads();
-    const int mv = *s_cnt;
+    const int mv = s_cnt;
+    if (threadIdx.x == 0) *P.m_cnt = mv;
+    if (mv == 0) return;
+    bool use_fast = fast != 0;
+    if (use_fast) {
+        unsigned long long* bkeys = keys + npad_alloc;                     // the keys in bucket order
+        dsum = 0;
+#pragma unroll
+        for (int w = 0; w < VISO_SORT_THREADS / 64; ++w) { dmn = min(dmn, s_red[0][w]); dmx = max(dmx, s_red[1][w]); dsum += s_sum[w]; }
+        // Bucket map, monotone in the distance: the accepted matches sit in a narrow peak with a few far outliers, so
+        // VISO_SORT_FINE buckets of one power-of-two width cover [dmn, dmn + 2 (mean - dmn)] (at most [dmn, dmx]) and
+        // the tail behind them goes to log-linear buckets (32 per octave).
+        unsigned long long mean_off = dsum / (unsigned long long)mv - dmn;
+        for (int trim = 0; trim < 2; ++trim) {   // the mean of what lies within twice the mean, twice: outliers drop out
+            unsigned long long ts = 0;
+            unsigned int tn = 0;
+            for (int e = threadIdx.x; e < mv; e += VISO_SORT_THREADS) {
+                const unsigned long long off = (keys[e] >> 32) - dmn;
+                if (off <= 2 * mean_off) { ts += off; ++tn; }
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { ts += (unsigned long long)__shfl_xor((long long)ts, o); tn += (unsigned int)__shfl_xor((int)tn, o); }
+            __syncthreads();
+            if (lane == 0) { s_sum[wv] = ts; s_red[0][wv] = tn; }
+            __syncthreads();
+            ts = 0; tn = 0;
+#pragma unroll
+            for (int w = 0; w < VISO_SORT_THREADS / 64; ++w) { ts += s_sum[w]; tn += s_red[0][w]; }
+            mean_off = tn ? ts / tn : 0;
+        }
+        const unsigned long long span = min((unsigned long long)(dmx - dmn), 2 * mean_off + 1);
+        int sh = 0;
+        while (sh < 32 && (span >> sh) >= (unsigned long long)VISO_SORT_FINE) ++sh;
+        auto bucket_of_dist = [&](uint32_t d) -> int {
+            const uint32_t off = d - dmn, f = off >> sh;
+            if (f < (uint32_t)VISO_SORT_FINE) return (int)f;
+            const uint32_t t = off - ((uint32_t)VISO_SORT_FINE << sh) + 1u;     // >= 1
+            const int lg = 31 - __clz((int)t);
+            const uint32_t frac = lg >= 5 ? (t >> (lg - 5)) & 31u : (t << (5 - lg)) & 31u;
+            return VISO_SORT_FINE + lg * 32 + (int)frac;                         // < VISO_SORT_FINE + 1024
+        };
+#define SORT_BUCKET(D) bucket_of_dist((uint32_t)(D))
+        for (int e = threadIdx.x; e < mv; e += VISO_SORT_THREADS) atomicAdd(&s_start[SORT_BUCKET(keys[e] >> 32)], 1);
+        __syncthreads();
+        if (wv == 0) {   // exclusive scan of the bucket counts (32 per lane + wave scan), largest bucket
+            int c[VISO_SORT_NB / 64], tot = 0, big = 0;
+#pragma unroll
+            for (int q = 0; q < VISO_SORT_NB / 64; ++q) { c[q] = s_start[lane * (VISO_SORT_NB / 64) + q]; tot += c[q]; big = max(big, c[q]); }
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; big = max(big, __shfl_xor(big, o)); }
+            int run = incl - tot;
+#pragma unroll
+            for (int q = 0; q < VISO_SORT_NB / 64; ++q) { s_start[lane * (VISO_SORT_NB / 64) + q] = run; run += c[q]; }
+            if (lane == 0) s_maxb = big;
+        }
+        __syncthreads();
+        use_fast = s_maxb <= VISO_SORT_BMAX;
+        if (use_fast) {
+            // scatter into bucket order: the running offset of bucket b ends up at the bucket's END = start of b + 1
+            for (int e = threadIdx.x; e < mv; e += VISO_SORT_THREADS) {
+                const unsigned long long k = keys[e];
+                bkeys[atomicAdd(&s_start[SORT_BUCKET(k >> 32)], 1)] = k;
+            }
+            __syncthreads();
+            for (int p = threadIdx.x; p < mv; p += VISO_SORT_THREADS) {
+                const unsigned long long k = bkeys[p];
+                const int b = SORT_BUCKET(k >> 32);
+                const int s0 = b ? s_start[b - 1] : 0, s1 = s_start[b];
+                int r = s0;
+                int q = s0;
+                for (; q + 4 <= s1; q += 4) {   // independent LDS reads: four in flight
+                    const unsigned long long k0 = bkeys[q], k1 = bkeys[q + 1], k2 = bkeys[q + 2], k3 = bkeys[q + 3];
+                    r += (k0 < k ? 1 : 0) + (k1 < k ? 1 : 0) + (k2 < k ? 1 : 0) + (k3 < k ? 1 : 0);
+                }
+                for (; q < s1; ++q) r += bkeys[q] < k ? 1 : 0;
+                const int i1 = (int)(uint32_t)k;
+                const int2 rr = P.res[i1];
+                P.sorted[3 * r + 0] = i1;
+                P.sorted[3 * r + 1] = rr.x;
+                P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
+                P.pos[i1] = r;
+            }
+            return;
+        }
+#undef SORT_BUCKET
+    }
+    // the network: keys padded with ~0 to a power of two
     int npad = 64;
     while (npad < mv) npad <<= 1;
     for (int i = mv + threadIdx.x; i < npad; i += VISO_SORT_THREADS) keys[i] = ~0ull;
@@ -930,7 +1048,6 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
         P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
         P.pos[i1] = r;
     }
-    if (threadIdx.x == 0) *P.m_cnt = mv;
 }
 
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max) {
@@ -941,10 +1058,11 @@ int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int c
     }
     int npad = 64;
     while (npad < cap_max) npad <<= 1;
-    if ((size_t)npad * 8 + 16 > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)sort_matches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, npad * 8 + 16));
-    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS),
-                       (size_t)npad * sizeof(unsigned long long) + 16, s, probs_dev, n_probs, npad);
+    const int fast = npad <= VISO_SORT_FAST_MAX ? 1 : 0;
+    const size_t lds = (size_t)npad * sizeof(unsigned long long) * (fast ? 2 : 1) + 16;   // keys (+ the keys in bucket order)
+    if (lds > 40 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)sort_matches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS), lds, s, probs_dev, n_probs, npad, fast);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

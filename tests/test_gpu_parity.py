@@ -100,6 +100,29 @@ def test_match_desc_many_ties(viso, oracle, F):
         assert np.array_equal(libviso_amd.match_desc(kp1, kp2, d1, d2, mp), oracle.match_desc(kp1, kp2, d1, d2, mp))
 
 
+def test_match_list_order_with_piled_up_distances(viso, oracle):
+    """sort_matches_kernel ranks inside distance buckets; when the distances pile up (here: a few hundred matches with
+    the SAME SAD, then two values, then one outlier that stretches the bucket range) it must fall back to its network
+    and still deliver the (dist asc, i1 asc) order."""
+    rng = np.random.default_rng(11)
+    n = 600
+    kp = np.stack([rng.uniform(0, 600, n), rng.uniform(0, 300, n)], 1).astype(np.float32)
+    mp = MatchParams.temporal(); mp.enforce_2nd_best = 0; mp.radius = 3.0
+    kp2 = np.concatenate([np.array([[5000.0, 5000.0]], np.float32), kp])          # target 0 far away (Q1 never cuts)
+    base = rng.integers(-50, 50, (n, 121)).astype(np.float32)
+    for variant in range(3):
+        d1 = base.copy()
+        d2 = np.concatenate([np.zeros((1, 121), np.float32), base.copy()])
+        d2[1:, 0] += 7                                                            # every match: SAD 7
+        if variant >= 1:
+            d2[1::2, 1] += 3                                                      # half of them: SAD 10
+        if variant == 2:
+            d2[17, 2:40] += 900                                                   # one far outlier: wide bucket range
+        got = libviso_amd.match_desc(kp, kp2, d1, d2, mp)
+        want = oracle.match_desc(kp, kp2, d1, d2, mp)
+        assert len(want) > 500 and np.array_equal(got, want), variant
+
+
 def test_match_desc_extreme_values_and_general_path(viso, oracle):
     rng = np.random.default_rng(9)
     kp1, kp2, d1, d2 = rand_problem(rng, 120, 130, lo=-32768, hi=32768)   # full int16 range (fast path)
