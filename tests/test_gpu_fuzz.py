@@ -91,3 +91,49 @@ def test_match_desc_randomised(viso, oracle, variant):
         assert n_nonempty > 100
     finally:
         libviso_amd.set_matcher_variant(libviso_amd.DEFAULT_MATCHER)
+
+
+def _medium_case(rng, F):
+    """Image-sized problems: hundreds to thousands of keypoints with clusters, so that the tile / round / window
+    machinery of the batch kernels (union lists, stereo passes, overflow queue, bucket sort of the match list) runs at
+    its real sizes."""
+    n1, n2 = int(rng.integers(200, 2600)), int(rng.integers(200, 2600))
+    w, h = float(rng.choice([300, 1241, 2048])), float(rng.choice([100, 376, 1024]))
+
+    def pts(n):
+        k = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], 1)
+        if rng.random() < 0.5:   # clusters: dense blobs that overflow lists and K caps
+            nb = int(rng.integers(1, 6))
+            c = np.stack([rng.uniform(0, w, nb), rng.uniform(0, h, nb)], 1)
+            m = rng.random(n) < rng.uniform(0.2, 0.8)
+            k[m] = c[rng.integers(0, nb, m.sum())] + rng.normal(0, rng.uniform(2, 30), (m.sum(), 2))
+        if rng.random() < 0.5:
+            k = np.round(k)
+        return k.astype(np.float32)
+    kp2 = pts(n2)
+    kp1 = pts(n1)
+    lo, hi = (-4, 5) if rng.random() < 0.25 else (-1020, 1021)
+    d2 = rng.integers(lo, hi, (n2, 121)).astype(np.float32)
+    d1 = rng.integers(lo, hi, (n1, 121)).astype(np.float32)
+    k = int(rng.uniform(0, 0.9) * min(n1, n2))
+    if k:   # planted correspondences (small motion, descriptor noise)
+        src = rng.choice(n2, k, replace=False)
+        kp1[:k] = kp2[src] + rng.normal(0, 3, (k, 2)).astype(np.float32)
+        if rng.random() < 0.6:
+            kp1[:k, 1] = kp2[src, 1] + rng.normal(0, 0.4, k).astype(np.float32)   # near-rectified rows for the stereo gate
+        d1[:k] = d2[src] + rng.integers(-6, 7, (k, 121))
+    mp = MatchParams.stereo(F) if rng.random() < 0.45 else MatchParams.temporal()
+    mp.enforce_2nd_best = int(rng.random() < 0.6)
+    mp.max_neighbors = int(rng.choice([20, 50, 200, 250, 250, 1000]))
+    mp.radius = float(rng.choice([20, 80, 80, 80, 200]))
+    return kp1, kp2, d1, d2, mp
+
+
+def test_match_desc_randomised_image_sized(viso, oracle):
+    F = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+    rng = np.random.default_rng(777)
+    for it in range(int(os.environ.get("VISO_FUZZ_MEDIUM_ITERS", "6"))):   # VISO_FUZZ_MEDIUM_ITERS=200 for a soak
+        kp1, kp2, d1, d2, mp = _medium_case(rng, F if it % 3 else _random_F(rng, oracle))
+        want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+        got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+        assert np.array_equal(got, want), (it, len(kp1), len(kp2), mp.max_neighbors, mp.radius, mp.enforce_epipolar, mp.enforce_2nd_best)
