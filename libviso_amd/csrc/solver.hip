@@ -447,8 +447,12 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
         // 200 waves go to 50 CUs instead of one to each of 200
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        const long long cb = (nh + 3) / 4;
-        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)(cb < 128 ? cb : 128)), dim3(256), 0, s, a);
+        // one wave per undecided hypothesis: ~1-2 % of them; room for 2.5 % (waves without an item leave at once,
+        // hypotheses beyond the grid are taken in a second turn of the same waves)
+        long long cb = (nh / 40 + 3) / 4;
+        if (cb < 128) cb = 128;
+        if (cb > (nh + 3) / 4) cb = (nh + 3) / 4;
+        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         const int groups = (iters + INL_H - 1) / INL_H;
         hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(n_items * groups)), dim3(256), 0, s, a, groups);
