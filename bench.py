@@ -22,12 +22,21 @@ N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU; frames shard across ranks (each rank owns its own
 subsequence: weak scaling), no data-path collective; RCCL only gathers the
-final trajectory in the end-to-end leg.
+final trajectory in the end-to-end leg.  `python bench.py --gpus N` on its own
+starts those N ranks itself (a child process tree, before this process touches
+the GPU); a world size that is not --gpus is an error, never an N = 1 line.
+
+The timed region of K steps is repeated (at least 5 regions, at least ~0.6 s of
+GPU work in total): `value` is the median region, min / max are beside it.
 """
 import argparse
 import concurrent.futures
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,7 +61,7 @@ CLK_GHZ = 2.4                  # max clock
 VALU_CYCLES_FULL = 2
 VALU_CYCLES_SAD = 4
 L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def b_alg_bytes(n, scored, m_out, dlen=121):
@@ -102,28 +111,60 @@ def workload_name(args):
     return f"{tag}: {geo}, SAD matcher only (pack + 3 match_desc/frame + sort)"
 
 
+def kernel_source_sha():
+    """sha256 over the sources libviso_hip.so is built from (libviso_amd/csrc: *.hip, *.h, *.cpp, Makefile), in name
+    order.  tools/pmc_to_json.py and tools/pmc_summary.py store it in the counter files they write; load_pmc refuses
+    counters taken on other sources."""
+    d = os.path.join(ROOT, "libviso_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode() + b"\0")
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def load_pmc(kname, default_workload):
     """Counter figures of the committed rocprofv3 --pmc passes (profiles/, tools/profile_round.sh + tools/pmc_batch.sh,
     `--streams 1`, this command's defaults).  PMC counters cannot be read from inside this process; they are only
-    used when the workload is the one those passes ran."""
-    out = {"hbm_bytes": None, "sq": None, "src": []}
+    used when the workload is the one those passes ran AND the files carry the sha256 of the kernel sources this
+    tree holds: counters of another build are dropped, loudly."""
+    out = {"hbm_bytes": None, "sq": None, "src": [], "dropped": []}
     if not default_workload:
+        out["dropped"].append("not the workload of the committed counter passes")
         return out
-    p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm.json")
+    sha = kernel_source_sha()
+
+    def usable(d, name):
+        got = d.get("kernel_source_sha256")
+        if got == sha:
+            return True
+        out["dropped"].append(f"profiles/{name}: taken on sources {str(got)[:12]}, this tree is {sha[:12]} -> counters NOT used")
+        print(f"bench.py: PMC file profiles/{name} does not belong to these kernel sources; its ceilings are null "
+              f"(re-run tools/profile_round.sh + tools/pmc_batch.sh)", file=sys.stderr)
+        return False
+    name = f"{PROFILE_ROUND}_pmc_hbm.json"
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         d = json.load(open(p))
-        if kname in d.get("kernel", ""):
+        if kname in d.get("kernel", "") and usable(d, name):
             out["hbm_bytes"] = d["hbm_bytes_per_launch_corrected"]
-            out["src"].append(f"profiles/{PROFILE_ROUND}_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+            out["src"].append(f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                               "one stream, gfx950 x2 fetch correction)")
-    p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_sq.json")
+    else:
+        out["dropped"].append(f"profiles/{name} does not exist")
+    name = f"{PROFILE_ROUND}_pmc_sq.json"
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         d = json.load(open(p))
-        for k, v in d.items():
-            if kname in k:
-                out["sq"] = v
-                out["src"].append(f"profiles/{PROFILE_ROUND}_pmc_sq.json (rocprofv3 --pmc SQ_* / TCP_* passes, one stream)")
-                break
+        if usable(d, name):
+            for k, v in d.get("kernels", {}).items():
+                if kname in k:
+                    out["sq"] = v
+                    out["src"].append(f"profiles/{name} (rocprofv3 --pmc SQ_* / TCP_* passes, one stream)")
+                    break
+    else:
+        out["dropped"].append(f"profiles/{name} does not exist")
     return out
 
 
@@ -184,25 +225,48 @@ def main():
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--matcher", type=int, default=None, help="kernel for the temporal calls (viso_ctx_set_matcher); default: the build's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--images", action="store_true",
-                    help="also time the resident image-in pipeline (device-side descriptor extraction / Harris) on synthetic images")
+    ap.add_argument("--images", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-images", action="store_true",
+                    help="skip the resident image-in legs (device-side descriptor extraction / Harris on synthetic images)")
+    ap.add_argument("--min-region-seconds", type=float, default=0.6,
+                    help="the K-step timed region is repeated until this much GPU work has been timed (at least 5 regions)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight per GPU, one HIP stream each (steps go round robin over them)")
     ap.add_argument("--ab-variants", default="", help="matcher variants timed by --ab (default: all of the build)")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variants, interleaved, same process")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a child process tree.  Nothing in this process
+        # has touched the GPU (torch is not imported yet), and it is a child, not an exec.
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus:
+        # never an honest-looking N = 1 line for a run that was asked for N GPUs (or the other way round)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
+        raise SystemExit(2)
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     # rehearsal on a 1-GPU box: VISO_BENCH_SAME_DEVICE=1 puts every rank on device 0 (use --backend gloo)
-    dev_index = 0 if os.environ.get("VISO_BENCH_SAME_DEVICE") == "1" else local_rank
+    same_device = os.environ.get("VISO_BENCH_SAME_DEVICE") == "1"
+    if not same_device and torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, the node has {torch.cuda.device_count()} "
+                         "(VISO_BENCH_SAME_DEVICE=1 --backend gloo rehearses N ranks on one device)")
+    dev_index = 0 if same_device else local_rank
     torch.cuda.set_device(dev_index)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
@@ -211,6 +275,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     import libviso_amd
     from libviso_amd import synth
@@ -244,7 +310,8 @@ def main():
             dist.barrier()
 
     def timed(fn, steps, warmup, objs=None):
-        """fn(obj) is called once per step, round robin over the per-stream objects (default: the resident batches)."""
+        """fn(obj) is called once per step, round robin over the per-stream objects (default: the resident batches).
+        One region: exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
         objs = objs or [b for _, b in lanes]
         for i in range(warmup):
             fn(objs[i % len(objs)])
@@ -260,6 +327,22 @@ def main():
             dt = float(t.item())
         return dt
 
+    def timed_regions(fn, steps, warmup, objs=None, max_regions=64):
+        """The K-step region repeated: warm-up once, then R >= 5 regions with R * region >= --min-region-seconds
+        (R derived from the first region's max-over-ranks time, so every rank agrees).  Returns the list of region
+        times; the reported figure is the median."""
+        dts = [timed(fn, steps, warmup, objs)]
+        r = int(min(max_regions, max(5, math.ceil(args.min_region_seconds / max(dts[0], 1e-6)))))
+        for _ in range(r - 1):
+            dts.append(timed(fn, steps, 0, objs))
+        return dts
+
+    def spread(dts, units):
+        """units per region / region time: median, min, max over the regions."""
+        v = sorted(units / d for d in dts)
+        return {"median": float(np.median(v)), "min": v[0], "max": v[-1], "regions": len(v),
+                "timed_seconds_total": float(sum(dts))}
+
     # ---- configs[1]: matcher only ------------------------------------------
     for _, b in lanes:
         b.kernel_timing(False)
@@ -268,7 +351,8 @@ def main():
     sync_all()
     for _, b in lanes:
         b.kernel_timing(True)
-    dt = timed(lambda b: b.run_matcher(), args.steps, 0)
+    dts_m = timed_regions(lambda b: b.run_matcher(), args.steps, 0)
+    dt = float(np.median(dts_m))
     kern_ms_sum, kern_n = 0.0, 0
     for _, b in lanes:
         ms, n = b.kernel_ms()
@@ -278,6 +362,7 @@ def main():
     kern_ms_region = kern_ms_sum / max(kern_n, 1)
     frames_total = args.frames * args.steps * world
     fps = frames_total / dt
+    fps_spread = spread(dts_m, frames_total)
 
     # ---- the dominant kernel alone: a single-stream pass, HIP events on its stream ------------
     # (with several streams the events of the timed region also see the other streams' kernels sharing the CUs,
@@ -346,6 +431,7 @@ def main():
     roofline = {
         "bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
         "traffic": pmc["hbm_bytes"], "traffic_source": "; ".join(pmc["src"]) or None,
+        "pmc_dropped": pmc["dropped"] or None, "kernel_source_sha256": kernel_source_sha(),
         "kernel": kname, "kernel_ms": kern_ms, "kernel_launches": kern_n1,
         "kernel_ms_source": f"HIP events on the kernel's stream, {kern_n1} launches, ONE batch in flight (step alone: {step_ms_single:.3f} ms)",
         "kernel_ms_in_timed_region_overlapped": kern_ms_region,
@@ -391,15 +477,25 @@ def main():
 
     # ---- configs[2]: end to end (matcher + circle + RANSAC/GN) ---------------
     e2e = None
+    collective = None
     if not args.no_e2e:
-        dt2 = timed(lambda b: b.run(), max(1, args.steps // 2), n_streams)
+        dts2 = timed_regions(lambda b: b.run(), args.steps, n_streams)
+        dt2 = float(np.median(dts2))
         tr, ok, n_inl = batch.poses()
-        if world > 1:   # the one exchange step: gather per-frame transforms (RCCL over xGMI)
-            rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64)], 1), device=coll_dev)
+        if world > 1:   # the one exchange step: gather per-frame records {tr[6], ok, n_inl} (RCCL over xGMI)
+            rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64), n_inl[:, None].astype(np.float64)], 1),
+                               device=coll_dev)
             out = [torch.empty_like(rec) for _ in range(world)]
+            t0 = time.perf_counter()
             dist.all_gather(out, rec)
+            gathered = torch.stack(out).cpu().numpy()
+            collective = {"backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": dist.get_world_size(),
+                          "op": "all_gather of per-frame records {tr[6], ok, n_inl}", "gathered_records": int(gathered.shape[0] * (gathered.shape[1] - 1)),
+                          "bytes_per_rank": int(rec.numel() * 8), "seconds": time.perf_counter() - t0,
+                          "poses_ok_all_ranks": int(gathered[:, 1:, 6].sum())}
         err = float(np.abs(tr[1:][ok[1:] == 1] - seq["tr_gt"][1:][ok[1:] == 1]).max()) if ok[1:].any() else None
-        e2e = {"fps": args.frames * max(1, args.steps // 2) * world / dt2,
+        e2e = {"fps": args.frames * args.steps * world / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+               "fps_spread": spread(dts2, args.frames * args.steps * world),
                "workload": "configs[2]: matcher + circle join + RANSAC/Gauss-Newton",
                "poses_ok": int(ok[1:].sum()), "frames": int(args.frames),
                "max_abs_tr_err_vs_ground_truth": err}
@@ -445,8 +541,8 @@ def main():
                 (b.run if full else b.run_matcher)()
             return f
         s_steps = max(2 * n_streams, args.steps // 4)
-        dts = timed(stream_step(False), s_steps, n_streams)
-        dte = timed(stream_step(True), s_steps, n_streams) if not args.no_e2e else None
+        dts = float(np.median(timed_regions(stream_step(False), s_steps, n_streams)))
+        dte = float(np.median(timed_regions(stream_step(True), s_steps, n_streams))) if not args.no_e2e else None
         bytes_step = seq["kp"].nbytes + seq["desc"].nbytes + seq["n"].nbytes
         streaming = {"feature_in": {"fps_matcher": args.frames * s_steps * world / dts,
                                     "fps_end_to_end": args.frames * s_steps * world / dte if dte else None,
@@ -478,7 +574,7 @@ def main():
             b.upload_images_async(pi.a, pk.a, nn)
             b.run_images(False)
         i_steps = max(2 * n_streams, args.steps // 2)
-        dti = timed(img_step, i_steps, n_streams, objs=ibs)
+        dti = float(np.median(timed_regions(img_step, i_steps, n_streams, objs=ibs)))
         ibytes = iseq["images"].nbytes + iseq["kp"].nbytes + iseq["n"].nbytes
         streaming["image_in"] = {"fps_end_to_end": (nfi - 1) * i_steps * world / dti, "frames_per_step": nfi - 1,
                                  "host_bytes_per_step_per_gpu": ibytes, "pcie_GBps_per_gpu": ibytes * i_steps / dti / 1e9,
@@ -491,7 +587,7 @@ def main():
 
     # ---- resident image-in pipeline: uint8 images + keypoints already in HBM ---------
     e2e_img = None
-    if args.images:
+    if not args.no_images:
         if iseq is None:
             iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
         isteps = max(n_streams, args.steps // 2)
@@ -501,9 +597,11 @@ def main():
             ib.upload_images(iseq["images"], iseq["kp"], iseq["n"])
             ib.set_params(st, tm, iseq["param"], seed=1, first_frame=rank * (nfi - 1))
             ibs.append(ib)
-        dt3 = timed(lambda b: b.run_images(False), isteps, n_streams, objs=ibs)
+        dts3 = timed_regions(lambda b: b.run_images(False), isteps, n_streams, objs=ibs)
+        dt3 = float(np.median(dts3))
         tri, oki, _ = ibs[0].poses()
         e2e_img = {"fps": (nfi - 1) * isteps * world / dt3, "frames": nfi - 1,
+                   "fps_spread": spread(dts3, (nfi - 1) * isteps * world),
                    "workload": "resident uint8 images + keypoints -> Sobel descriptor windows on device -> matcher + circle + RANSAC/GN",
                    "poses_ok": int(oki[1:].sum()),
                    "max_abs_tr_err_vs_ground_truth": float(np.abs(tri[1:][oki[1:] == 1] - iseq["tr_gt"][1:][oki[1:] == 1]).max()) if oki[1:].any() else None}
@@ -520,10 +618,12 @@ def main():
         def detect_and_run(b):
             b.detect()
             b.run_images(False)
-        dt4 = timed(detect_and_run, isteps, n_streams, objs=dbs)
+        dts4 = timed_regions(detect_and_run, isteps, n_streams, objs=dbs)
+        dt4 = float(np.median(dts4))
         trd, okd, _ = dbs[0].poses()
         e2e_img["with_harris_detection"] = {
             "fps": (nfi - 1) * isteps * world / dt4,
+            "fps_spread": spread(dts4, (nfi - 1) * isteps * world),
             "workload": "resident uint8 images only -> binned Harris (1200 corners/image, 24x5 bins) -> descriptors -> matcher + circle + RANSAC/GN",
             "poses_ok": int(okd[1:].sum()),
             "max_abs_tr_err_vs_ground_truth": float(np.abs(trd[1:][okd[1:] == 1] - iseq["tr_gt"][1:][okd[1:] == 1]).max()) if okd[1:].any() else None}
@@ -540,6 +640,9 @@ def main():
             "metric": "stereo_frames_per_sec_1241x376_matcher",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value_spread": fps_spread,
+            "timing": f"the {args.steps}-step region (barrier + synchronize on both sides, max over ranks) repeated "
+                      f"{fps_spread['regions']} times after the warm-up; value / ms_per_step = the median region",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": workload_name(args),
@@ -549,6 +652,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "collective": collective,
             "streaming": streaming,
             "end_to_end_from_images": e2e_img,
             "matcher_ab": ab,

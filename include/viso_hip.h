@@ -88,10 +88,20 @@ int viso_ctx_destroy(viso_ctx* ctx);
 void* viso_ctx_stream(viso_ctx* ctx);
 int viso_ctx_synchronize(viso_ctx* ctx);
 /* Which kernel takes the temporal match_desc calls of this context (ctx == NULL: the default context of the
- * plain family): 3 = match_union_kernel (rows gathered from L2, one row load scored against four y-adjacent
- * queries).  Identical results from every variant; the parity tests run all of them.  Further variants exist in
- * -DVISO_DEBUG_VARIANTS builds only.  Returns VISO_ERR_ARG for a variant this build does not have. */
+ * plain family): 3 = match_union_kernel (rows gathered from the XCD's L2; a wave scores every row it loads against
+ * eight y-adjacent queries; vector-ALU bound).  Further variants (2 = match_batch_kernel<0>,
+ * 4 = match_strip_kernel) exist in -DVISO_DEBUG_VARIANTS builds only; every variant gives identical results, and
+ * the parity tests run over whatever viso_matcher_variants() reports for the build under test.  Returns
+ * VISO_ERR_ARG for a variant this build does not have. */
 int viso_ctx_set_matcher(viso_ctx* ctx, int variant);
+/* The variants of this build: fills out[0..cap), returns their number.  Needs no device. */
+int viso_matcher_variants(int* out, int cap);
+/* How the RANSAC stage splits the <= 100 Gauss-Newton iterations of a 3-point hypothesis (src/viso.cpp:1593) between
+ * its two kernels: the lane-per-hypothesis kernel runs the first `split`, the wave-per-hypothesis kernel the rest of
+ * the few that are still undecided.  0 = the build's default (10); 100 = the lane kernel alone.  Every split gives
+ * bit-identical hypotheses (tests/test_gpu_solver_edges.py); this is a tuning / test knob.  ctx == NULL: the default
+ * context of the plain family. */
+int viso_ctx_set_gn_split(viso_ctx* ctx, int split);
 /* Name of that kernel as it appears in rocprofv3 summaries. */
 const char* viso_ctx_matcher_kernel_name(viso_ctx* ctx);
 const char* viso_last_error(void);
@@ -257,6 +267,10 @@ int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok,
 /* All frames at once: tr [n_frames][6], ok [n_frames], n_inl [n_frames]
  * (entry 0 is zero/0: the first frame has no predecessor, :1256-1260). */
 int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl);
+/* Per-hypothesis state of the last run's RANSAC stage (diagnostics / tests): tr_h [n_frames][ransac_iter][6],
+ * ok_h, cnt_h [n_frames][ransac_iter] (support sizes; frame 0 unused), *n_undecided = hypotheses that needed the
+ * wave-per-hypothesis kernel.  Any pointer may be NULL. */
+int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided);
 /* Work counters of the last run, for the algorithmic-bytes model of
  * per (which,t) the number of scored (query,candidate) pairs C
  * and matches emitted M_out.  scored/m_out: [3][n_frames] int64. */

@@ -62,6 +62,9 @@ def load():
     L.viso_ctx_matcher_kernel_name.restype = C.c_char_p
     L.viso_ctx_matcher_kernel_name.argtypes = [C.c_void_p]
     L.viso_ctx_set_matcher.argtypes = [C.c_void_p, C.c_int]
+    L.viso_matcher_variants.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.viso_ctx_set_gn_split.argtypes = [C.c_void_p, C.c_int]
+    L.viso_batch_get_hypotheses.argtypes = [C.c_void_p, f64p, i32p, i32p, i32p]
     L.viso_host_alloc.restype = C.c_void_p
     L.viso_host_alloc.argtypes = [C.c_size_t]
     L.viso_host_free.argtypes = [C.c_void_p]
@@ -128,8 +131,21 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-MATCHER_VARIANTS = (3,)   # what this build of libviso_hip.so offers (viso_ctx_set_matcher)
 DEFAULT_MATCHER = 3
+
+
+def matcher_variants():
+    """What this build of libviso_hip.so offers (viso_ctx_set_matcher): (3,) for the product build, (2, 3, 4) for
+    `make DEBUG_VARIANTS=1`.  Asked of the library itself, so a debug build gets its variants tested."""
+    out = (C.c_int * 8)()
+    n = load().viso_matcher_variants(out, 8)
+    return tuple(out[i] for i in range(min(n, 8)))
+
+
+def __getattr__(name):   # MATCHER_VARIANTS: resolved on first use (needs the library, not a device)
+    if name == "MATCHER_VARIANTS":
+        return matcher_variants()
+    raise AttributeError(name)
 
 
 def set_matcher_variant(v, ctx=None):
@@ -137,6 +153,13 @@ def set_matcher_variant(v, ctx=None):
     r = load().viso_ctx_set_matcher(ctx.h if ctx is not None else None, int(v))
     if r != 1:
         _err("viso_ctx_set_matcher", r)
+
+
+def set_gn_split(split, ctx=None):
+    """viso_ctx_set_gn_split: iterations of a 3-point hypothesis done by the lane-per-hypothesis kernel (0 = default)."""
+    r = load().viso_ctx_set_gn_split(ctx.h if ctx is not None else None, int(split))
+    if r != 1:
+        _err("viso_ctx_set_gn_split", r)
 
 
 def matcher_kernel_name(ctx=None):
@@ -484,6 +507,16 @@ class Batch:
         n = np.zeros(self.nf, np.int32)
         self._chk("viso_batch_get_poses", self.L.viso_batch_get_poses(self.h, ptr(tr, C.c_double), ptr(ok, C.c_int32), ptr(n, C.c_int32)))
         return tr, ok, n
+
+    def hypotheses(self, iters):
+        """(tr_h [nf][iters][6], ok_h [nf][iters], cnt_h [nf][iters], n_undecided) of the last run's RANSAC stage."""
+        tr = np.zeros((self.nf, iters, 6))
+        ok = np.zeros((self.nf, iters), np.int32)
+        cnt = np.zeros((self.nf, iters), np.int32)
+        nu = np.zeros(1, np.int32)
+        self._chk("viso_batch_get_hypotheses", self.L.viso_batch_get_hypotheses(
+            self.h, ptr(tr, C.c_double), ptr(ok, C.c_int32), ptr(cnt, C.c_int32), ptr(nu, C.c_int32)))
+        return tr, ok, cnt, int(nu[0])
 
     def counters(self):
         sc = np.zeros((3, self.nf), np.int64)

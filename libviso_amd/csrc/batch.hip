@@ -15,12 +15,14 @@
 #include <string.h>
 #include <vector>
 
+#define VISO_NPIN_SLOTS 4
+
 struct viso_batch {
     viso_ctx* ctx;
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
     float2* kp; float* desc; int* n; uint16_t* packed; int* bad_img; int* bad_any; int* zero;
-    float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // x-sorted view of every image
+    float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // column-bucket view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
     ImageView* views;                                       // [nf*2] (+1 empty)
@@ -33,6 +35,9 @@ struct viso_batch {
     int *circ, *pcl, *mc;
     double* tr_h; int *ok_h, *cnt_h, *hq;   // hq: list of undecided hypotheses (launch_ransac)
     int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_sample_kernel)
+    // the *_async uploads stage the caller's (pageable, possibly temporary) n array through a small pinned ring:
+    // slot k is reusable once the copy that read it has passed (n_pin_ev[k])
+    int* n_pin; hipEvent_t n_pin_ev[VISO_NPIN_SLOTS]; bool n_pin_used[VISO_NPIN_SLOTS]; int n_pin_next;
     double* tr; int *ok, *n_inl, *inl;
     MatchParamsDev mp[2];
     SolverParamsDev sp;
@@ -95,10 +100,12 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     if (b->ev_join) note(hipEventDestroy(b->ev_join));
     if (b->ev_ransac) note(hipEventDestroy(b->ev_ransac));
     for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
+    for (int k = 0; k < VISO_NPIN_SLOTS; ++k) if (b->n_pin_ev[k]) note(hipEventDestroy(b->n_pin_ev[k]));
+    if (b->n_pin) note(hipHostFree(b->n_pin));
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->tile_flag, b->qord, b->ovf_q};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -214,6 +221,8 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
         }
         b->solver_stream = ctx->solver_stream;
     }
+    b->n_pin = nullptr; b->n_pin_next = 0;
+    for (int k = 0; k < VISO_NPIN_SLOTS; ++k) { b->n_pin_ev[k] = nullptr; b->n_pin_used[k] = false; }
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
     b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr;
@@ -241,6 +250,13 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
     A(dalloc(&b->tr, nf * 6)); A(dalloc(&b->ok, nf)); A(dalloc(&b->n_inl, nf)); A(dalloc(&b->inl, nf * c));
+    if (r >= 0 && hipHostMalloc((void**)&b->n_pin, sizeof(int) * VISO_NPIN_SLOTS * 2 * nf, hipHostMallocDefault) != hipSuccess) {
+        b->n_pin = nullptr;
+        viso_set_error("viso_batch_create: hipHostMalloc of the n staging ring failed");
+        r = VISO_ERR_NOMEM;
+    }
+    for (int k = 0; r >= 0 && k < VISO_NPIN_SLOTS; ++k)
+        if (hipEventCreateWithFlags(&b->n_pin_ev[k], hipEventDisableTiming) != hipSuccess) { b->n_pin_ev[k] = nullptr; r = VISO_ERR_HIP; }
     if (r < 0) { viso_batch_destroy(b); return nullptr; }
     bool ok = hipMemset(b->zero, 0, 8 * sizeof(int)) == hipSuccess &&
               hipMemset(b->n, 0, nf * 2 * sizeof(int)) == hipSuccess &&
@@ -283,6 +299,20 @@ extern "C" int viso_host_free(void* p) {
     return VISO_OK;
 }
 
+// n[2*nf] of the caller -> the next slot of the batch's pinned ring -> device, on stream s.  The caller's array is
+// not read after this returns.
+static int stage_n_async(viso_batch* b, int f0, int nf, const int32_t* n, hipStream_t s) {
+    const int k = b->n_pin_next;
+    b->n_pin_next = (k + 1) % VISO_NPIN_SLOTS;
+    if (b->n_pin_used[k]) HIP_TRY(hipEventSynchronize(b->n_pin_ev[k]));   // the copy that read this slot VISO_NPIN_SLOTS uploads ago
+    int* slot = b->n_pin + (size_t)k * 2 * b->nf;
+    memcpy(slot, n, sizeof(int) * (size_t)nf * 2);
+    HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, slot, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(b->n_pin_ev[k], s));
+    b->n_pin_used[k] = true;
+    return VISO_OK;
+}
+
 // viso_batch_upload without the wait: the three copies are enqueued on the context's stream (behind the batch's
 // previous run, in front of the next one) and the call returns.  The host buffers must stay untouched until the
 // stream has passed the copies (viso_ctx_synchronize, or any result getter of a later run); with buffers from
@@ -300,8 +330,7 @@ extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const floa
     const size_t c = (size_t)b->cap;
     HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
-    return VISO_OK;
+    return stage_n_async(b, f0, nf, n, s);
 }
 
 extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
@@ -324,7 +353,7 @@ extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, con
     HIP_TRY(hipMemcpyAsync(b->images + (size_t)f0 * 2 * per, images, per * 2 * (size_t)nf, hipMemcpyHostToDevice, s));
     if (kp) {
         HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(b->n + (size_t)f0 * 2, n, sizeof(int) * (size_t)nf * 2, hipMemcpyHostToDevice, s));
+        return stage_n_async(b, f0, nf, n, s);
     }
     return VISO_OK;
 }
@@ -518,7 +547,7 @@ static int run_rest(viso_batch* b) {
     }
     HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, ss));           // vector<double> tr(6,0), :1312
     if (b->nf > 1) {
-        if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq)) < 0) return r;   // :1313
+        if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq, b->ctx->gn_split)) < 0) return r;   // :1313
     }
     if (ss != s) {
         HIP_TRY(hipEventRecord(b->ev_ransac, ss));
@@ -587,6 +616,19 @@ extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int3
     if (tr) HIP_TRY(hipMemcpy(tr, b->tr, sizeof(double) * 6 * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (ok) HIP_TRY(hipMemcpy(ok, b->ok, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
     if (n_inl) HIP_TRY(hipMemcpy(n_inl, b->n_inl, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
+    return VISO_OK;
+}
+
+// The per-hypothesis state of the last run's RANSAC stage (test / diagnostics): tr_h [n_frames][iters][6], ok_h and
+// cnt_h [n_frames][iters] (frame 0 unused), *n_undecided = hypotheses the lane-per-hypothesis kernel handed on.
+extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided) {
+    if (!b || !b->tr_h) { viso_set_error("viso_batch_get_hypotheses: no run yet"); return VISO_ERR_ARG; }
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
+    const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
+    if (tr_h) HIP_TRY(hipMemcpy(tr_h, b->tr_h, sizeof(double) * 6 * k, hipMemcpyDeviceToHost));
+    if (ok_h) HIP_TRY(hipMemcpy(ok_h, b->ok_h, sizeof(int) * k, hipMemcpyDeviceToHost));
+    if (cnt_h) HIP_TRY(hipMemcpy(cnt_h, b->cnt_h, sizeof(int) * k, hipMemcpyDeviceToHost));
+    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq, sizeof(int), hipMemcpyDeviceToHost));
     return VISO_OK;
 }
 

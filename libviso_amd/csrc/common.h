@@ -40,15 +40,18 @@ struct ImageView {               // one image's keypoints + descriptors on the d
     const float2* kp;            // [n] boundary order (x,y)
     const float* frows;          // [n][dlen] boundary-layout descriptors (original order)
     const int* n;                // keypoint count (device, ragged batches)
-    float2* skp;                 // [n] keypoints sorted by x (ties by index)
-    int* sidx;                   // [n] sorted position -> original index
-    int* rank;                   // [n] original index -> sorted position
+    float2* skp;                 // [n] keypoints grouped by column bucket (counting sort by bucket_of(x): 256 buckets over
+                                 //     the image's x range).  NO order inside a bucket (scattered with LDS atomics), and
+                                 //     keypoints with a NaN x share the last bucket with the largest columns.
+    int* sidx;                   // [n] bucket-order position -> original index
+    int* rank;                   // [n] original index -> bucket-order position
     int* bstart;                 // [VISO_NB+1] first sorted position of each column bucket
     float* xinfo;                // [8] x0, scale of the column bucket map; smallest and largest finite keypoint y;
-                                 //     [4] number of keypoints whose x is not NaN (they sort first), as a float
-    uint8_t* qord;               // [n rounded up to 64] y order inside every block of 64 sorted positions: entry B*64 + r =
+                                 //     [4] number of keypoints whose x is not NaN, as a float: a COUNT only, not a prefix
+                                 //     length (NaN-x keypoints sit anywhere inside the last bucket)
+    uint8_t* qord;               // [n rounded up to 64] y order inside every block of 64 bucket-order positions: entry B*64 + r =
                                  //     offset (0..63) in block B of the keypoint with y rank r (positions past n rank last)
-    uint16_t* rows;              // [n][128] packed descriptor rows, x-sorted order
+    uint16_t* rows;              // [n][128] packed descriptor rows, bucket order
     int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
                                  //     every problem that reads the image then takes the general (double) kernel
 };
@@ -80,6 +83,7 @@ struct viso_ctx {
     hipStream_t stream;
     bool own_stream;
     int matcher_variant;         // viso_ctx_set_matcher
+    int gn_split;                // viso_ctx_set_gn_split
     // second, high-priority stream of the context: the RANSAC stage of its batches runs here, beside the next run's
     // matcher on `stream` (viso_ctx_synchronize waits for both).  One per CONTEXT, not per batch: the runtime maps
     // streams onto a handful of hardware queues, and two busy RANSAC streams that land on one queue serialise
@@ -95,9 +99,9 @@ int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
 viso_ctx* viso_default_ctx();
 
 // ---- launchers (host) -------------------------------------------------------
-// x-sort every image's keypoints (+ inverse permutation and column index)
+// group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
 int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max);
-// pack boundary-layout float descriptors into biased u16 rows in x-sorted order;
+// pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
 int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any);
@@ -153,8 +157,10 @@ struct TriItem {
 };
 
 // queue: device scratch of 1 + n_items * iters ints (list of the hypotheses stage 1 leaves undecided)
+// split: iterations the lane-per-hypothesis kernel runs before it hands undecided hypotheses to the wave-per-hypothesis
+// kernel (viso_ctx::gn_split; 100 = the lane kernel does everything)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue);
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split);
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);

@@ -31,6 +31,7 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     memset(c, 0, sizeof(*c));
     c->device = device;
     c->matcher_variant = VISO_MATCHER_DEFAULT;
+    c->gn_split = 0;   // 0 = the build's default (VISO_GN_SPLIT, solver.hip)
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -81,6 +82,26 @@ extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
     if (!known) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
     c->matcher_variant = variant;
     return VISO_OK;
+}
+
+extern "C" int viso_ctx_set_gn_split(viso_ctx* c, int split) {
+    c = ctx_or_default(c);
+    if (!c) return VISO_ERR_HIP;
+    if (split < 0 || split > 100) { viso_set_error("viso_ctx_set_gn_split: 0 (default) or 1..100"); return VISO_ERR_ARG; }
+    c->gn_split = split;
+    return VISO_OK;
+}
+
+// Variants this build of the library offers (no device needed): fills out[0..cap) and returns how many exist.
+extern "C" int viso_matcher_variants(int* out, int cap) {
+#ifdef VISO_DEBUG_VARIANTS
+    const int v[] = {2, 3, 4};
+#else
+    const int v[] = {3};
+#endif
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; out && i < n && i < cap; ++i) out[i] = v[i];
+    return n;
 }
 
 extern "C" const char* viso_ctx_matcher_kernel_name(viso_ctx* c) {

@@ -74,7 +74,7 @@ extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, 
 // ---------------------------------------------------------------------------
 // Fused extract + pack for the batch pipeline: the
 // 11x11 Sobel-x window of every keypoint goes straight from the uint8 image
-// into the matcher's biased-u16 row (x-sorted order); the N x 121 float
+// into the matcher's biased-u16 row (column-bucket order); the N x 121 float
 // descriptor matrix of the reference (src/viso.cpp:1008) is never materialised.
 // Sobel of uint8 is an integer in [-1020, 1020], so the u16 path is always exact.
 // One wave = one keypoint at a time: lane l produces elements 2l and 2l+1.

@@ -2,13 +2,14 @@
 //
 // Replaces match_desc + radiusSearch + sampsonDistance of the reference
 // (src/viso.cpp:669-726, 170-203, 655-666).  Integer abs-diff work: no MFMA;
-// the levers are x-sorted images (a query tile only scans the +-radius column
+// the levers are column-bucketed images (a query tile only scans the +-radius column
 // window of the target image), coalesced 256-B descriptor rows, wave64
 // ballot/DPP reductions and keeping a problem's working set inside one XCD's L2.
 //
 // Kernels
-//   sort_kp_kernel       per image: keypoints sorted by x (+ inverse permutation, bucket index)
-//   pack_desc_kernel     f32 N x dlen (boundary layout) -> u16 N x 128 rows (+bias), x-sorted order
+//   sort_kp_kernel       per image: keypoints grouped into 256 column buckets (counting sort; no order inside a
+//                        bucket, NaN x in the last one) + inverse permutation, bucket index, y order per 64-block
+//   pack_desc_kernel     f32 N x dlen (boundary layout) -> u16 N x 128 rows (+bias), bucket order
 //   match_kernel<false>  neighbour gate + epipolar gate + SAD + best/2nd-best   (hot, u16)
 //   match_kernel<true>   same walk, double-accumulated SAD for non-integer data
 //   sort_matches_kernel  (dist,i1)-ordered match list, inverse permutation, count
@@ -20,7 +21,7 @@
 // because the best/second-best update is order independent except for ties
 // (`<=`: the LAST equal candidate wins, Q2), the winner is the candidate of
 // minimal SAD with the LARGEST key.  No neighbour list is materialised, and the
-// order in which candidates are visited (here: x-sorted) is irrelevant.
+// order in which candidates are visited (here: column buckets) is irrelevant.
 #include "common.h"
 #include "match_dev.h"
 
@@ -152,7 +153,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 // One wave = VISO_PACK_RPW consecutive ORIGINAL rows = one contiguous, 16-B aligned run of RPW * dlen floats of
 // the boundary-layout matrix: streamed in with 16-B loads per lane, staged in LDS (the rows are 121 floats long,
 // so row boundaries fall anywhere in a lane's 16 B), then lane l converts floats 2l, 2l+1 of every row into one
-// packed dword and the wave writes each 256-B row to its x-sorted position rank[i] (two full cache lines).
+// packed dword and the wave writes each 256-B row to its bucket-order position rank[i] (two full cache lines).
 #define VISO_PACK_RPW 8   // rows per wave
 
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
@@ -694,7 +695,7 @@ __device__ __forceinline__ void match_tile_slot(const MatchArgs& a, int vb, uint
     const MatchParamsDev& mp = a.mp[P.pidx];
     if ((mp.epi != 0) != (EPI != 0)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // x range of the tile (queries are x-sorted; NaNs sort last and are ignored)
+    // x range of the tile (any 64 consecutive bucket-order entries; the reductions ignore NaN x)
     if (wave == 0) {
         float x = (q0 + lane < q1) ? P.q.skp[q0 + lane].x : __builtin_nanf("");
         float mn = x, mx = x;
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 //   4 = match_strip_kernel  (window rows resident in LDS, tools/experiments/match_strip.hip: 0.60 ms against 0.44 ms)
 //   2 = match_batch_kernel<0> (rows gathered from L2, one pair per 8-lane group, match_batch.hip: 0.63 ms)
 // 2 and 4 exist in -DVISO_DEBUG_VARIANTS builds only (make DEBUG_VARIANTS=1).
-// The stereo problems always take match_batch_kernel<1>.  Same results from all of them (parity tests run each).
+// The stereo problems always take match_batch_kernel<1>.  Same results from all of them (the parity tests run over viso_matcher_variants(): a DEBUG_VARIANTS build gets all three tested).
 const char* matcher_kernel_name(int variant) {
     return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : "match_strip_kernel";
 }

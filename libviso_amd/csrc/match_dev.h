@@ -74,6 +74,10 @@ __device__ __forceinline__ float epipolar_band(const double* F, double thresh, f
     const double T = Xt * (fabs(F[0]) * X + fabs(F[1]) * Y + fabs(F[2])) + Yt * (fabs(F[3]) * X + fabs(F[4]) * Y + fabs(F[5])) +
                      fabs(F[6]) * X + fabs(F[7]) * Y + fabs(F[8]);
     const double D = M0 * M0 + M1 * M1 + N0 * N0 + N1 * N1;
+    // The bound rests on the computed ad = (float)e and ad * ad being NORMAL floats.  Where the smallest |e| it relies
+    // on, sqrt(thresh D), is below ~1e-18 its square is no longer one (a tiny-scaled F, or thresh = 0): ad * ad may
+    // flush to 0, the reference's gate then ACCEPTS the candidate, and no band may cull it.
+    if (!(sqrt(thresh * D) >= 1e-18)) return inf;
     const double Emin = (sqrt(thresh * D) * (1.0 + 2e-6) + 1e-9 * T) * (1.0 + 2e-6);
     const double band = ((Emin + (double)r * M0 + G) / m1) * (1.0 + 1e-6) + 1e-6;
     if (!(band == band) || band > 3.0e38) return inf;
@@ -87,9 +91,12 @@ __device__ __forceinline__ bool key_less(uint32_t ad, uint32_t ai, uint32_t bd, 
     return ad < bd || (ad == bd && ai < bi);
 }
 
+// Column bucket of x.  NaN x shares the last bucket with the largest columns; a NaN product (x0 = +-inf with scale 0)
+// goes to bucket 0 explicitly — never (int)NaN.
 __device__ __forceinline__ int bucket_of(float x, float x0, float scale) {
     if (x != x) return VISO_NB - 1;
     const float f = floorf((x - x0) * scale);
+    if (f != f) return 0;
     return f <= 0.f ? 0 : (f >= (float)(VISO_NB - 1) ? VISO_NB - 1 : (int)f);
 }
 

@@ -59,6 +59,7 @@ __device__ __forceinline__ int st_scan_incl(int v, int lane) {
 __device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
     if (y != y) return ST_NBY - 1;
     const float f = floorf((y - y0) * scale);
+    if (f != f) return 0;                       // inf * 0: never (int)NaN
     return f <= 0.f ? 0 : (f >= (float)(ST_NBY - 1) ? ST_NBY - 1 : (int)f);
 }
 

@@ -66,6 +66,7 @@ __device__ __forceinline__ void mu_merge(MuTrack& a, const MuTrack& b) {
 __device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {   // monotone in y
     if (y != y) return MU_NBY - 1;
     const float f = floorf((y - y0) * scale);
+    if (f != f) return 0;                       // inf * 0: never (int)NaN
     return f <= 0.f ? 0 : (f >= (float)(MU_NBY - 1) ? MU_NBY - 1 : (int)f);
 }
 

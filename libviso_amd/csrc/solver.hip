@@ -97,21 +97,82 @@ __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
 }
 
 // ---- stage 1b: one WAVE per unfinished hypothesis: iterations VISO_GN_SPLIT..99, same arithmetic ------------
-// Per iteration: lanes 0..2 evaluate the three sincos, every lane builds the rotation; lane (p, j), p < 3 points,
-// j < 6 parameters, computes column j of point p's three Jacobian rows (and the residuals) exactly as
-// accumulate_point does; lanes 0..26 each sum one entry of J^T J / J^T r over the 12 rows in the reference's order;
-// every lane then solves the same 6x6 system redundantly (no broadcast, no divergence).  Values are bit-identical
-// to gn_serial's: only who computes them changes.
+// A single wave on a serial fp64 chain issues one instruction every 4+ cycles, so its time per iteration is its
+// instruction count: the work is spread over the lanes instead of being repeated in every lane.
+//   Jacobian   lane (p, j), p < 3 points, j < 6 parameters (lanes 0..17): column j of point p's rows and, for
+//              j == 0, the residuals, exactly as accumulate_point computes them -> LDS JE[p][row 0..3][col 0..6]
+//              (row 3 repeats row 1, src/viso.cpp:1479,1481; col 6 = weighted residual)
+//   J^T J, J^T r   matrix lane (r, c) = lane r * 8 + c, r < 6, c < 7: ONE entry of the augmented system [A | b],
+//              summed over the 12 rows in the reference's order (A[r][c] and A[c][r] are the same products in the
+//              same order: symmetric bit for bit, what symmetrize() copies in gn_serial)
+//   6x6 LU     cv::solve(DECOMP_LU) = lu_solve6 of solver_dev.h with one entry per lane: per pivot column the
+//              candidates come to every lane as scalars (v_readlane: first strict maximum of |.|, singular iff
+//              < DBL_EPSILON), rows i and k change places through one cross-lane move, every lane below / right of
+//              the pivot does its own  a += (a_ri * d) * a_ic  (d = -1 / pivot; a_ri by ds_swizzle inside the
+//              lane's 8-group, a_ic by ds_bpermute), lane (i, i) keeps -d
+//   back substitution   the 21 + 6 entries it needs come back as scalars; s -= A[i][c] * x[c] in the reference's
+//              order c = i+1..5, x[i] = s * (1 / pivot): computed uniformly by every lane (the step, the
+//              convergence test and tr stay wave uniform)
+// Values are bit-identical to gn_serial's (tests/test_gpu_solver_edges.py runs every hypothesis both ways): only
+// who computes them changes.  ~60 VGPRs instead of 205, about a third of the instructions per iteration.
+__device__ __forceinline__ double rdlane(double v, int src_lane) {   // src_lane: compile-time constant
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+template <int I>
+__device__ __forceinline__ double swz_bcast8(double v) {   // element I of the lane's aligned group of 8 lanes
+    constexpr int pat = (I << 5) | 0x18;                   // bitmask mode: lane' = (lane & 0x18) | I  (per 32 lanes)
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bperm(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// one pivot step of the lane-distributed LU; returns false when the system is singular (uniform)
+template <int I>
+__device__ __forceinline__ bool lu_lane_step(double& a, int lane, int row, int col) {
+    double cv[6];
+#pragma unroll
+    for (int j = I; j < 6; ++j) cv[j] = rdlane(a, j * 8 + I);      // column I, rows I..5: scalars
+    int k = I;
+    double best = fabs(cv[I]), piv = cv[I];
+#pragma unroll
+    for (int j = I + 1; j < 6; ++j) {
+        const double v = fabs(cv[j]);
+        if (v > best) { best = v; k = j; piv = cv[j]; }            // first strict maximum
+    }
+    if (best < DBL_EPSILON) return false;
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k != I) {                                                  // uniform: rows I and k change places
+        const int d8 = (k - I) * 8;
+        const int src = lane + (row == I ? d8 : row == k ? -d8 : 0);
+        a = bperm(a, src);
+    }
+    const double d = -1 / piv;
+    const double a_ri = swz_bcast8<I>(a);                          // A[row][I]
+    const double a_ic = bperm(a, I * 8 + col);                     // A[I][col]
+    const double alpha = a_ri * d;
+    const double upd = a + alpha * a_ic;
+    if (row > I && row < 6 && col > I && col < 7) a = upd;
+    if (lane == I * 8 + I) a = -d;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
-    __shared__ double s_J[4][3][3][6];
-    __shared__ double s_res[4][3][4];
-    __shared__ double s_S[4][27];
+    __shared__ double s_JE[4][3][4][8];      // [wave][point][row][col 0..5 = J, 6 = residual, 7 = pad]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
     // a SMALL grid walks the list of undecided hypotheses (a launch with one wave per hypothesis would push
-    // thousands of 200-register workgroups, nearly all of which leave at once, through a GPU that is busy with
-    // another batch's matcher)
+    // thousands of workgroups, nearly all of which leave at once, through a GPU that is busy with another batch's
+    // matcher)
     const int n_undecided = a.queue[0];
+    const int row = lane >> 3, col = lane & 7;       // this lane's entry of [A | b] (row < 6, col < 7)
+    const int mrow = min(row, 5), mcol = min(col, 6);
     for (int qi = (int)blockIdx.x * 4 + wv; qi < n_undecided; qi += (int)gridDim.x * 4) {
     const int gid = a.queue[1 + qi];
     const int item = gid / a.iters, h = gid % a.iters;
@@ -130,20 +191,13 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     const double X1p = X[0 * ld + ai], Y1p = X[1 * ld + ai], Z1p = X[2 * ld + ai];
     const double o0 = obs[0 * ld + ai], o1 = obs[1 * ld + ai], o2 = obs[2 * ld + ai], o3 = obs[3 * ld + ai];
     const double weight = 1.0 / (fabs(obs[0 * ld + p] - sp.cu) / fabs(sp.cu) + 0.05);   // Q6: position, not index
-    // this lane's normal-equation entry: e < 21 -> A[ep][eq] (upper triangle, row major), e >= 21 -> B[e - 21]
-    int ep = 0, eq = 0;
-    {
-        int e = lane, row = 0, len = 6;
-        while (row < 5 && e >= len) { e -= len; ++row; --len; }
-        if (lane < 21) { ep = row; eq = row + e; } else { ep = min(lane - 21, 5); eq = 0; }
-    }
     int ok = 0;
     for (int it = a.split; it < 100; ++it) {
-        // rotation: one sincos per lane (lanes 0..2 matter), then the table of solver_dev.h
+        // rotation: one sincos per lane (lanes 0..2 matter), the six values come back as scalars
         double sv, cv;
         const int l3 = lane % 3;
         sincos(l3 == 0 ? tr[0] : l3 == 1 ? tr[1] : tr[2], &sv, &cv);
-        const double sx = __shfl(sv, 0), cx = __shfl(cv, 0), sy = __shfl(sv, 1), cy = __shfl(cv, 1), sz = __shfl(sv, 2), cz = __shfl(cv, 2);
+        const double sx = rdlane(sv, 0), cx = rdlane(cv, 0), sy = rdlane(sv, 1), cy = rdlane(cv, 1), sz = rdlane(sv, 2), cz = rdlane(cv, 2);
         RotDev R;
         rot_from_sincos(sx, cx, sy, cy, sz, cz, tr, R);
         // column j of point p (the switch of accumulate_point, evaluated for all three rotation parameters and
@@ -159,46 +213,44 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
         const double Y1cd = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : j == 4 ? 1.0 : 0.0;
         const double Z1cd = j == 0 ? z0 : j == 1 ? z1 : j == 2 ? z2 : j == 5 ? 1.0 : 0.0;
         if (lane < 18) {
-            s_J[wv][p][0][j] = wf * (X1cd * Z1c - X1c * Z1cd) / zz;
-            s_J[wv][p][1][j] = wf * (Y1cd * Z1c - Y1c * Z1cd) / zz;
-            s_J[wv][p][2][j] = wf * (X1cd * Z1c - X2c * Z1cd) / zz;
+            const double j0 = wf * (X1cd * Z1c - X1c * Z1cd) / zz;
+            const double j1 = wf * (Y1cd * Z1c - Y1c * Z1cd) / zz;
+            const double j2 = wf * (X1cd * Z1c - X2c * Z1cd) / zz;
+            s_JE[wv][p][0][j] = j0;
+            s_JE[wv][p][1][j] = j1;
+            s_JE[wv][p][2][j] = j2;
+            s_JE[wv][p][3][j] = j1;
             if (j == 0) {
-                s_res[wv][p][0] = weight * (o0 - pred[0]);
-                s_res[wv][p][1] = weight * (o1 - pred[1]);
-                s_res[wv][p][2] = weight * (o2 - pred[2]);
-                s_res[wv][p][3] = weight * (o3 - pred[3]);
+                s_JE[wv][p][0][6] = weight * (o0 - pred[0]);
+                s_JE[wv][p][1][6] = weight * (o1 - pred[1]);
+                s_JE[wv][p][2][6] = weight * (o2 - pred[2]);
+                s_JE[wv][p][3][6] = weight * (o3 - pred[3]);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // one entry of J^T J / J^T r per lane, summed over points and rows in the reference's order
-        if (lane < 27) {
-            double acc = 0;
+        // this lane's entry of [J^T J | J^T r], summed over points and rows in the reference's order
+        double acc = 0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jr = (r == 3) ? 1 : r;
-                    const double lhs = s_J[wv][i][jr][ep];
-                    const double rhs = lane < 21 ? s_J[wv][i][jr][eq] : s_res[wv][i][r];
-                    acc += lhs * rhs;
-                }
-            s_S[wv][lane] = acc;
+            for (int r = 0; r < 4; ++r) acc += s_JE[wv][i][r][mrow] * s_JE[wv][i][r][mcol];
+        __builtin_amdgcn_wave_barrier();   // s_JE is rewritten next iteration
+        // cv::solve(DECOMP_LU), one entry per lane (src/viso.cpp:1602-1606)
+        bool regular = lu_lane_step<0>(acc, lane, row, col);
+        regular = regular && lu_lane_step<1>(acc, lane, row, col);
+        regular = regular && lu_lane_step<2>(acc, lane, row, col);
+        regular = regular && lu_lane_step<3>(acc, lane, row, col);
+        regular = regular && lu_lane_step<4>(acc, lane, row, col);
+        regular = regular && lu_lane_step<5>(acc, lane, row, col);
+        if (!regular) { ok = 0; break; }
+        double B[6];
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double sacc = rdlane(acc, i * 8 + 6);
+#pragma unroll
+            for (int c = i + 1; c < 6; ++c) sacc -= rdlane(acc, i * 8 + c) * B[c];
+            B[i] = sacc * rdlane(acc, i * 8 + i);
         }
-        __builtin_amdgcn_wave_barrier();
-        // every lane solves the same system
-        double A[6][6], B[6];
-        {
-            int c = 0;
-#pragma unroll
-            for (int pp = 0; pp < 6; ++pp)
-#pragma unroll
-                for (int qq = pp; qq < 6; ++qq) A[pp][qq] = s_S[wv][c++];
-#pragma unroll
-            for (int pp = 0; pp < 6; ++pp) B[pp] = s_S[wv][21 + pp];
-        }
-        __builtin_amdgcn_wave_barrier();   // s_J / s_S are rewritten next iteration
-        symmetrize(A);
-        if (!lu_solve6(A, B)) { ok = 0; break; }      // src/viso.cpp:1602-1606
         bool converged = true;
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj)
@@ -212,7 +264,7 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
         for (int jj = 0; jj < 6; ++jj) S.tr_h[6 * h + jj] = tr[jj];
         S.ok_h[h] = ok;
     }
-    __builtin_amdgcn_wave_barrier();   // the wave's LDS slices are reused by its next hypothesis
+    __builtin_amdgcn_wave_barrier();   // the wave's LDS slice is reused by its next hypothesis
     }
 }
 
@@ -432,11 +484,11 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
 
 
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue) {
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split) {
     if (n_items <= 0) return VISO_OK;
     SolverArgs a;
     a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
-    a.split = VISO_GN_SPLIT;
+    a.split = split >= 1 && split <= 100 ? split : VISO_GN_SPLIT;
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
@@ -622,7 +674,7 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue)) < 0) return r;
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split)) < 0) return r;
     int res[4];
     HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(best_tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));

@@ -131,8 +131,12 @@ struct OdometryResult {
 // sequence_odometry, src/viso.cpp:1167-1330, minus the front-end and the debug
 // dumps: frames are pulled from `frames`, processed on the GPU in chunks of
 // `chunk` frames (one-frame halo between chunks), poses chained on the host.
+// first_frame_index: index of the generator's first frame in the whole sequence — the RANSAC stream of frame t
+// is keyed on (ransac_seed, first_frame_index + t), so a sub-range gives the records of the full run
+// (kitti_shard.hpp).  device: HIP device ordinal.
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGenerator frames,
-                                 int chunk = 64, uint64_t ransac_seed = 0);
+                                 int chunk = 64, uint64_t ransac_seed = 0, uint64_t first_frame_index = 0,
+                                 int device = 0);
 
 }  // namespace viso
 
@@ -196,6 +200,7 @@ private:
 // debug dumps: detection (MAX_FEATURE_NUM 1200, radius 5, :1171-1174), description, matching and the
 // solver all run on the device, `chunk` frames per batch.
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images,
-                                 int chunk = 64, uint64_t ransac_seed = 0);
+                                 int chunk = 64, uint64_t ransac_seed = 0, uint64_t first_frame_index = 0,
+                                 int device = 0);
 
 }  // namespace viso

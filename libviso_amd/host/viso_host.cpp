@@ -274,7 +274,7 @@ bool minimize_reproj_from_procrustes(const Matd& X, const Matd& observe, std::ve
 namespace {
 struct Ctx {
     viso_ctx* c;
-    Ctx() : c(viso_ctx_create(0, nullptr)) { if (!c) throw std::runtime_error(std::string("viso_ctx_create: ") + viso_last_error()); }
+    explicit Ctx(int device) : c(viso_ctx_create(device, nullptr)) { if (!c) throw std::runtime_error(std::string("viso_ctx_create: ") + viso_last_error()); }
     ~Ctx() { viso_ctx_destroy(c); }
 };
 
@@ -288,13 +288,17 @@ struct ChunkPipeline {
         int nf = 0, cap = 0, dlen = 0;      // shape the batch was created for
         int global0 = 0;                    // global frame index of the chunk's first frame (its halo)
         bool busy = false;
+        explicit Slot(int device) : ctx(device) {}
+        Slot(const Slot&) = delete;
         ~Slot() { if (b) viso_batch_destroy(b); }
     };
     Slot slot[2];
     int next = 0;
     OdometryResult& out;
     double pose[16];
-    explicit ChunkPipeline(OdometryResult& o) : out(o) { std::memcpy(pose, out.poses[0].ptr(), sizeof(pose)); }
+    ChunkPipeline(OdometryResult& o, int device) : slot{Slot(device), Slot(device)}, out(o) {
+        std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
+    }
 
     // batch of the slot the next chunk goes to (drains the chunk that used it two steps ago first)
     viso_batch* acquire(int nf, int cap, int dlen, int global0) {
@@ -339,7 +343,7 @@ struct ChunkPipeline {
 }
 
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGenerator frames, int chunk,
-                                 uint64_t ransac_seed) {
+                                 uint64_t ransac_seed, uint64_t first_frame_index, int device) {
     if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("sequence_odometry: P1,P2 must be 3x4");
     if (chunk < 1) chunk = 1;
     Matd F = F_from_P(P1, P2);                                        // :1176-1180
@@ -351,7 +355,7 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
     OdometryResult out;
     out.poses.push_back(Matd::eye(4));                                // :1189-1190
     out.frame_of_pose.push_back(0);
-    ChunkPipeline pipe(out);
+    ChunkPipeline pipe(out, device);
     std::vector<StereoFeatures> buf;                                  // frames of the current chunk (buf[0] = halo)
     int global0 = 0;                                                  // global index of buf[0]
     bool eos = false;
@@ -384,7 +388,7 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
             }
         viso_batch* b = pipe.acquire(nf, cap, dlen, global0);
         int r = viso_batch_upload(b, 0, nf, kp.data(), desc.data(), n.data());
-        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
+        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, first_frame_index + (uint64_t)global0);
         if (r >= 0) r = viso_batch_run(b);                            // asynchronous: the next chunk is packed meanwhile
         hip_check(r, "sequence_odometry");
         pipe.submitted();
@@ -494,7 +498,7 @@ StereoImageGenerator::result_type StereoImageGenerator::operator()() {
 }
 
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images, int chunk,
-                                 uint64_t ransac_seed) {
+                                 uint64_t ransac_seed, uint64_t first_frame_index, int device) {
     if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("sequence_odometry: P1,P2 must be 3x4");
     if (chunk < 1) chunk = 1;
     const int MAX_FEATURE_NUM = 1200;                                   // :1171
@@ -508,7 +512,7 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
     OdometryResult out;
     out.poses.push_back(Matd::eye(4));
     out.frame_of_pose.push_back(0);
-    ChunkPipeline pipe(out);
+    ChunkPipeline pipe(out, device);
     std::vector<std::pair<Image, Image>> buf;
     int global0 = 0;
     bool eos = false;
@@ -530,7 +534,7 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
             }
         viso_batch* b = pipe.acquire(nf, MAX_FEATURE_NUM, VISO_DESC_LEN, global0);
         int r = viso_batch_upload_images(b, 0, nf, img.data(), rows, cols, nullptr, nullptr);
-        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, (uint64_t)global0);
+        if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, first_frame_index + (uint64_t)global0);
         if (r >= 0) r = viso_batch_detect(b, detector.n(), detector.nbinx(), detector.nbiny(), (double)detector.k());   // :1226-1227
         if (r >= 0) r = viso_batch_run_images(b, 0);                                                                    // :1230-1313, asynchronous
         hip_check(r, "sequence_odometry");

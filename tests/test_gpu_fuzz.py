@@ -137,3 +137,21 @@ def test_match_desc_randomised_image_sized(viso, oracle):
         want = oracle.match_desc(kp1, kp2, d1, d2, mp)
         got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
         assert np.array_equal(got, want), (it, len(kp1), len(kp2), mp.max_neighbors, mp.radius, mp.enforce_epipolar, mp.enforce_2nd_best)
+
+
+def test_stereo_gate_with_a_tiny_scaled_F(viso, oracle):
+    """Sampson is scale invariant in exact arithmetic, but the reference squares a FLOAT: ad * ad (src/viso.cpp:664-665).
+    With |F| ~ 1e-25 that product flushes to 0, the gate value is 0 and every in-radius candidate passes; with
+    thresh = 0 only such candidates pass.  The epipolar band must not cull what the reference accepts there
+    (epipolar_band returns +inf below the normal-float range)."""
+    F0 = oracle.F_from_P(synth.KITTI_P1, synth.KITTI_P2)
+    rng = np.random.default_rng(4242)
+    for scale, thresh in ((1e-25, 1.0), (1e-30, 1.0), (1e-21, 1.0), (1e-19, 1.0), (1e-17, 1.0), (1.0, 0.0), (1e-25, 0.0)):
+        for it in range(2):
+            kp1, kp2, d1, d2, mp = _medium_case(rng, F0 * scale)
+            mp = MatchParams.stereo(F0 * scale)
+            mp.sampson_thresh = thresh
+            mp.max_neighbors = 200 if it else 1000
+            want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+            got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+            assert np.array_equal(got, want), (scale, thresh, it, len(kp1), len(kp2))

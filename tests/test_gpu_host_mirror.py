@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import libviso_amd
-import pngutil
+import kitti_tree
 from libviso_amd import hostmath, synth
 from libviso_amd.abi import MatchParams
 
@@ -64,15 +64,7 @@ def test_kitti_driver_on_images(oracle, tmp_path):
         pytest.fail("libviso_amd/viso_kitti is missing: run __graft_entry__.build()")
     seq = synth.make_image_sequence(12, 6, n_kp=1500, width=720, height=240)
     home = str(tmp_path)
-    base = os.path.join(home, "sequences", "07")
-    for side in (0, 1):
-        os.makedirs(os.path.join(base, f"image_{side}"))
-        for t in range(6):
-            # KITTI's own layout: image_0/%06d.png, 8-bit grayscale (src/kitti.cpp:108-110)
-            pngutil.write_gray_png(os.path.join(base, f"image_{side}", "%06d.png" % t), seq["images"][t, side])
-    with open(os.path.join(base, "calib.txt"), "w") as f:
-        for name, P in (("P0", seq["P1"]), ("P1", seq["P2"]), ("P2", seq["P1"]), ("P3", seq["P2"])):
-            f.write(name + ": " + " ".join("%.12e" % v for v in P.reshape(-1)) + "\n")
+    kitti_tree.write_tree(home, "07", seq)
     nf, cap = 6, 1200
     kp = np.zeros((nf, 2, cap, 2), np.float32); n = np.zeros((nf, 2), np.int32); desc = np.zeros((nf, 2, cap, 121), np.float32)
     for t in range(nf):

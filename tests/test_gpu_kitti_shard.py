@@ -1,0 +1,97 @@
+"""BASELINE configs[3] (one KITTI sequence sharded over the GPUs of a node, trajectory gathered once) on a
+synthetic KITTI tree: any number of ranks writes the byte-identical pose file.
+
+  viso_kitti                                   one process (the reference's flow, src/kitti.cpp:79-118)
+  viso_kitti --gpus W --same-device            W forked rank processes, rank files, gather on the host
+  python -m libviso_amd.kitti_shard --gpus W   W torch.distributed ranks, records all-gathered (gloo here: the box
+                                               has one GPU; --backend nccl is the same code path with RCCL)
+Frames shard with a one-frame halo (src/viso.cpp:1208-1222), RANSAC streams are keyed on the absolute frame index,
+the pose chain (src/viso.cpp:1315-1321) runs over the gathered records."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import kitti_tree
+import libviso_amd
+from libviso_amd import hostmath, synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(os.path.dirname(libviso_amd.SO_PATH), "viso_kitti")
+N_FRAMES = 11          # 10 pairs: W = 3 cuts them 4 + 3 + 3
+FIRST = 5              # the files are 000005.png ...: `begin` is not 0
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    home = str(tmp_path_factory.mktemp("kitti"))
+    seq = synth.make_image_sequence(41, N_FRAMES, n_kp=1500, width=720, height=240)
+    kitti_tree.write_tree(home, "03", seq, first_index=FIRST)
+    return home, seq
+
+
+def _pose_file(home, sha):
+    return os.path.join(home, "results", "03", sha, "data", "03.txt")
+
+
+def _run(cmd, home):
+    env = dict(os.environ, KITTI_HOME=home, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_any_number_of_ranks_writes_the_same_pose_file(oracle, tree):
+    home, seq = tree
+    if not os.path.exists(EXE):
+        pytest.fail("libviso_amd/viso_kitti is missing: run __graft_entry__.build()")
+    out = _run([EXE, "w1", "03", str(FIRST)], home)
+    one = open(_pose_file(home, "w1"), "rb").read()
+    assert f"frames {N_FRAMES} " in out
+    assert len(one.splitlines()) == N_FRAMES        # identity + one pose per solved pair
+    # forked rank processes + rank files + host gather (C++ only)
+    for w in (2, 3):
+        out = _run([EXE, f"fork{w}", "03", str(FIRST), "--gpus", str(w), "--same-device"], home)
+        assert f"ranks {w}" in out
+        assert open(_pose_file(home, f"fork{w}"), "rb").read() == one, w
+        for r in range(w):
+            assert os.path.exists(os.path.join(home, "results", "03", f"fork{w}", "shards", f"03.{r}of{w}.rec"))
+    # torch.distributed ranks + one all-gather of the records
+    for w in (1, 2, 3):
+        out = _run([sys.executable, "-m", "libviso_amd.kitti_shard", f"dist{w}", "03", str(FIRST), "--gpus", str(w),
+                    "--backend", "gloo", "--same-device"], home)
+        assert f"ranks {w}" in out
+        assert open(_pose_file(home, f"dist{w}"), "rb").read() == one, w
+    # chunking inside a rank does not matter either
+    _run([EXE, "chunk3", "03", str(FIRST), "--gpus", "2", "--same-device", "--chunk", "3"], home)
+    assert open(_pose_file(home, "chunk3"), "rb").read() == one
+
+    # and the file is the oracle's: detector + extractor + loop body on the CPU, RANSAC keys = absolute frame index
+    cap = 1200
+    kp = np.zeros((N_FRAMES, 2, cap, 2), np.float32); n = np.zeros((N_FRAMES, 2), np.int32)
+    desc = np.zeros((N_FRAMES, 2, cap, 121), np.float32)
+    for t in range(N_FRAMES):
+        for side in range(2):
+            k, _ = oracle.detect_harris_binned(seq["images"][t, side])
+            n[t, side] = len(k); kp[t, side, :len(k)] = k
+            desc[t, side, :len(k)] = oracle.extract_descriptors(seq["images"][t, side], k)
+    st, tm = MatchParams.stereo(oracle.F_from_P(seq["P1"], seq["P2"])), MatchParams.temporal()
+    want = oracle.sequence(kp, desc, n, st, tm, seq["param"], seed=0, first_frame=FIRST)
+    poses, _ = hostmath.chain_poses(want["tr"], want["ok"])
+    got = np.loadtxt(_pose_file(home, "w1")).reshape(-1, 12)
+    assert got.shape[0] == len(poses)
+    for g, p in zip(got, poses):
+        assert np.abs(g - p[:3].reshape(-1)).max() < 2e-6 + 1e-5 * np.abs(p).max()
+
+
+def test_sub_range_with_begin_and_end(tree):
+    """begin/end (src/kitti.cpp:86-94) under sharding: frames FIRST+2 .. FIRST+8, W = 1 and 2."""
+    home, _ = tree
+    _run([EXE, "sub1", "03", str(FIRST + 2), str(FIRST + 8)], home)
+    _run([EXE, "sub2", "03", str(FIRST + 2), str(FIRST + 8), "--gpus", "2", "--same-device"], home)
+    a, b = open(_pose_file(home, "sub1"), "rb").read(), open(_pose_file(home, "sub2"), "rb").read()
+    assert a == b and len(a.splitlines()) == 7

@@ -1,0 +1,155 @@
+"""Edges of the solver contract (reference src/viso.cpp:1509-1537, 1583-1623) on the HIP path against the oracle:
+values placed AT the two thresholds (inlier_threshold^2, thresh) and one ulp either side, and the two ways the
+RANSAC stage can run a 3-point hypothesis (lane per hypothesis / wave per hypothesis with the 6x6 LU spread over
+lanes) compared bit for bit."""
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.int64)
+
+
+def test_every_split_of_the_gn_iterations_gives_the_same_hypotheses(viso):
+    """ransac_hyp_kernel (gn_serial: a lane runs the reference's loop) and ransac_coop_kernel (a wave per hypothesis:
+    Jacobian columns, normal-equation entries and the LU's entries one per lane) must agree to the last bit on every
+    hypothesis: state after the loop, verdict, support size.  split = 100 leaves everything to the lane kernel,
+    split = 1 nearly everything to the wave kernel."""
+    seq = synth.make_sequence(303, 17, n_kp=900, width=900, height=300, outlier_frac=0.35, noise_sigma=9.0)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    iters = seq["param"].ransac_iter
+    got = {}
+    for split in (100, 0, 1, 4, 37):
+        ctx = libviso_amd.Context(0)
+        libviso_amd.set_gn_split(split, ctx)
+        b = libviso_amd.Batch(ctx, 17, 900)
+        b.upload(seq["kp"], seq["desc"], seq["n"])
+        b.set_params(st, tm, seq["param"], seed=11)
+        b.run()
+        tr_h, ok_h, cnt_h, n_und = b.hypotheses(iters)
+        got[split] = (tr_h[1:], ok_h[1:], cnt_h[1:], n_und, b.poses())
+        b.close(); ctx.close()
+    ref = got[100]
+    assert ref[3] == 0                                   # nothing handed on
+    assert got[0][3] > 0 and got[1][3] > got[0][3]       # the wave kernel did have work
+    for split in (0, 1, 4, 37):
+        tr_h, ok_h, cnt_h, _, poses = got[split]
+        assert np.array_equal(ok_h, ref[1]), split
+        assert np.array_equal(cnt_h, ref[2]), split
+        decided = ok_h == 1                              # tr of a failed hypothesis is never read (src/viso.cpp:1559-1560)
+        assert np.array_equal(_bits(tr_h[decided]), _bits(ref[0][decided])), split
+        for a, r in zip(poses, ref[4]):
+            assert np.array_equal(_bits(a) if a.dtype == np.float64 else a, _bits(r) if r.dtype == np.float64 else r), split
+    # the mix this test is about: converged late, exhausted (100 iterations), singular
+    assert (ref[1] == 0).any() and (ref[1] == 1).any()
+
+
+def test_get_inliers_at_the_threshold(viso, oracle):
+    """err2 == inlier_threshold^2 exactly, one ulp below, one ulp above (strict <, src/viso.cpp:1527-1533).  With tr = 0
+    sin and cos are exact on both sides, so predict() is plain IEEE arithmetic: the observations are searched (in
+    ulps of obs[0]) until the sum of squares lands exactly on the three targets."""
+    X, obs, _, param = synth.make_solver_case(4, m=6000, outlier_frac=0.0, noise=0.0)
+    f, cu, cv, base = param.f, param.cu, param.cv, param.base
+    pred = np.stack([f * X[0] / X[2] + cu, f * X[1] / X[2] + cv, f * (X[0] - base) / X[2] + cu, f * X[1] / X[2] + cv])
+    thr2 = param.inlier_threshold * param.inlier_threshold
+    targets = {"below": np.nextafter(thr2, 0.0), "at": thr2, "above": np.nextafter(thr2, np.inf)}
+    rng = np.random.default_rng(8)
+    obs = pred + rng.choice([-1.0, 1.0], pred.shape)           # e = 1 + 1 + 1 + 1 nominally
+    hits = {k: [] for k in targets}
+
+    def err2(o, i):
+        e = o - pred[:, i]
+        return ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]
+    for i in range(X.shape[1]):
+        o = obs[:, i].copy()
+        for _ in range(200):                                    # walk obs[0] by ulps towards the next wanted target
+            want = min(targets, key=lambda k: len(hits[k]))
+            e = err2(o, i)
+            if e == targets[want]:
+                hits[want].append(i)
+                break
+            away = o[0] > pred[0, i]
+            o[0] = np.nextafter(o[0], (np.inf if away else -np.inf) if e < targets[want] else pred[0, i])
+        obs[:, i] = o
+    assert min(len(v) for v in hits.values()) > 50, {k: len(v) for k, v in hits.items()}
+    tr = np.zeros(6)
+    inl0, rms0 = oracle.get_inliers(X, obs, tr, param)
+    inl1, rms1 = libviso_amd.get_inliers(X, obs, tr, param)
+    assert np.array_equal(inl0, inl1) and rms0 == rms1
+    s = set(inl1.tolist())
+    assert all(i in s for i in hits["below"]) and not any(i in s for i in hits["at"]) and not any(i in s for i in hits["above"])
+    # the same points as the support count of RANSAC hypotheses (inlier_count_kernel) and of the refit (block_inliers):
+    # a batch-free call with one explicit triple
+    samples = np.tile(np.array([[0, 1, 2]], np.int32), (param.ransac_iter, 1))
+    ok0, tr0, in0 = oracle.ransac_minimize_reproj(X, obs, param, samples=samples)
+    ok1, tr1, in1 = libviso_amd.ransac_minimize_reproj(X, obs, param, samples=samples)
+    assert ok0 == ok1 and np.array_equal(in0, in1)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_first_gn_step_at_the_convergence_threshold(viso, oracle, seed):
+    """src/viso.cpp:1610 (Q7): "converged" iff no component of the step exceeds thresh.  thresh is set to the largest
+    component of the first step itself (found by bisection on the oracle: the smallest thresh for which it stops after
+    one iteration), and to its two neighbours.  A 3-point solve from zero: the lane-per-hypothesis arithmetic is the
+    reference's sum order, sin 0 / cos 0 are exact, so the step is the same double on both sides and the verdicts must
+    agree at all three."""
+    X, obs, _, param = synth.make_solver_case(60 + seed, m=40, outlier_frac=0.0, noise=0.4)
+    samples = np.tile(np.array([[3, 17, 29]], np.int32), (param.ransac_iter, 1))
+    active = samples[0]
+
+    def oracle_iters(thresh):
+        param.thresh = thresh
+        ok, tr, it = oracle.minimize_reproj(X, obs, np.zeros(6), param, active)
+        return ok, tr, it
+    lo, hi = 0.0, 1e6                                    # iterations(lo) > 1, iterations(hi) == 1
+    assert oracle_iters(hi)[2] == 1 and oracle_iters(lo)[2] > 1
+    lo_b, hi_b = np.float64(lo).view(np.int64), np.float64(hi).view(np.int64)
+    while hi_b - lo_b > 1:
+        mid = (lo_b + hi_b) // 2
+        if oracle_iters(float(np.int64(mid).view(np.float64)))[2] == 1:
+            hi_b = mid
+        else:
+            lo_b = mid
+    pmax = float(np.int64(hi_b).view(np.float64))         # the largest component of the first step, as the oracle computes it
+    assert pmax > 0
+    for thresh in (np.nextafter(pmax, 0.0), pmax, np.nextafter(pmax, np.inf)):
+        ok0, tr0, it0 = oracle_iters(float(thresh))
+        assert (it0 == 1) == (thresh >= pmax)
+        # the reference's RANSAC loop with this one triple: every hypothesis is this solve (ransac_hyp_kernel: the
+        # reference's summation order); what comes out (support set, refit) depends on whether the first step
+        # counted as converged (then tr stays 0: the step is NOT applied, :1616-1617)
+        param.thresh = float(thresh)
+        o_ok, o_tr, o_inl = oracle.ransac_minimize_reproj(X, obs, param, samples=samples)
+        g_ok, g_tr, g_inl = libviso_amd.ransac_minimize_reproj(X, obs, param, samples=samples)
+        assert o_ok == g_ok and np.array_equal(o_inl, g_inl), thresh
+
+
+def test_create_set_params_destroy_does_not_leak(viso):
+    """viso_batch_destroy must free everything viso_batch_set_params allocated (samp_h was left behind)."""
+    import torch
+    seq = synth.make_sequence(1, 2, n_kp=64, width=200, height=100)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+
+    def cycle():
+        b = libviso_amd.Batch(ctx, 64, 256)
+        b.set_params(st, tm, seq["param"], seed=1)
+        seq["param"].ransac_iter = 200                    # reallocation of the hypothesis buffers
+        b.set_params(st, tm, seq["param"], seed=1)
+        seq["param"].ransac_iter = 50
+        b.close()
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    ctx.close()
+    assert free0 - free1 < (1 << 20), f"{(free0 - free1) / 2**20:.1f} MiB lost over 40 create/destroy cycles"

@@ -2,7 +2,11 @@
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha   # noqa: E402  the counters belong to exactly these kernel sources
 
 out = {}
 for d in sys.argv[1:]:
@@ -13,4 +17,7 @@ for d in sys.argv[1:]:
     for k, v in acc.items():
         out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 keep = {k: v for k, v in out.items() if "match" in k or "ransac" in k or "pack" in k or "sort" in k}
-print(json.dumps(keep, indent=1))
+print(json.dumps({"kernel_source_sha256": kernel_source_sha(),
+                  "workload": f"configs[1], {os.environ.get('VISO_PMC_FRAMES', '512')} frame pairs/batch, 2000 kp/image, one stream "
+                              "(tools/pmc_batch.sh)",
+                  "kernels": keep}, indent=1))

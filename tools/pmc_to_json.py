@@ -4,7 +4,11 @@ wide, 16 B/lane, coalesced reads -> x2; WRITE_SIZE is exact)."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha   # noqa: E402  the counters belong to exactly these kernel sources
 
 
 def per_kernel(d, counter):
@@ -20,7 +24,8 @@ fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "W
 main = sys.argv[3] if len(sys.argv) > 3 else "match_union_kernel"
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --streams 1 "
                   "--steps 4 --warmup 1 --no-cpu --no-e2e --no-streaming (two separate passes, tools/profile_round.sh)",
-       "workload": "configs[1], 256 frame pairs/batch, 2000 kp/image (bench.py defaults)",
+       "workload": f"configs[1], {os.environ.get('VISO_PMC_FRAMES', '512')} frame pairs/batch, 2000 kp/image (bench.py defaults)",
+       "kernel_source_sha256": kernel_source_sha(),
        "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reads exactly 1/2 of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE exact",
        "other_kernels": {}}
 for k in sorted(set(fetch) | set(write)):
