@@ -256,6 +256,8 @@ def main():
         # never an honest-looking N = 1 line for a run that was asked for N GPUs (or the other way round)
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
         raise SystemExit(2)
+    if world > 1:
+        print(f"bench.py: rank {rank}/{world} started (pid {os.getpid()})", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
