@@ -52,6 +52,10 @@ struct ImageView {               // one image's keypoints + descriptors on the d
     uint8_t* qord;               // [n rounded up to 64] y order inside every block of 64 bucket-order positions: entry B*64 + r =
                                  //     offset (0..63) in block B of the keypoint with y rank r (positions past n rank last)
     uint16_t* rows;              // [n][128] packed descriptor rows, bucket order
+    uint2* sums;                 // [n] bucket order: sums of the row's four 32-element blocks, each clamped to int16 and
+                                 //     biased like the elements (4 x u16).  sum_k |S_q,k - S_t,k| <= SAD(q, t) (triangle
+                                 //     inequality per block; clamping is 1-Lipschitz): the lower bound match_prune_kernel
+                                 //     prunes candidates with.  Written by the pack kernels together with the rows.
     int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
                                  //     every problem that reads the image then takes the general (double) kernel
 };
@@ -174,6 +178,7 @@ struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
+int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,

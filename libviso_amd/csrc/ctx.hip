@@ -75,9 +75,9 @@ extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
     c = ctx_or_default(c);
     if (!c) return VISO_ERR_HIP;
 #ifdef VISO_DEBUG_VARIANTS
-    const bool known = variant >= 2 && variant <= 4;
+    const bool known = variant >= 2 && variant <= 5;
 #else
-    const bool known = variant == 3;
+    const bool known = variant == 3 || variant == 5;
 #endif
     if (!known) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
     c->matcher_variant = variant;
@@ -95,9 +95,9 @@ extern "C" int viso_ctx_set_gn_split(viso_ctx* c, int split) {
 // Variants this build of the library offers (no device needed): fills out[0..cap) and returns how many exist.
 extern "C" int viso_matcher_variants(int* out, int cap) {
 #ifdef VISO_DEBUG_VARIANTS
-    const int v[] = {2, 3, 4};
+    const int v[] = {2, 3, 4, 5};
 #else
-    const int v[] = {3};
+    const int v[] = {3, 5};
 #endif
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; out && i < n && i < cap; ++i) out[i] = v[i];
@@ -188,8 +188,8 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if ((r = ctx_scratch(c, 8, sizeof(int) * n1, (void**)&dpos)) < 0) return r;
     if ((r = ctx_scratch(c, 9, sizeof(int) * 16, (void**)&dmisc)) < 0) return r;
     if ((r = ctx_scratch(c, 10, sizeof(MatchProblem) + 2 * sizeof(ImageView), (void**)&dprob)) < 0) return r;
-    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64), 16-B aligned pieces
-    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64; };
+    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64) + sums (8n), 16-B aligned pieces
+    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64 + ((8 * n + 15) / 16) * 16; };
     if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
     int* dtile;
     if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
@@ -212,6 +212,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         v.bstart = (int*)tail;
         v.xinfo = (float*)(tail + 4 * (VISO_NB + 1));
         v.qord = (uint8_t*)(tail + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16);
+        v.sums = (uint2*)((unsigned char*)v.qord + ((n + 63) / 64) * 64);
         return v;
     };
     MatchProblem P{};

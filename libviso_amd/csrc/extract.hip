@@ -5,6 +5,7 @@
 // recomputes its 3x3 stencil from the uint8 image (L2-resident, 467 KB at
 // 1241x376).
 #include "common.h"
+#include "match_dev.h"
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
         if (k >= nk) break;                       // wave uniform
         const unsigned char* win = s_win[wv][k];
         uint32_t packed = 0;
+        int vsum = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 2 * lane + h;
@@ -155,8 +157,11 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
                 }
             }
             packed |= ((uint32_t)(v + VISO_BIAS) & 0xffffu) << (16 * h);
+            vsum += v;
         }
         reinterpret_cast<uint32_t*>(I.rows + (size_t)(j0 + k) * VISO_ROW)[lane] = packed;
+        const uint2 bs = pack_block_sums(vsum);      // ImageView::sums
+        if (lane == 0) I.sums[j0 + k] = bs;
     }
 }
 

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
         const uint32_t ua = (uint32_t)((int)ar + VISO_BIAS) & 0xffffu, ub = (uint32_t)((int)br + VISO_BIAS) & 0xffffu;
         const int d = __builtin_amdgcn_readlane(dst, k);
         ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
+        // block sums (ImageView::sums): lanes 16b..16b+15 hold block b; meaningless for flagged images (never read then)
+        const uint2 bs = pack_block_sums((int)ar + (int)br);
+        if (lane == 0) I.sums[d] = bs;
     }
     if (__any(isbad) && lane == 0) { atomicOr(I.bad, 1); atomicOr(bad_any, 1); }
 }
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
 // 2 and 4 exist in -DVISO_DEBUG_VARIANTS builds only (make DEBUG_VARIANTS=1).
 // The stereo problems always take match_batch_kernel<1>.  Same results from all of them (the parity tests run over viso_matcher_variants(): a DEBUG_VARIANTS build gets all three tested).
 const char* matcher_kernel_name(int variant) {
-    return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : "match_strip_kernel";
+    return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : variant == 5 ? "match_prune_kernel" : "match_strip_kernel";
 }
 
 // layout 0: problems in any order (both instantiations enumerate all of them);

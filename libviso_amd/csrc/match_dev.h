@@ -10,6 +10,19 @@ __device__ __forceinline__ int mbcnt(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// v = this lane's share (elements 2l, 2l+1) of a row: the four 32-element block sums (16 lanes each), clamped to int16,
+// biased, packed as 4 x u16.  Valid in every lane.
+__device__ __forceinline__ uint2 pack_block_sums(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // lane ^ 1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // lane ^ 2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // 7 - lane within 8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // 15 - lane within 16
+    v = min(max(v, -32768), 32767) + VISO_BIAS;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane(v, 0), s1 = (uint32_t)__builtin_amdgcn_readlane(v, 16);
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane(v, 32), s3 = (uint32_t)__builtin_amdgcn_readlane(v, 48);
+    return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+}
+
 // cvflann::L1<float> over 2 elements: result = 0; result += |a0-b0|; result += |a1-b1|
 __device__ __forceinline__ float l1_kp(float qx, float qy, float2 t) {
     float r = fabsf(qx - t.x);

@@ -62,22 +62,22 @@ def test_get_inliers_at_the_threshold(viso, oracle):
     rng = np.random.default_rng(8)
     obs = pred + rng.choice([-1.0, 1.0], pred.shape)           # e = 1 + 1 + 1 + 1 nominally
     hits = {k: [] for k in targets}
-
-    def err2(o, i):
-        e = o - pred[:, i]
-        return ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]
+    # err2 moves by ~2e-13 per ulp of one observation, an ulp of 4 is 4e-16 (9e-16 above): single steps jump over the
+    # targets, but the four components together reach every double near 4 -- random ulp offsets of all four, per point
+    # until one of the three targets is hit exactly (the next wanted one first)
+    ob = obs.view(np.int64)
     for i in range(X.shape[1]):
-        o = obs[:, i].copy()
-        for _ in range(200):                                    # walk obs[0] by ulps towards the next wanted target
-            want = min(targets, key=lambda k: len(hits[k]))
-            e = err2(o, i)
-            if e == targets[want]:
+        k = rng.integers(-40, 41, (4, 4000))
+        o = (ob[:, i, None] + k).view(np.float64)               # +-1 on the bits = one ulp
+        e = o - pred[:, i, None]
+        e2 = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]
+        for want in sorted(targets, key=lambda t: len(hits[t])):
+            j = np.flatnonzero(e2 == targets[want])
+            if len(j):
+                obs[:, i] = o[:, j[0]]
                 hits[want].append(i)
                 break
-            away = o[0] > pred[0, i]
-            o[0] = np.nextafter(o[0], (np.inf if away else -np.inf) if e < targets[want] else pred[0, i])
-        obs[:, i] = o
-    assert min(len(v) for v in hits.values()) > 50, {k: len(v) for k, v in hits.items()}
+    assert min(len(v) for v in hits.values()) > 20, {k: len(v) for k, v in hits.items()}
     tr = np.zeros(6)
     inl0, rms0 = oracle.get_inliers(X, obs, tr, param)
     inl1, rms1 = libviso_amd.get_inliers(X, obs, tr, param)
@@ -109,14 +109,16 @@ def test_first_gn_step_at_the_convergence_threshold(viso, oracle, seed):
         return ok, tr, it
     lo, hi = 0.0, 1e6                                    # iterations(lo) > 1, iterations(hi) == 1
     assert oracle_iters(hi)[2] == 1 and oracle_iters(lo)[2] > 1
-    lo_b, hi_b = np.float64(lo).view(np.int64), np.float64(hi).view(np.int64)
+    bits = lambda x: int(np.float64(x).view(np.uint64))             # positive doubles order like their bit patterns
+    val = lambda b: float(np.uint64(b).view(np.float64))
+    lo_b, hi_b = bits(lo), bits(hi)
     while hi_b - lo_b > 1:
         mid = (lo_b + hi_b) // 2
-        if oracle_iters(float(np.int64(mid).view(np.float64)))[2] == 1:
+        if oracle_iters(val(mid))[2] == 1:
             hi_b = mid
         else:
             lo_b = mid
-    pmax = float(np.int64(hi_b).view(np.float64))         # the largest component of the first step, as the oracle computes it
+    pmax = val(hi_b)                                     # the largest component of the first step, as the oracle computes it
     assert pmax > 0
     for thresh in (np.nextafter(pmax, 0.0), pmax, np.nextafter(pmax, np.inf)):
         ok0, tr0, it0 = oracle_iters(float(thresh))
