@@ -551,6 +551,30 @@ def main():
                                     "host_bytes_per_step_per_gpu": bytes_step, "pcie_GBps_per_gpu": bytes_step * s_steps / dts / 1e9,
                                     "workload": "every step: viso_batch_upload_async of N x 121 f32 descriptors + keypoints from pinned "
                                                 "host memory, then the resident pipeline; alternating between two different sequences"}}
+        # the same with int16 descriptor rows (viso_batch_upload_i16_async: the lossless encoding, half the bytes)
+        h16 = []
+        for rev in (False, True):
+            pd16 = libviso_amd.PinnedArray(seq["desc"].shape, np.int16)
+            pd16.a[...] = (seq["desc"][::-1] if rev else seq["desc"]).astype(np.int16)
+            h16.append(pd16)
+
+        def stream_step_i16(full):
+            def f(b):
+                i = cnt["i"] % 2
+                cnt["i"] += 1
+                b.upload_i16(hosts[i][0].a, h16[i].a, hosts[i][2], asynchronous=True)
+                (b.run if full else b.run_matcher)()
+            return f
+        dts16 = float(np.median(timed_regions(stream_step_i16(False), s_steps, n_streams)))
+        dte16 = float(np.median(timed_regions(stream_step_i16(True), s_steps, n_streams))) if not args.no_e2e else None
+        bytes16 = seq["kp"].nbytes + seq["desc"].nbytes // 2 + seq["n"].nbytes
+        streaming["feature_in_i16"] = {"fps_matcher": args.frames * s_steps * world / dts16,
+                                       "fps_end_to_end": args.frames * s_steps * world / dte16 if dte16 else None,
+                                       "host_bytes_per_step_per_gpu": bytes16, "pcie_GBps_per_gpu": bytes16 * s_steps / dts16 / 1e9,
+                                       "workload": "as feature_in, descriptors as N x 121 int16 (viso_batch_upload_i16_async): same results, "
+                                                   "half the descriptor bytes over PCIe"}
+        for pd16 in h16:
+            pd16.close()
         for pk, pd, _ in hosts:
             pk.close(); pd.close()
         for _, b in lanes:   # the resident legs below expect the original sequence

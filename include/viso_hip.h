@@ -219,6 +219,15 @@ int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
  * host that feeds new frames every step (sequence_odometry consumes fresh data per frame, src/viso.cpp:1205-1231). */
 int viso_batch_upload_async(viso_batch* b, int f0, int nf, const float* kp,
                             const float* desc, const int32_t* n);
+/* The same uploads with the descriptors as int16 (N x dlen, tightly packed over [nf][2][cap][dlen]): the lossless
+ * encoding of what MyFeatureExtractor produces (3x3 Sobel of uint8: integers in [-1020, 1020], src/viso.cpp:1004-1024)
+ * at half the bytes of the reference's CV_32F rows (:995,1008) — the PCIe-bound streaming mode moves half the data.
+ * Same results as the f32 uploads of the same values.  All frames of a batch must come through ONE of the two
+ * families (the int16 rows live in the f32 rows' device buffer); needs dlen <= 128. */
+int viso_batch_upload_i16(viso_batch* b, int f0, int nf, const float* kp,
+                          const int16_t* desc16, const int32_t* n);
+int viso_batch_upload_i16_async(viso_batch* b, int f0, int nf, const float* kp,
+                                const int16_t* desc16, const int32_t* n);
 void* viso_host_alloc(size_t bytes);
 int viso_host_free(void* p);
 /* Device pointers of the boundary-layout buffers, for producers that already

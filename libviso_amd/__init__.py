@@ -71,6 +71,8 @@ def load():
     L.viso_batch_upload_async.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, i32p]
     L.viso_batch_upload_images_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
                                                  f32p, i32p]
+    L.viso_batch_upload_i16.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.POINTER(C.c_int16), i32p]
+    L.viso_batch_upload_i16_async.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.POINTER(C.c_int16), i32p]
     L.viso_match_desc.restype = C.c_int
     L.viso_match_desc.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, f32p, C.c_int, MP, i32p, intp]
     L.viso_minimize_reproj.restype = C.c_int
@@ -435,6 +437,16 @@ class Batch:
         nf = kp.shape[0]
         self._chk("viso_batch_upload_async", self.L.viso_batch_upload_async(self.h, f0, nf, ptr(kp, C.c_float),
                                                                              ptr(desc, C.c_float), ptr(n, C.c_int32)))
+
+    def upload_i16(self, kp, desc16, n, f0=0, asynchronous=False):
+        """Descriptors as int16 [nf][2][cap][dlen] (the lossless encoding of the Sobel windows; half the bytes).
+        asynchronous=True: enqueued on the context's stream; kp / desc16 should be PinnedArray views."""
+        kp, n = _f32(kp), _i32(n)
+        assert desc16.dtype == np.int16 and desc16.flags.c_contiguous
+        nf = kp.shape[0]
+        assert kp.shape == (nf, 2, self.cap, 2) and desc16.shape == (nf, 2, self.cap, self.dlen)
+        fn = self.L.viso_batch_upload_i16_async if asynchronous else self.L.viso_batch_upload_i16
+        self._chk("viso_batch_upload_i16", fn(self.h, f0, nf, ptr(kp, C.c_float), ptr(desc16, C.c_int16), ptr(n, C.c_int32)))
 
     def upload_images_async(self, images, kp, n, f0=0):
         assert images.dtype == np.uint8 and images.flags.c_contiguous and kp.dtype == np.float32 and kp.flags.c_contiguous

@@ -44,6 +44,7 @@ struct viso_batch {
     unsigned long long seed, first_frame;
     bool params_set;
     bool timing;
+    bool desc_i16;             // the descriptor buffer holds int16 rows (viso_batch_upload_i16*), not the f32 boundary layout
     // The RANSAC stage of run k (latency bound: a few hundred waves on serial fp64 chains for ~1 ms) runs on a
     // stream of its own (the context's second stream), so that the matcher of run k+1 — which touches none of its
     // buffers — fills the GPU beside it: stream (matcher, triangulation, circle join) --ev_join--> solver_stream (RANSAC) --ev_ransac--> the next
@@ -208,7 +209,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     viso_batch* b = new viso_batch();
     b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
     b->n_probs = ((n_frames + 7) / 8) * 24;
-    b->params_set = false; b->timing = false;
+    b->params_set = false; b->timing = false; b->desc_i16 = false;
     b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     b->solver_stream = nullptr; b->ev_join = nullptr; b->ev_ransac = nullptr; b->ransac_pending = false;
     if (ctx->solver_stream) {
@@ -279,6 +280,7 @@ extern "C" int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
     if (nf == 0) return VISO_OK;
     int r;
     if ((r = enter(b)) < 0) return r;
+    b->desc_i16 = false;
     // the batch's kernels run on a non-blocking stream: order the copies behind them, then wait (synchronous call)
     hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
@@ -327,11 +329,42 @@ extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const floa
     if (nf == 0) return VISO_OK;
     int r;
     if ((r = enter(b)) < 0) return r;
+    b->desc_i16 = false;
     hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
     HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->desc + (size_t)f0 * 2 * c * b->dlen, desc, sizeof(float) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice, s));
     return stage_n_async(b, f0, nf, n, s);
+}
+
+// The descriptors as int16 (N x dlen, tightly packed): the lossless encoding of the reference's Sobel windows (integers
+// in [-1020, 1020], src/viso.cpp:1004-1024) at half the bytes of the CV_32F boundary layout.  They live in the same
+// device buffer as the f32 rows (reinterpreted), so all frames of a batch must come through ONE of the two families;
+// the last upload decides which pack kernel the next run uses.  sync != 0: wait for the copies.
+static int upload_i16_impl(viso_batch* b, int f0, int nf, const float* kp, const int16_t* desc16, const int32_t* n, bool sync,
+                           const char* who) {
+    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc16 || !n))) { viso_set_error("%s: bad argument", who); return VISO_ERR_ARG; }
+    if (b->dlen > VISO_ROW) { viso_set_error("%s: int16 descriptors need dlen <= %d", who, VISO_ROW); return VISO_ERR_UNSUPPORTED; }
+    for (int i = 0; i < 2 * nf; ++i)
+        if (n[i] < 0 || n[i] > b->cap) { viso_set_error("%s: n[%d]=%d exceeds cap %d", who, i, n[i], b->cap); return VISO_ERR_ARG; }
+    if (nf == 0) return VISO_OK;
+    int r;
+    if ((r = enter(b)) < 0) return r;
+    b->desc_i16 = true;
+    hipStream_t s = b->ctx->stream;
+    const size_t c = (size_t)b->cap;
+    int16_t* d16 = reinterpret_cast<int16_t*>(b->desc);
+    HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d16 + (size_t)f0 * 2 * c * b->dlen, desc16, sizeof(int16_t) * (size_t)nf * 2 * c * b->dlen, hipMemcpyHostToDevice, s));
+    if ((r = stage_n_async(b, f0, nf, n, s)) < 0) return r;
+    if (sync) HIP_TRY(hipStreamSynchronize(s));
+    return VISO_OK;
+}
+extern "C" int viso_batch_upload_i16(viso_batch* b, int f0, int nf, const float* kp, const int16_t* desc16, const int32_t* n) {
+    return upload_i16_impl(b, f0, nf, kp, desc16, n, true, "viso_batch_upload_i16");
+}
+extern "C" int viso_batch_upload_i16_async(viso_batch* b, int f0, int nf, const float* kp, const int16_t* desc16, const int32_t* n) {
+    return upload_i16_impl(b, f0, nf, kp, desc16, n, false, "viso_batch_upload_i16_async");
 }
 
 extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
@@ -417,7 +450,9 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
         if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols)) < 0) return r;
     } else {
-        if ((r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any)) < 0) return r;
+        if (b->desc_i16) r = launch_pack_i16(s, b->views, b->nf * 2, b->cap, b->dlen, reinterpret_cast<const int16_t*>(b->desc));
+        else r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any);
+        if (r < 0) return r;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {

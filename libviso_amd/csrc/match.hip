@@ -212,6 +212,67 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
     if (__any(isbad) && lane == 0) { atomicOr(I.bad, 1); atomicOr(bad_any, 1); }
 }
 
+// The same rows from int16 descriptors (viso_batch_upload_i16*: the lossless encoding of the reference's N x 121
+// CV_32F Sobel windows, half the PCIe bytes).  desc16: [n_img][cap][dlen] int16, tightly packed; one wave = 8
+// consecutive rows = one contiguous 16-B aligned run of 8 * dlen * 2 bytes.  An int16 always fits the rows: no flag.
+__global__ __launch_bounds__(256) void pack_desc_i16_kernel(const ImageView* __restrict__ imgs, int n_img, int cap, int cap_stride,
+                                                            int dlen, const int16_t* __restrict__ desc16) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_buf[4][VISO_PACK_RPW * VISO_ROW];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+    typedef const __attribute__((address_space(1))) uint16_t* gu16_t;
+    typedef const __attribute__((address_space(1))) int* gint_t;
+    typedef __attribute__((address_space(1))) uint32_t* gout_t;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    const long long row0 = wave * VISO_PACK_RPW;
+    if (row0 >= (long long)n_img * cap) return;
+    const int img = (int)(row0 / cap);      // cap is a multiple of VISO_PACK_RPW: a wave never straddles images
+    const ImageView I = imgs[img];
+    const int n = *I.n;
+    const int r0 = (int)(row0 % cap);
+    if (r0 >= n) return;
+    const int nrows = min(VISO_PACK_RPW, n - r0);
+    const int ne = nrows * dlen;            // int16 elements of this wave's rows, contiguous
+    const int16_t* src = desc16 + ((size_t)img * cap_stride + r0) * dlen;
+    uint16_t* buf = s_buf[wv];
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+        const gvec_t v = (gvec_t)reinterpret_cast<const u32x4*>(src);
+        const int nq = ne >> 3;             // 16-B pieces
+        for (int q = lane; q < nq; q += 64) *reinterpret_cast<u32x4*>(buf + 8 * q) = v[q];
+        const int e = (nq << 3) + lane;     // the up to 7 elements behind the last full 16 B
+        if (e < ne) buf[e] = ((gu16_t)reinterpret_cast<const uint16_t*>(src))[e];
+    } else {
+        for (int e = lane; e < ne; e += 64) buf[e] = ((gu16_t)reinterpret_cast<const uint16_t*>(src))[e];
+    }
+    int dst = 0;
+    if (lane < nrows) dst = ((gint_t)I.rank)[r0 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int c = 2 * lane;
+#pragma unroll
+    for (int k = 0; k < VISO_PACK_RPW; ++k) {
+        if (k >= nrows) break;              // wave uniform
+        const int a = c < dlen ? (int)(int16_t)buf[k * dlen + c] : 0;
+        const int b = c + 1 < dlen ? (int)(int16_t)buf[k * dlen + c + 1] : 0;
+        const uint32_t ua = (uint32_t)(a + VISO_BIAS) & 0xffffu, ub = (uint32_t)(b + VISO_BIAS) & 0xffffu;
+        const int d = __builtin_amdgcn_readlane(dst, k);
+        ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
+        const uint2 bs = pack_block_sums(a + b);
+        if (lane == 0) I.sums[d] = bs;
+    }
+}
+
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16) {
+    if (n_img <= 0) return VISO_OK;
+    if (dlen > VISO_ROW) { viso_set_error("int16 descriptors longer than %d are not supported", VISO_ROW); return VISO_ERR_UNSUPPORTED; }
+    const int capp = (cap + VISO_PACK_RPW - 1) / VISO_PACK_RPW * VISO_PACK_RPW;
+    const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
+    if (waves == 0) return VISO_OK;
+    hipLaunchKernelGGL(pack_desc_i16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp, cap, dlen, desc16);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
 __global__ void flag_all_kernel(int* flags, int n, int* any) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = 1;
