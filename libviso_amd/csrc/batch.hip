@@ -445,8 +445,8 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     int r;
     if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
-    HIP_TRY(hipMemsetAsync(b->scored, 0, b->zeroed_bytes, s));   // scored, ovf_cnt, bad_img, bad_any
-    if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap)) < 0) return r;
+    // the run's counters (scored, ovf_cnt, bad_img, bad_any) are zeroed by the first kernel of the run, not by a memset
+    if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap, reinterpret_cast<uint32_t*>(b->scored), (int)(b->zeroed_bytes / 4))) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
         if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols)) < 0) return r;
     } else {
@@ -581,7 +581,7 @@ static int run_rest(viso_batch* b) {
             HIP_TRY(hipStreamWaitEvent(ss, b->ev_join, 0));
         }
     }
-    HIP_TRY(hipMemsetAsync(b->tr, 0, sizeof(double) * 6 * (size_t)b->nf, ss));           // vector<double> tr(6,0), :1312
+    // vector<double> tr(6,0), :1312: ransac_refit_kernel writes the zeros itself where no solve succeeds
     if (b->nf > 1) {
         if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq, b->ctx->gn_split)) < 0) return r;   // :1313
     }

@@ -104,7 +104,8 @@ viso_ctx* viso_default_ctx();
 
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max);
+// zero_words / n_zero: optional 32-bit words the kernel zeroes on the way (a run's counters: one memset less in front of it)
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words = nullptr, int n_zero = 0);
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
@@ -172,7 +173,8 @@ int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_it
                                const SolverParamsDev& sp, int cap);
 struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_kernel (tiles of 64 queries)
     const MatchProblem* probs;
-    int n_probs, bpp, gs, gf, gc, _pad;
+    int n_probs, bpp, gs, gf, gc;
+    int vblocks;                 // match_batch_kernel: (problem, tile) slots the grid walks (the stereo instantiation gets a small grid)
     int* bad;                    // [0] "some image of this run is flagged": lets the (normally idle) general kernels leave at once
                                  // [1] tiles match_stereo_kernel left to match_batch_kernel<1> (0: that kernel leaves at once)
     MatchParamsDev mp[2];

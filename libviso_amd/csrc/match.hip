@@ -43,13 +43,21 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 // order inside every block of 64 consecutive entries (ImageView::qord).
 #define VISO_IMG_THREADS 512
 
-__global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc) {
+__global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
+                                                                   uint32_t* zero_words, int n_zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* ykey = reinterpret_cast<uint32_t*>(smem);   // [n rounded up to 64] sortable y of the entry at each position
     __shared__ int s_cnt[VISO_NB + 1];                    // bucket counts -> starts -> running offsets
     __shared__ float s_red[5][VISO_IMG_THREADS / 64];
     __shared__ float s_x[2];
     if ((int)blockIdx.x >= n_img) return;
+    if (zero_words) {   // this workgroup's slice of the run's counters (first kernel of a run: everything that counts comes later)
+        const int per = (n_zero + n_img - 1) / n_img;
+        for (int i = threadIdx.x; i < per; i += VISO_IMG_THREADS) {
+            const int j = (int)blockIdx.x * per + i;
+            if (j < n_zero) zero_words[j] = 0u;
+        }
+    }
     const ImageView I = imgs[blockIdx.x];
     const int n = *I.n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     }
 }
 
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max) {
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero) {
     if (n_img <= 0) return VISO_OK;
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
@@ -144,7 +152,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
     const size_t lds = (size_t)n64 * sizeof(uint32_t) + 16;
     if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_kp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64);
+    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64, zero_words, n_zero);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -921,7 +929,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     }
     // general (non-u16) path: normally idle (no image is flagged and every block leaves at once), so
     // it gets a small grid that strides over the (problem, tile) slots when it does have work
-    const unsigned gblocks = (unsigned)(blocks < 2048 ? blocks : 2048);
+    const unsigned gblocks = (unsigned)(blocks < 512 ? blocks : 512);
     if (general_possible) {
         hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());

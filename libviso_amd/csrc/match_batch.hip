@@ -60,24 +60,28 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     __shared__ int s_idx[MB_KPCAP];
     __shared__ float s_xr[4];
     if (EPI && a.bad[1] == 0) return;   // match_stereo_kernel has done every stereo tile (rectified pairs: always)
+    // The grid walks the (problem, tile) slots: for the stereo instantiation it is a SMALL grid (the kernel is normally
+    // idle — rectified pairs decline no tile — and thousands of workgroups that leave at once cost ~19 us per step)
+    for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
+    if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's LDS is still being read by other waves
     int prob, qblk;
     {
-        const int b = blockIdx.x;
+        const int b = vb;
         const int xcd = b & 7, slot = b >> 3;
         const int g = slot / a.bpp;
         prob = ((g / a.gc) * a.gs + a.gf + g % a.gc) * 8 + xcd;
         qblk = slot % a.bpp;
-        if (prob >= a.n_probs) return;
+        if (prob >= a.n_probs) continue;
     }
     const MatchProblem P = a.probs[prob];
-    if ((*P.q.bad | *P.t.bad) != 0) return;   // non-integer descriptors: the general kernel does this problem
+    if ((*P.q.bad | *P.t.bad) != 0) continue;   // non-integer descriptors: the general kernel does this problem
     const int n1 = *P.q.n, n2 = *P.t.n;
     const int q0 = qblk * MB_QPB;
-    if (q0 >= n1) return;
+    if (q0 >= n1) continue;
     const int q1 = min(q0 + MB_QPB, n1);
     const MatchParamsDev& mp = a.mp[P.pidx];
-    if ((mp.epi != 0) != (EPI != 0)) return;
-    if (EPI && P.tile_flag[qblk] == 0) return;   // match_stereo_kernel (narrow epipolar band) has done this tile
+    if ((mp.epi != 0) != (EPI != 0)) continue;
+    if (EPI && P.tile_flag[qblk] == 0) continue;   // match_stereo_kernel (narrow epipolar band) has done this tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // ---- tile window (identical to match_kernel)
     if (wave == 0) {
@@ -450,6 +454,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
     scored += (unsigned long long)__shfl_xor((long long)scored, 16);
     scored += (unsigned long long)__shfl_xor((long long)scored, 32);
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
+    }   // walk over the slots
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
@@ -458,7 +463,7 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     a.probs = probs_dev;
     a.n_probs = n_probs;
     a.bpp = (cap_max + MB_QPB - 1) / MB_QPB;
-    a.gs = 1; a.gf = 0; a.gc = 1; a._pad = 0;
+    a.gs = 1; a.gf = 0; a.gc = 1; a.vblocks = 0;
     a.bad = bad;
     a.mp[0] = mp[0];
     a.mp[1] = mp[1];
@@ -473,6 +478,7 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
 #ifdef VISO_DEBUG_VARIANTS
     if (variant == 2) {
+        at.vblocks = (int)bt;
         hipLaunchKernelGGL((match_batch_kernel<0>), dim3((unsigned)bt), dim3(MB_THREADS), 0, s, at);
         HIP_TRY(hipGetLastError());
     } else
@@ -495,7 +501,8 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         const int r = launch_match_stereo(s, as, cap_max);
         if (r < 0) return r;
     }
-    hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)bs), dim3(MB_THREADS), 0, s, as);
+    as.vblocks = (int)bs;
+    hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)(bs < 1024 ? bs : 1024)), dim3(MB_THREADS), 0, s, as);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -29,6 +29,7 @@ struct SolverArgs {
 __global__ __launch_bounds__(256) void ransac_sample_kernel(SolverArgs a) {
     const int lane = threadIdx.x & 63;
     const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid == 0 && lane == 0) a.queue[0] = 0;   // the list of undecided hypotheses (ransac_hyp_kernel appends) starts empty
     if (gid >= (long long)a.n_items * a.iters) return;
     const int item = (int)(gid / a.iters), h = (int)(gid % a.iters);
     const SolverItem S = a.items[item];
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
     const int m = *S.m_ptr;
     if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
         if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
+        if (threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // vector<double> tr(6,0), :1312 (no memset in front of the stage)
         return;
     }
     if (threadIdx.x == 0) {
@@ -450,13 +452,14 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
         for (int h = 0; h < a.iters; ++h)
             if (S.ok_h[h] && S.cnt_h[h] > best_cnt) { best_cnt = S.cnt_h[h]; best = h; }   // strict >, :1564
         scratch[4] = best;
-        for (int j = 0; j < 6; ++j) tr_s[j] = best >= 0 ? S.tr_h[6 * best + j] : S.tr[j];
+        for (int j = 0; j < 6; ++j) tr_s[j] = best >= 0 ? S.tr_h[6 * best + j] : 0.0;
     }
     __syncthreads();
     const int best = scratch[4];
     __syncthreads();
     if (best < 0) {   // no hypothesis found any support: best_inliers stays empty, :1571
         if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
+        if (threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // best_tr keeps the caller's zeros, :1312
         return;
     }
     double tr[6];
@@ -492,7 +495,6 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
-        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), s));
         hipLaunchKernelGGL(ransac_sample_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
