@@ -19,7 +19,7 @@ import numpy as np
 from .abi import (DESC_LEN, MatchParams, Param, declare_common, f32p, f64p, i32p, i64p, intp, ptr)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libviso_hip.so")
+SO_PATH = os.environ.get("VISO_HIP_SO") or os.path.join(_HERE, "libviso_hip.so")   # VISO_HIP_SO: another build of the library (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
 

@@ -1,23 +1,28 @@
-// match_union.hip — temporal (no epipolar gate) matcher, "one row load, four queries".
+// match_union.hip — temporal (no epipolar gate) matcher: one row load scored against EIGHT y-adjacent queries.
 //
-// The matcher is bound by the texture-address unit: every candidate pair costs two 16-B gathers per lane
-// (match_batch.hip: TA busy ~80 %).  Queries that are close in the image share most of their candidates, so
-// this kernel scores a loaded target row against FOUR queries at once:
+// The dominant kernel (97 % of the scored pairs).  It is bound by vector-ALU issue, not by memory: VALUBusy 1.04 with
+// 7 waves per SIMD; HBM traffic is the compulsory u16 rows (x 1.05), the row gathers are served by the
+// XCD's L2.  What it spends per useful SAD is what matters, so everything is arranged to share work between queries:
 //
-//   tile    64 x-adjacent queries (one workgroup, 4 waves) and their target window in LDS, as match_batch.hip;
-//           the tile's queries are additionally ranked by y, and every wave works on rounds of four
-//           y-adjacent queries (their L1 diamonds overlap by ~2/3: the union of the four candidate sets is
-//           about a third of their sum)
-//   phase 1 one scan of the window for the round: per target a 4-bit membership mask (which of the four
-//           queries has it in radius, Q1 cut included); targets with a non-zero mask go to the union list
-//   phase 2 rolling pipeline over the union list, 8 lanes per row: load the row once, SAD against the four
-//           query rows (staged per wave in LDS: 8 x ds_read_b128 per pass cost less than the 32 registers that
-//           would hold them — 6 instead of 5 waves per SIMD), lanes sub = 0..3 of each 8-lane group keep a
-//           running (min, second min with multiplicity, argmin, tie) for "their" query — no SAD goes to memory
-//   phase 3 merge the 8 partial trackers per query across the lane groups, ratio test, store
+//   tile    64 consecutive (column-bucket order) queries of one problem = one 256-thread workgroup; the +-radius column
+//           window of the target image (two loads from the bucket index), its KEYPOINTS (8 B each, not its rows)
+//           bucket-sorted by y in LDS
+//   round   eight y-adjacent queries (ImageView::qord) per wave, two rounds per wave: their L1 diamonds overlap so much
+//           that the union of the candidate sets is ~94 rows for 8 x 51.5 candidates
+//   phase 1 one scan of the y buckets the round's diamonds touch, 32 targets per step with both lane halves on the same
+//           targets (lanes 0..31 test queries 0..3, lanes 32..63 queries 4..7; Q1 cut and radius as ONE unsigned compare
+//           of the bit pattern of |dx| + |dy|); targets with a non-zero 8-bit membership mask are appended (ballot +
+//           mbcnt) to the round's union list in LDS; per-query in-radius counts (K cap) are bit counts over the list
+//   phase 2 rolling pipeline over the union list, 8 lanes per row, 2 passes in flight: two global_load_dwordx4 per lane,
+//           8 x v_sad_u16 against each of the eight query rows (staged per wave in LDS), a transposing reduction (three
+//           exchange steps, each halving the partial sums a lane carries: every lane of the 8-lane group ends with the
+//           total of ITS query) and a packed-key tracker (key = SAD << 9 | list position; m2 = med3, m1 = min) — no SAD
+//           ever goes to memory
+//   phase 3 merge the 8 partial trackers per query across the lane groups, ratio test in double, store
 //
-// Same results as the other matcher kernels.  Irregular rounds (a query with more than K in-radius
-// candidates, a union list that does not fit, an exact tie of the minimum) go to match_overflow_kernel.
+// Same results as the other matcher kernels.  Irregular rounds (a query with more than K in-radius candidates, a union
+// list that does not fit, an exact tie of the minimum) go to match_overflow_kernel.  match_prune.hip is the same tile /
+// scan with exact candidate pruning in front of a cell-granular phase 2 (variant 5: fewer instructions, same time).
 #include "common.h"
 #include "match_dev.h"
 
