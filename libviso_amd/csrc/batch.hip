@@ -445,13 +445,14 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     int r;
     if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
+    const int with_sums = b->ctx->matcher_variant == 5;   // block sums: only match_prune_kernel reads them
     // the run's counters (scored, ovf_cnt, bad_img, bad_any) are zeroed by the first kernel of the run, not by a memset
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap, reinterpret_cast<uint32_t*>(b->scored), (int)(b->zeroed_bytes / 4))) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
-        if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols)) < 0) return r;
+        if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols, with_sums)) < 0) return r;
     } else {
-        if (b->desc_i16) r = launch_pack_i16(s, b->views, b->nf * 2, b->cap, b->dlen, reinterpret_cast<const int16_t*>(b->desc));
-        else r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any);
+        if (b->desc_i16) r = launch_pack_i16(s, b->views, b->nf * 2, b->cap, b->dlen, reinterpret_cast<const int16_t*>(b->desc), with_sums);
+        else r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any, with_sums);
         if (r < 0) return r;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;

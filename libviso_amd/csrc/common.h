@@ -109,9 +109,10 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any);
+// with_sums != 0: also the rows' block sums (ImageView::sums), which only match_prune_kernel (matcher variant 5) reads
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int with_sums);
 // the same from int16 descriptors [n_img][cap][dlen] (viso_batch_upload_i16*): never flags anything
-int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16);
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int with_sums);
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt);
@@ -186,7 +187,7 @@ int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long lon
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
-                        int rows, int cols);
+                        int rows, int cols, int with_sums);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
 int launch_harris_bins(hipStream_t s, const float* resp, int n_img, int rows, int cols, int n_features, int nbinx,
                        int nbiny, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,

@@ -234,7 +234,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         const int one[1] = {1};
         HIP_TRY(hipMemcpyAsync(dmisc + 2, one, sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(dmisc + 7, one, sizeof(int), hipMemcpyHostToDevice, s));
-    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7)) < 0) return r;
+    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, c->matcher_variant == 5)) < 0) return r;
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];

@@ -5,11 +5,11 @@
 # then: python3 tools/pmc_to_json.py gpurun_out/prof_fetch gpurun_out/prof_write <kernel> > profiles/<round>_pmc_hbm.json
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-Q="--no-cpu --no-e2e --no-streaming"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o s --output-format csv -- python3 bench.py --no-cpu --no-streaming > gpurun_out/prof_stats_bench.json 2>gpurun_out/prof_stats.err &&
+Q="--no-cpu --no-e2e --no-streaming --no-images"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o s --output-format csv -- python3 bench.py --no-cpu --no-streaming --no-images > gpurun_out/prof_stats_bench.json 2>gpurun_out/prof_stats.err &&
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats1 -o s --output-format csv -- python3 bench.py --streams 1 $Q > gpurun_out/prof_stats1_bench.json 2>gpurun_out/prof_stats1.err &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 $Q > /dev/null 2>gpurun_out/prof_fetch.err &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 $Q > /dev/null 2>gpurun_out/prof_write.err &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 --min-region-seconds 0 $Q > /dev/null 2>gpurun_out/prof_fetch.err &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 --min-region-seconds 0 $Q > /dev/null 2>gpurun_out/prof_write.err &&
 K=$(python3 -c "import json;print(json.load(open('gpurun_out/prof_stats1_bench.json'))['roofline']['kernel'])") &&
 python3 tools/pmc_to_json.py gpurun_out/prof_fetch gpurun_out/prof_write "$K" > gpurun_out/${TAG}_pmc_hbm.json &&
 cp gpurun_out/prof_stats/s_kernel_stats.csv gpurun_out/${TAG}_kernel_stats_3streams.csv &&
