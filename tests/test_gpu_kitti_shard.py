@@ -95,3 +95,23 @@ def test_sub_range_with_begin_and_end(tree):
     _run([EXE, "sub2", "03", str(FIRST + 2), str(FIRST + 8), "--gpus", "2", "--same-device"], home)
     a, b = open(_pose_file(home, "sub1"), "rb").read(), open(_pose_file(home, "sub2"), "rb").read()
     assert a == b and len(a.splitlines()) == 7
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_them():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the bench launches two ranks itself (here both on
+    the one device of the box, gloo for the record gather) and rank 0 prints a line for N = 2 whose `collective` object
+    says how many ranks took part in the all-gather."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(VISO_BENCH_SAME_DEVICE="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "24",
+                        "--kp", "600", "--steps", "3", "--warmup", "1", "--min-region-seconds", "0", "--no-cpu",
+                        "--no-streaming", "--no-images"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["collective"]["ranks"] == 2 and d["collective"]["gathered_records"] == 2 * 24
+    assert d["end_to_end"]["poses_ok"] > 0
+    assert "rank 0/2 started" in r.stderr and "rank 1/2 started" in r.stderr
