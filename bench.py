@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--matcher", type=int, default=None, help="kernel for the temporal calls (viso_ctx_set_matcher); default: the build's")
+    ap.add_argument("--gn-split", type=int, default=0, help="viso_ctx_set_gn_split (0 = the build's default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--images", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-images", action="store_true",
@@ -295,6 +296,8 @@ def main():
     for _ in range(n_streams):
         c = libviso_amd.Context(dev_index)
         libviso_amd.set_matcher_variant(variant, c)
+        if args.gn_split:
+            libviso_amd.set_gn_split(args.gn_split, c)
         b = libviso_amd.Batch(c, nf, args.kp)
         b.upload(seq["kp"], seq["desc"], seq["n"])
         b.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)

@@ -8,7 +8,7 @@
 //   packed  [nf][2][cap][128] u16        biased rows the matcher reads (256 B, 16-B aligned)
 //   res     [3][nf][cap] int2            per query (target | -1, SAD)
 //   sorted  [3][nf][cap][3] int          match lists in (dist,i1) order; pos = inverse
-//   x [nf][4][cap], X [nf][3][cap], x_c, Xp_c   double, SoA rows like cv::Mat(4,M)
+//   x_c [nf][4][cap], Xp_c [nf][3][cap]   double, SoA rows like cv::Mat(4,M): the solver's inputs, written by the circle join
 // `which` = 0 stereo L->R of frame t, 1 temporal left (t vs t-1), 2 temporal right.
 #include "common.h"
 
@@ -30,8 +30,8 @@ struct viso_batch {
     int2* ovf_q;                 // the launch's overflow queue: up to one entry per query of the batch
     int* tile_flag; int tiles;   // [3][nf][tiles] per-64-query-tile scratch of the stereo kernels
     int2* res; int* sorted; int* pos; int* m_cnt; int* ovf_cnt; unsigned long long* scored; size_t zeroed_bytes;
-    double *x, *X, *x_c, *Xp_c;
-    TriItem* tri; JoinItem* join; SolverItem* sitems;
+    double *x_c, *Xp_c;          // the solver's inputs: gathered + triangulated by the circle join
+    JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
     double* tr_h; int *ok_h, *cnt_h, *hq;   // hq: list of undecided hypotheses (launch_ransac)
     int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_sample_kernel)
@@ -105,7 +105,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     if (b->n_pin) note(hipHostFree(b->n_pin));
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->sums, b->zero, b->probs, b->res, b->sorted,
-                    b->pos, b->m_cnt, b->scored, b->x, b->X, b->x_c, b->Xp_c, b->tri, b->join,
+                    b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
@@ -159,14 +159,6 @@ static int build_items(viso_batch* b) {
         }
     }
     HIP_TRY(hipMemcpy(b->probs, P.data(), sizeof(MatchProblem) * P.size(), hipMemcpyHostToDevice));
-    std::vector<TriItem> T((size_t)nf);
-    for (int t = 0; t < nf; ++t) {
-        TriItem& it = T[(size_t)t];
-        it.kp1 = img_kp(t, 0); it.kp2 = img_kp(t, 1);
-        it.match = b->sorted + ((size_t)0 * nf + t) * cap * 3; it.m_cnt = b->m_cnt + t;
-        it.x = b->x + (size_t)t * 4 * cap; it.X = b->X + (size_t)t * 3 * cap; it.ld = cap;
-    }
-    HIP_TRY(hipMemcpy(b->tri, T.data(), sizeof(TriItem) * T.size(), hipMemcpyHostToDevice));
     if (nf > 1) {
         std::vector<JoinItem> J((size_t)nf - 1);
         for (int t = 1; t < nf; ++t) {
@@ -176,8 +168,7 @@ static int build_items(viso_batch* b) {
             j.res22 = b->res + ((size_t)2 * nf + t) * cap;
             j.pos_lrp = b->pos + ((size_t)0 * nf + (t - 1)) * cap;
             j.res_lrp = b->res + ((size_t)0 * nf + (t - 1)) * cap;
-            j.x = b->x + (size_t)t * 4 * cap; j.ldx = cap;
-            j.Xp = b->X + (size_t)(t - 1) * 3 * cap; j.ldXp = cap;
+            j.kp1 = img_kp(t, 0); j.kp2 = img_kp(t, 1); j.kp1p = img_kp(t - 1, 0); j.kp2p = img_kp(t - 1, 1);
             j.circ = b->circ + (size_t)t * cap * 4; j.pcl = b->pcl + (size_t)t * cap * 2; j.mc = b->mc + t;
             j.x_c = b->x_c + (size_t)t * 4 * cap; j.Xp_c = b->Xp_c + (size_t)t * 3 * cap; j.ldc = cap;
         }
@@ -248,8 +239,8 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->ovf_cnt = r >= 0 ? reinterpret_cast<int*>(b->scored + 3 * nf) : nullptr;
     b->bad_img = r >= 0 ? b->ovf_cnt + 3 * nf : nullptr;
     b->bad_any = r >= 0 ? b->bad_img + 2 * nf : nullptr;
-    A(dalloc(&b->x, nf * 4 * c)); A(dalloc(&b->X, nf * 3 * c)); A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
-    A(dalloc(&b->tri, nf)); A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
+    A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
+    A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
     A(dalloc(&b->tr, nf * 6)); A(dalloc(&b->ok, nf)); A(dalloc(&b->n_inl, nf)); A(dalloc(&b->inl, nf * c));
     if (r >= 0 && hipHostMalloc((void**)&b->n_pin, sizeof(int) * VISO_NPIN_SLOTS * 2 * nf, hipHostMallocDefault) != hipSuccess) {
@@ -574,9 +565,8 @@ static int run_rest(viso_batch* b) {
     hipStream_t ss = b->solver_stream ? b->solver_stream : s;
     // the circle join rewrites what the previous run's RANSAC reads (x_c, Xp_c, mc)
     if (ss != s && b->ransac_pending) HIP_TRY(hipStreamWaitEvent(s, b->ev_ransac, 0));
-    if ((r = launch_collect_triangulate(s, b->tri, b->nf, b->sp, b->cap)) < 0) return r;   // :1245-1247
     if (b->nf > 1) {
-        if ((r = launch_circle_join(s, b->join, b->nf - 1)) < 0) return r;                // :1282, 1292-1305
+        if ((r = launch_circle_join(s, b->join, b->nf - 1, b->sp)) < 0) return r;         // :1245-1247 (the rows it joins), :1282, 1292-1305
         if (ss != s) {
             HIP_TRY(hipEventRecord(b->ev_join, s));
             HIP_TRY(hipStreamWaitEvent(ss, b->ev_join, 0));

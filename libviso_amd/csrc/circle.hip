@@ -80,8 +80,11 @@ __global__ __launch_bounds__(CIRC_THREADS) void circle_general_kernel(CircleArgs
 // each of the three hops hits at most one row and becomes a table lookup:
 //   res11[ileft] -> ileft_prev ; pos_lr_prev[ileft_prev] -> k, iright_prev ;
 //   res22[iright] == iright_prev.
-// One workgroup per frame; also gathers x_c / Xp_c (src/viso.cpp:1292-1305).
-__global__ __launch_bounds__(CIRC_THREADS) void circle_join_kernel(const JoinItem* items, int n_items) {
+// One workgroup per frame.  x_c / Xp_c (src/viso.cpp:1292-1305) are computed here from the keypoints: x_c column =
+// collect_matches of the joined stereo match of frame t (:501-514), Xp_c column = triangulate_rectified<double> of the
+// joined stereo match of frame t-1 (:1137-1162, no clamp) — the same expressions, evaluated only for the rows the
+// solver will read, so the batch path needs no collect / triangulate launch of its own.
+__global__ __launch_bounds__(CIRC_THREADS) void circle_join_kernel(const JoinItem* items, int n_items, SolverParamsDev sp) {
     __shared__ int scratch[8];
     if ((int)blockIdx.x >= n_items) return;
     const JoinItem J = items[blockIdx.x];
@@ -108,19 +111,24 @@ __global__ __launch_bounds__(CIRC_THREADS) void circle_join_kernel(const JoinIte
             J.circ[4 * o + 0] = ileft; J.circ[4 * o + 1] = iright;
             J.circ[4 * o + 2] = ileft_prev; J.circ[4 * o + 3] = iright_prev;
             J.pcl[2 * o + 0] = r; J.pcl[2 * o + 1] = k;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) J.x_c[c * J.ldc + o] = J.x[c * J.ldx + r];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) J.Xp_c[c * J.ldc + o] = J.Xp[c * J.ldXp + k];
+            const float2 a1 = J.kp1[ileft], a2 = J.kp2[iright];
+            J.x_c[0 * J.ldc + o] = (double)a1.x; J.x_c[1 * J.ldc + o] = (double)a1.y;
+            J.x_c[2 * J.ldc + o] = (double)a2.x; J.x_c[3 * J.ldc + o] = (double)a2.y;
+            const float2 p1 = J.kp1p[ileft_prev], p2 = J.kp2p[iright_prev];
+            const double uL = p1.x, vL = p1.y, uR = p2.x;
+            const double d = uL - uR;                       // src/viso.cpp:1148-1151, no clamp
+            J.Xp_c[0 * J.ldc + o] = sp.base * (uL - sp.cu) / d;
+            J.Xp_c[1 * J.ldc + o] = sp.base * (vL - sp.cv) / d;
+            J.Xp_c[2 * J.ldc + o] = sp.f * sp.base / d;
         }
         running += total;
     }
     if (threadIdx.x == 0) *J.mc = running;
 }
 
-int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items) {
+int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items, const SolverParamsDev& sp) {
     if (n_items <= 0) return VISO_OK;
-    hipLaunchKernelGGL(circle_join_kernel, dim3(n_items), dim3(CIRC_THREADS), 0, s, items_dev, n_items);
+    hipLaunchKernelGGL(circle_join_kernel, dim3(n_items), dim3(CIRC_THREADS), 0, s, items_dev, n_items, sp);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

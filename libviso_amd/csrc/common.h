@@ -152,8 +152,9 @@ struct JoinItem {
     const int2* res11;                       // temporal-left results, per query
     const int2* res22;                       // temporal-right results, per query
     const int* pos_lrp; const int2* res_lrp; // previous frame's stereo: row of query / result
-    const double* x; int ldx;                // 4 x ldx   current frame (uL,vL,uR,vR)
-    const double* Xp; int ldXp;              // 3 x ldXp  previous frame 3-D points
+    const float2* kp1; const float2* kp2;    // keypoints of frame t (left, right): x_c is collect_matches of the joined rows
+    const float2* kp1p; const float2* kp2p;  // keypoints of frame t-1: Xp_c is triangulate_rectified of the joined rows,
+                                             // computed in the join itself (src/viso.cpp:501-514, 1137-1162, 1292-1305)
     int* circ; int* pcl; int* mc;            // outputs
     double* x_c; double* Xp_c; int ldc;      // 4 x ldc, 3 x ldc
 };
@@ -169,7 +170,7 @@ struct TriItem {
 // kernel (viso_ctx::gn_split; 100 = the lane kernel does everything)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
                   unsigned long long seed, const SolverParamsDev& sp, int* queue, int split);
-int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items);
+int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items, const SolverParamsDev& sp);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);
 struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_kernel (tiles of 64 queries)

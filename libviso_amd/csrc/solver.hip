@@ -336,8 +336,9 @@ __device__ int block_inliers(const double* tr, const SolverParamsDev& sp, const 
     for (int base = 0; base < m; base += REFIT_THREADS) {
         const int i = base + threadIdx.x;
         double e2 = 0;
-        const bool in = (i < m) && is_inlier(R, sp, X, obs, ld, i, &e2);
-        if (last_err2 && i == m - 1) *last_err2 = e2;
+        const bool want_e2 = last_err2 && i == m - 1;    // Q8: the rms is the LAST point's error (:1535): that one exactly
+        const bool in = (i < m) && is_inlier(R, sp, X, obs, ld, i, want_e2 ? &e2 : nullptr);
+        if (want_e2) *last_err2 = e2;
         const unsigned long long msk = __ballot(in);
         if (lane == 0) scratch[wave] = __popcll(msk);
         __syncthreads();
@@ -501,9 +502,11 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
         // 200 waves go to 50 CUs instead of one to each of 200
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        // one wave per undecided hypothesis: ~1-2 % of them; room for 2.5 % (waves without an item leave at once,
-        // hypotheses beyond the grid are taken in a second turn of the same waves)
-        long long cb = (nh / 40 + 3) / 4;
+        // one wave per undecided hypothesis.  After 10 iterations 1-2 % of them are undecided (room for 2.5 %); a shorter
+        // first stage hands on more (the waves are light: 117 VGPRs), so the grid grows with what can be expected; waves
+        // without an entry leave at once, entries beyond the grid are taken in further turns of the same waves
+        const int div = a.split >= 10 ? 40 : a.split >= 6 ? 16 : a.split >= 4 ? 6 : 3;
+        long long cb = (nh / div + 3) / 4;
         if (cb < 128) cb = 128;
         if (cb > (nh + 3) / 4) cb = (nh + 3) / 4;
         hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb), dim3(256), 0, s, a);

@@ -60,8 +60,30 @@ __device__ __forceinline__ void predict_point(const RotDev& R, const SolverParam
 }
 
 // squared reprojection error test of get_inliers (src/viso.cpp:1524-1533)
+// get_inliers' test of one point (src/viso.cpp:1527-1533): sum_k (observe_k - predict_k)^2 < inlier_threshold^2, strict.
+// The reference's three divisions by Z (:1486-1489) cost ~30 fp64 instructions each here.  The verdict only needs them
+// when the sum is within rounding distance of the threshold: first the sum with ONE reciprocal of Z (refined to < 1 ulp)
+// and its error bound — every prediction is then off by < 4 ulps of its magnitude, the sum by far less than
+// 1e-12 (S + 1), S = sum_k (|observe_k| + |predict_k|)^2 —, and only a sum inside that band (or not a number) is decided
+// by the reference's own expression.  Same verdicts, bit for bit; err2_out (the Q8 rms, :1535) always takes the exact path.
 __device__ __forceinline__ bool is_inlier_pt(const RotDev& R, const SolverParamsDev& sp, double X0, double X1, double X2,
                                              double o0, double o1, double o2, double o3, double* err2_out) {
+    const double thr2 = sp.inlier_threshold * sp.inlier_threshold;
+    if (!err2_out) {
+        const double X1c = R.r00 * X0 + R.r01 * X1 + R.r02 * X2 + R.tx;
+        const double Y1c = R.r10 * X0 + R.r11 * X1 + R.r12 * X2 + R.ty;
+        const double Z1c = R.r20 * X0 + R.r21 * X1 + R.r22 * X2 + R.tz;
+        double rz = __builtin_amdgcn_rcp(Z1c);
+        rz = fma(fma(-Z1c, rz, 1.0), rz, rz);          // two Newton steps: < 1 ulp from 1 / Z1c for any normal Z1c
+        rz = fma(fma(-Z1c, rz, 1.0), rz, rz);
+        const double p0 = sp.f * X1c * rz + sp.cu, p1 = sp.f * Y1c * rz + sp.cv, p2 = sp.f * (X1c - sp.base) * rz + sp.cu;
+        const double e0 = o0 - p0, e1 = o1 - p1, e2 = o2 - p2, e3 = o3 - p1;
+        const double approx = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        const double a0 = fabs(o0) + fabs(p0), a1 = fabs(o1) + fabs(p1), a2 = fabs(o2) + fabs(p2), a3 = fabs(o3) + fabs(p1);
+        const double band = 1e-12 * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + 1.0);
+        if (approx < thr2 - band) return true;         // any NaN / inf makes both tests false: the exact path decides
+        if (approx > thr2 + band) return false;
+    }
     double pred[4], X1c, Y1c, Z1c, X2c;
     predict_point(R, sp, X0, X1, X2, pred, X1c, Y1c, Z1c, X2c);
     const double e0 = o0 - pred[0];
@@ -70,7 +92,7 @@ __device__ __forceinline__ bool is_inlier_pt(const RotDev& R, const SolverParams
     const double e3 = o3 - pred[3];
     const double err2 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
     if (err2_out) *err2_out = err2;
-    return err2 < sp.inlier_threshold * sp.inlier_threshold;
+    return err2 < thr2;
 }
 __device__ __forceinline__ bool is_inlier(const RotDev& R, const SolverParamsDev& sp, const double* X,
                                           const double* obs, int ld, int i, double* err2_out) {
