@@ -25,6 +25,8 @@ def test_pipeline_soak(viso, oracle):
         seed, ff = int(rng.integers(0, 1 << 40)), int(rng.integers(0, 1 << 20))
         want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=seed, first_frame=ff)
         ctx = libviso_amd.Context(0)
+        variants = libviso_amd.MATCHER_VARIANTS
+        libviso_amd.set_matcher_variant(variants[c % len(variants)], ctx)      # every matcher kernel of the build takes its turn
         b = libviso_amd.Batch(ctx, nf, seq["kp"].shape[2])
         b.upload(seq["kp"], seq["desc"], seq["n"])
         b.set_params(st, tm, seq["param"], seed=seed, first_frame=ff)
@@ -37,3 +39,5 @@ def test_pipeline_soak(viso, oracle):
                 A, B = libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])
                 assert np.linalg.norm(A - B) / np.linalg.norm(B) < 1e-5, what
         b.close(); ctx.close()
+        if c % 20 == 19:
+            print(f"soak: {c + 1} cases clean", flush=True)
