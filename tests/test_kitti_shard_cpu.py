@@ -158,3 +158,28 @@ def test_launcher_refuses_a_world_that_is_not_gpus(tmp_path):
     r = subprocess.run([sys.executable, "-m", "libviso_amd.kitti_shard", "x", "00", "--gpus", "2", "--backend", "gloo"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     assert r.returncode == 7 and "WORLD_SIZE" in r.stderr
+
+
+def test_broken_rank_files_are_refused(host, tmp_path):
+    """A rank file with an impossible record count, a truncated one, a missing one: `--gather` reports and writes nothing
+    (no pose file assembled from half a sequence).  The same inputs run clean under -fsanitize=address,undefined."""
+    from libviso_amd import kitti_shard
+    home = str(tmp_path)
+    _tree(home, "05", 11)
+    shards = os.path.join(home, "results", "05", "x", "shards")
+    ranges = kitti_shard.partition(11, 3)
+    for r, (a, b) in enumerate(ranges):
+        _write_rank_file(os.path.join(shards, f"05.{r}of3.rec"), a, b, [_fake_record(t) for t in range(a + 1, b + 1)])
+    env = dict(os.environ, KITTI_HOME=home)
+    out = os.path.join(home, "results", "05", "x", "data", "05.txt")
+    bad = os.path.join(shards, "05.1of3.rec")
+    a, b = ranges[1]
+    for blob in (struct.pack("<4i", 0x56534B52, a, b, 1000000),                 # more records than the range holds
+                 struct.pack("<4i", 0x56534B52, a, b, b - a) + b"\0" * 10,      # truncated
+                 struct.pack("<4i", 0x12345678, a, b, 0)):                      # not a rank file
+        open(bad, "wb").write(blob)
+        r = subprocess.run([EXE, "x", "05", "--gather", "3"], capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode == 3 and "cannot read" in r.stderr and not os.path.exists(out)
+    os.remove(bad)
+    r = subprocess.run([EXE, "x", "05", "--gather", "3"], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 3 and not os.path.exists(out)
