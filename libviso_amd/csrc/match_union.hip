@@ -68,12 +68,18 @@ __device__ __forceinline__ void mu_merge(MuTrack& a, const MuTrack& b) {
     a.m1 = min(a.m1, b.m1);
 }
 
-__device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {   // monotone in y
-    if (y != y) return MU_NBY - 1;
-    const float f = floorf((y - y0) * scale);
-    if (f != f) return 0;                       // inf * 0: never (int)NaN
-    return f <= 0.f ? 0 : (f >= (float)(MU_NBY - 1) ? MU_NBY - 1 : (int)f);
+// y bucket of the staged window: monotone in y, total (NaN -> 0, +-inf saturate): v_cvt_i32_f32 truncates, saturates and
+// turns NaN into 0 (the C conversion would be undefined there), the clamp makes truncation and floor the same thing
+__device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {
+    const float f = (y - y0) * scale;
+    int b;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(b) : "v"(f));
+    return min(max(b, 0), MU_NBY - 1);
 }
+
+// the lane that carries query k of a round (lanes 0..31: queries 0..3, lanes 32..63: queries 4..7, repeated every four
+// lanes, so that a quad broadcast hands every lane the four queries its half tests in phase 1)
+__device__ __forceinline__ constexpr int mu_qlane(int k) { return (k & 3) + 32 * (k >> 2); }
 
 __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
@@ -193,19 +199,21 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     unsigned long long scored = 0;
     constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 2 rounds of 8 queries per wave
     // which of the round's eight queries the lane tracks after the transposing reduction (phase 2): the partners of
-    // the three exchange steps (lane ^ 1, lane ^ 2, 7 - lane within the 8-lane group) differ in exactly one of these
-    const bool sel0 = ((lane ^ (lane >> 2)) & 1) != 0, sel1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0, sel2 = ((lane >> 2) & 1) != 0;
-    const int myq = (sel0 ? 1 : 0) + (sel1 ? 2 : 0) + (sel2 ? 4 : 0);
+    // the three exchange steps (lane ^ 4, lane ^ 2, lane ^ 1 within the 8-lane group) differ in exactly one of these
+    const bool sel1 = ((lane >> 1) & 1) != 0, sel0 = (lane & 1) != 0;
+    const int myq = ((lane >> 2) & 1) + (sel1 ? 2 : 0) + (sel0 ? 4 : 0);
     const int msh = 31 - myq;   // membership bit of query myq in a list entry (bit 7 - k of the mask byte)
 
-    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 7) of the round
+    // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 3) + 4 * half
+    // of the round (mu_qlane)
+    const int qslot = (lane & 3) + 4 * half;
     int pli;
     float2 pq;
     int po;
 #define MU_PREFETCH(R)                                                                                    \
     do {                                                                                                  \
         const int base_ = wave * (MU_QPB / MU_WAVES) + (R) * MU_G;                                        \
-        pli = (int)P.q.qord[q0 + base_ + (lane & (MU_G - 1))];                                            \
+        pli = (int)P.q.qord[q0 + base_ + qslot];                                                          \
         const int j_ = q0 + pli;                                                                          \
         const int jc_ = min(j_, q1 - 1);                                                                  \
         pq = P.q.skp[jc_];                                                                                \
@@ -214,13 +222,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     MU_PREFETCH(0);
 
     for (int r = 0; r < ROUNDS; ++r) {
-        // ---------------- round setup.  Lane l holds query (l & 7); phase 1 wants, per lane, the four queries of its
-        // half: query 4 * half + i sits in lane 36 * half + i
-        const int my_orig = po, my_j = q0 + pli;   // lanes 0..7: the round's queries, for phase 3
+        // ---------------- round setup.  Lane l holds query (l & 3) + 4 * half: the four queries its half tests in phase 1
+        // are the four lanes of its quad (DPP quad broadcasts, no scalar traffic)
+        const int my_orig = po, my_j = q0 + pli;   // lanes mu_qlane(k): the round's queries, for phase 3
         if (!__any(po >= 0)) { if (r + 1 < ROUNDS) MU_PREFETCH(r + 1); continue; }   // wave uniform
-        // d = |dx| + |dy| is +0, positive or NaN: its bit pattern orders like the value and NaNs are above +inf,
-        // so (d <= radius && d < d0cut) is one unsigned compare against bits(d0) (target 0 in radius: Q1,
-        // src/viso.cpp:693) or bits(radius) + 1.  Dead slots (past the tile) get 0: nothing passes.
+        // d = |dx| + |dy| is +0, positive or NaN (sign bit clear: the add sees |dx| and |dy|): its bit pattern orders like
+        // the value and NaNs are above +inf, so (d <= radius && d < d0cut) is one unsigned compare against bits(d0)
+        // (target 0 in radius: Q1, src/viso.cpp:693) or bits(radius) + 1 — and, both sides being below 2^31, the SIGN of
+        // bits(d) - thr.  Dead slots (past the tile) get 0: nothing passes.
         uint32_t tq = __float_as_uint(radius) + 1u;
         if (has0) {
             const float d0 = l1_kp(pq.x, pq.y, kp0);
@@ -229,33 +238,48 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         if (po < 0) tq = 0u;
         float qx[4], qy[4];
         uint32_t thr[4];
-        float ymn = pq.y, ymx = pq.y;   // y extent of the round's queries (all lanes hold one of them)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xa_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), i));
-            const float xb_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.x), 4 + i));
-            const float ya_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), i));
-            const float yb_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pq.y), 4 + i));
-            const uint32_t ta_ = (uint32_t)__builtin_amdgcn_readlane((int)tq, i);
-            const uint32_t tb_ = (uint32_t)__builtin_amdgcn_readlane((int)tq, 4 + i);
-            qx[i] = half ? xb_ : xa_;
-            qy[i] = half ? yb_ : ya_;
-            thr[i] = half ? tb_ : ta_;
-            ymn = fminf(ymn, fminf(ya_, yb_));
-            ymx = fmaxf(ymx, fmaxf(ya_, yb_));
+        qx[0] = __uint_as_float(mu_dpp<0x00>(__float_as_uint(pq.x))); qy[0] = __uint_as_float(mu_dpp<0x00>(__float_as_uint(pq.y))); thr[0] = mu_dpp<0x00>(tq);
+        qx[1] = __uint_as_float(mu_dpp<0x55>(__float_as_uint(pq.x))); qy[1] = __uint_as_float(mu_dpp<0x55>(__float_as_uint(pq.y))); thr[1] = mu_dpp<0x55>(tq);
+        qx[2] = __uint_as_float(mu_dpp<0xAA>(__float_as_uint(pq.x))); qy[2] = __uint_as_float(mu_dpp<0xAA>(__float_as_uint(pq.y))); thr[2] = mu_dpp<0xAA>(tq);
+        qx[3] = __uint_as_float(mu_dpp<0xFF>(__float_as_uint(pq.x))); qy[3] = __uint_as_float(mu_dpp<0xFF>(__float_as_uint(pq.y))); thr[3] = mu_dpp<0xFF>(tq);
+        // y extent of the round's queries: quad min / max, then the two halves
+        float ymn, ymx;
+        {
+            float mn = fminf(fminf(qy[0], qy[1]), fminf(qy[2], qy[3]));
+            float mx = fmaxf(fmaxf(qy[0], qy[1]), fmaxf(qy[2], qy[3]));
+            const float mn0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 0));
+            const float mn1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 32));
+            const float mx0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 0));
+            const float mx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 32));
+            ymn = fminf(mn0, mn1);
+            ymx = fmaxf(mx0, mx1);
         }
         // the eight query rows: one word per lane and row from global memory (the loads land during the scan), then LDS
         uint32_t qw[MU_G];
 #pragma unroll
         for (int k = 0; k < MU_G; ++k) {
-            const int jk = q0 + __builtin_amdgcn_readlane(pli, k);
+            const int jk = q0 + __builtin_amdgcn_readlane(pli, mu_qlane(k));
             qw[k] = ((const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(P.q.rows))[(size_t)min(jk, q1 - 1) * (VISO_ROW / 2) + lane];
         }
         if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
         // ---------------- phase 1: one scan over the y buckets the round's diamonds touch, 32 targets per step: both
-        // halves read the same 32 entries, each tests its four queries -> 8-bit membership mask (bit 7 - k = query k),
-        // targets with a non-zero mask go to the union list.  entry = mask << 24 | window position << 8
+        // halves read the same 32 entries, each tests its four queries (sign of bits(d) - thr shifted into a 4-bit mask:
+        // sub + alignbit, no condition code), one v_permlane32_swap joins the halves' nibbles into the 8-bit membership
+        // mask (bit 7 - k = query k) in every lane; targets with a non-zero mask go to the union list (lanes 0..31
+        // write).  entry = mask << 24 | window position << 8.  cnt accumulates the set bits = in-radius (query, target)
+        // cells of the round (the same in both halves)
         int ucnt = 0;
+        uint32_t cnt = 0;
+#define MU_TEST4(T)                                                                                       \
+        ({                                                                                                \
+            uint32_t m_ = 0;                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+                m_ = __builtin_amdgcn_alignbit(m_, mu_l1_bits(qx[i], qy[i], (T)) - thr[i], 31);           \
+            /* swap(A, B): A's lanes 32..63 <-> B's lanes 0..31; with A = B = m_: r_[0] = the low half's nibble everywhere, */ \
+            /* r_[1] = the high half's */                                                                 \
+            const auto r_ = __builtin_amdgcn_permlane32_swap(m_, m_, false, false);                       \
+            (uint32_t)((r_[0] << 4) | r_[1]);                                                             \
+        })
         {
             const float ys = (fabsf(ymn) + fabsf(ymx) + fabsf(radius)) * 1e-6f + 1e-6f;   // covers the rounding of dy in the test
             int sc0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)] & ~63;   // steps of 64 stay inside the NaN padded array
@@ -267,50 +291,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 // two steps of 32 targets in flight
                 const float2 ta = s_ykp[base + l31], tb = s_ykp[base + 32 + l31];
                 const uint32_t pa = s_ypos[base + l31], pb = s_ypos[base + 32 + l31];
-                uint32_t ma = 0, mb = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool ina = mu_l1_bits(qx[i], qy[i], ta) < thr[i];
-                    const bool inb = mu_l1_bits(qx[i], qy[i], tb) < thr[i];
-                    ma = ma + ma + (ina ? 1u : 0u);
-                    mb = mb + mb + (inb ? 1u : 0u);
-                }
-                // lanes 0..31: own nibble = queries 0..3 (high nibble of the byte), partner's = queries 4..7
-                const uint32_t oa = (uint32_t)__shfl_xor((int)ma, 32), ob = (uint32_t)__shfl_xor((int)mb, 32);
-                const uint32_t m8a = half ? 0u : ((ma << 4) | oa), m8b = half ? 0u : ((mb << 4) | ob);
+                const uint32_t m8a = MU_TEST4(ta), m8b = MU_TEST4(tb);
+                cnt += (uint32_t)__popc(m8a) + (uint32_t)__popc(m8b);
                 const uint32_t ua = (uint32_t)__ballot(m8a != 0), ub = (uint32_t)__ballot(m8b != 0);
                 const int ca = __popc(ua);
-                if (m8a) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(ua, 0u), MU_UCAP - 1)] = (m8a << 24) | (pa << 8);
-                if (m8b) ul[min(ucnt + ca + (int)__builtin_amdgcn_mbcnt_lo(ub, 0u), MU_UCAP - 1)] = (m8b << 24) | (pb << 8);
+                if (m8a != 0 && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(ua, 0u), MU_UCAP - 1)] = (m8a << 24) | (pa << 8);
+                if (m8b != 0 && half == 0) ul[min(ucnt + ca + (int)__builtin_amdgcn_mbcnt_lo(ub, 0u), MU_UCAP - 1)] = (m8b << 24) | (pb << 8);
                 ucnt += ca + __popc(ub);
             }
             for (int base = wcap; base < W; base += 32) {   // windows wider than MU_KPCAP (dense data only)
                 const int w = base + l31;
                 float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
                 if (w < W) t2 = P.t.skp[lo + w];
-                uint32_t m = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m = m + m + ((mu_l1_bits(qx[i], qy[i], t2) < thr[i]) ? 1u : 0u);
-                const uint32_t o = (uint32_t)__shfl_xor((int)m, 32);
-                const uint32_t m8 = half ? 0u : ((m << 4) | o);
+                const uint32_t m8 = MU_TEST4(t2);
+                cnt += (uint32_t)__popc(m8);
                 const uint32_t u = (uint32_t)__ballot(m8 != 0);
-                if (m8) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(u, 0u), MU_UCAP - 1)] = (m8 << 24) | ((uint32_t)w << 8);
+                if (m8 != 0 && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(u, 0u), MU_UCAP - 1)] = (m8 << 24) | ((uint32_t)w << 8);
                 ucnt += __popc(u);
             }
         }
+#undef MU_TEST4
         const bool list_ovf = ucnt > MU_UCAP;
         const int nu = list_ovf ? 0 : ucnt;
         __builtin_amdgcn_wave_barrier();
-        // in-radius candidates per query (K cap): bit counts over the list; lane k (< 8) keeps query k's
-        int my_cnt = 0;
-        for (int b = 0; b < nu; b += VISO_WAVE) {
-            const uint32_t e = (b + lane) < nu ? ul[b + lane] : 0u;
-#pragma unroll
-            for (int k = 0; k < MU_G; ++k) {
-                const int c = __popcll(__ballot(((e >> (31 - k)) & 1u) != 0));
-                if (lane == k) my_cnt += c;
-            }
-        }
         // padding behind the list: copies of the last entry with an empty mask (scored, never counted)
         if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] & 0x00ffffffu;
         __builtin_amdgcn_wave_barrier();
@@ -354,15 +357,31 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             })
 #define MU_X1(A, B) ({ uint32_t k_ = sel0 ? (B) : (A); const uint32_t g_ = sel0 ? (A) : (B); k_ += mu_dpp<0xB1>(g_); k_; })   /* lane ^ 1 */
 #define MU_X2(A, B) ({ uint32_t k_ = sel1 ? (B) : (A); const uint32_t g_ = sel1 ? (A) : (B); k_ += mu_dpp<0x4E>(g_); k_; })   /* lane ^ 2 */
-#define MU_X4(A, B) ({ uint32_t k_ = sel2 ? (B) : (A); const uint32_t g_ = sel2 ? (A) : (B); k_ += mu_dpp<0x141>(g_); k_; })  /* 7 - lane */
+            // first exchange step, lane ^ 4, on all four pairs at once: a lane's bit 2 is its DPP BANK, so "keep A and add
+            // the partner's A" / "keep B and add the partner's B" are two bank-masked v_add_u32_dpp instead of two selects
+            // and an add: banks 0, 2 take A + A[lane + 4] (row_shl:4), banks 1, 3 take B + B[lane - 4] (row_shr:4), in
+            // place.  One asm block: the compiler's hazard recognizer does not see DPP reads inside inline asm (a VGPR
+            // written by the previous two VALU instructions must not be a DPP source), hence the leading s_nop 1; inside
+            // the block every source was written at least four instructions earlier.
+#define MU_X4x4(S0, S1, S2, S3, S4, S5, S6, S7)                                                            \
+            asm("s_nop 1\n\t"                                                                              \
+                "v_add_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
+                "v_add_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
+                "v_add_u32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
+                "v_add_u32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
+                "v_add_u32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
+                "v_add_u32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
+                "v_add_u32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
+                "v_add_u32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa"                              \
+                : "+v"(S0), "+v"(S2), "+v"(S4), "+v"(S6) : "v"(S1), "v"(S3), "v"(S5), "v"(S7))
 #define MU_REDUCE(SLOT, U)                                                                                \
             do {                                                                                           \
-                const uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
+                uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
                 __builtin_amdgcn_sched_barrier(0);   /* two halves: all sixteen query-row reads in flight at once cost 64 VGPRs */ \
-                const uint32_t s4_ = MU_SAD(4, SLOT), s5_ = MU_SAD(5, SLOT), s6_ = MU_SAD(6, SLOT), s7_ = MU_SAD(7, SLOT); \
-                const uint32_t a0_ = MU_X1(s0_, s1_), a1_ = MU_X1(s2_, s3_), a2_ = MU_X1(s4_, s5_), a3_ = MU_X1(s6_, s7_); \
-                const uint32_t c0_ = MU_X2(a0_, a1_), c1_ = MU_X2(a2_, a3_);                               \
-                const uint32_t m_ = MU_X4(c0_, c1_);                                                       \
+                uint32_t s4_ = MU_SAD(4, SLOT), s5_ = MU_SAD(5, SLOT), s6_ = MU_SAD(6, SLOT), s7_ = MU_SAD(7, SLOT); \
+                MU_X4x4(s0_, s1_, s2_, s3_, s4_, s5_, s6_, s7_);   /* s0_ s2_ s4_ s6_: queries (0|1) (2|3) (4|5) (6|7) by bit 2 */ \
+                const uint32_t c0_ = MU_X2(s0_, s2_), c1_ = MU_X2(s4_, s6_);                               \
+                const uint32_t m_ = MU_X1(c0_, c1_);                                                       \
                 const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
                 mu_update(tr, member_ ? ((m_ << 9) | (uint32_t)(U)) : 0xffffffffu);                        \
             } while (0)
@@ -387,15 +406,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 for (int p = 0; p < MU_NP; ++p) MU_REDUCE(p, (t + p) * 8 + g8);
             }
 #undef MU_REDUCE
-#undef MU_X4
+#undef MU_X4x4
 #undef MU_X2
 #undef MU_X1
 #undef MU_SAD
 #undef MU_ISSUE
         }
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
-        // query); lane l (< 8) then holds query myq(l): 0 1 2 3 7 6 5 4 -> bring query k to lane k; fetch the original
-        // target index, ratio test, store
+        // query); lane l (< 8) then holds query myq(l): 0 4 2 6 1 5 3 7 -> bring query k to the lane that carries its
+        // data (mu_qlane); fetch the original target index, ratio test, store
 #pragma unroll
         for (int m = 8; m < VISO_WAVE; m <<= 1) {
             MuTrack o;
@@ -404,14 +423,33 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             mu_merge(tr, o);
         }
         {
-            const int src = (lane & 7) < 4 ? (lane & 7) : 11 - (lane & 7);
+            const int k = qslot;   // the lane of query k after the reduction: bits (k & 1, k >> 1 & 1, k >> 2) -> lane bits (2, 1, 0)
+            const int src = ((k & 1) << 2) | (k & 2) | (k >> 2);
             tr.m1 = (uint32_t)__shfl((int)tr.m1, src);
             tr.m2 = (uint32_t)__shfl((int)tr.m2, src);
         }
-        if (lane < MU_G && my_orig >= 0) {
-            const bool none = tr.m1 == 0xffffffffu;
-            const uint32_t d1 = tr.m1 >> 9;
-            const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
+        const bool mine = (lane & 28) == 0 && my_orig >= 0;   // lanes mu_qlane(k) of live queries
+        const bool none = tr.m1 == 0xffffffffu;
+        const uint32_t d1 = tr.m1 >> 9;
+        const bool tie = !none && tr.m2 != 0xffffffffu && (tr.m2 >> 9) == d1;
+        // in-radius candidates per query (K cap, and what a query that leaves for the overflow kernel must not count):
+        // no query can have more than the list holds, so they are only needed when the list is longer than K or a
+        // minimum is tied — bit counts over the list then; lane mu_qlane(k) keeps query k's
+        const bool slow = nu > K || __any(mine && tie);   // wave uniform
+        int my_cnt = 0;
+        if (slow) {
+            for (int b = 0; b < nu; b += VISO_WAVE) {
+                const uint32_t e = (b + lane) < nu ? ul[b + lane] : 0u;
+#pragma unroll
+                for (int k = 0; k < MU_G; ++k) {
+                    const int c = __popcll(__ballot(((e >> (31 - k)) & 1u) != 0));
+                    if (lane == mu_qlane(k)) my_cnt += c;
+                }
+            }
+        } else if (!list_ovf && half == 0) {
+            scored += cnt;   // every result of the round stands: all its cells count (lanes 0..31 hold partial sums)
+        }
+        if (mine) {
             if (list_ovf || my_cnt > K || tie) {
                 // more than K candidates / union too long / exact tie of the minimum (largest-key rule): overflow kernel
                 P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, my_j);
@@ -427,13 +465,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     }
                 }
                 P.res[my_orig] = make_int2(accept ? idx : -1, none ? -1 : (int)d1);
-                scored += (unsigned long long)my_cnt;
+                if (slow) scored += (unsigned long long)my_cnt;
             }
         }
     }
-    // scored pairs of the tile's queries whose result stands (lanes 0..7 of every wave hold partial sums)
+    // scored pairs of the tile's queries whose result stands (partial sums in every lane)
 #pragma unroll
-    for (int m = 1; m < MU_G; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
+    for (int m = 1; m < VISO_WAVE; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 

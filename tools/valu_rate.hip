@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
             if (KIND == 34) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(a[i]) : "v"(b));
             if (KIND == 35) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
             if (KIND == 36) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (KIND == 37) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b));
+            if (KIND == 38) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b));
+            if (KIND == 39) asm volatile("v_add_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(a[i]) : "v"(b));
+            if (KIND == 40) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 41) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -138,5 +143,10 @@ int main() {
     run<34>("v_alignbit_b32", d, ghz);
     run<35>("v_perm_b32", d, ghz);
     run<36>("v_bfi_b32", d, ghz);
+    run<37>("v_permlane32_swap_b32", d, ghz);
+    run<38>("v_permlane16_swap_b32", d, ghz);
+    run<39>("v_add_u32 dpp row_shl:4 bank_mask", d, ghz);
+    run<40>("v_bcnt_u32_b32", d, ghz);
+    run<41>("v_cvt_i32_f32", d, ghz);
     return 0;
 }
