@@ -32,7 +32,9 @@
 #define MU_G 8             // queries per round
 #define MU_UCAP 448        // union list entries per round (+ MU_PAD < 512: a list position fits the 9 low bits of a tracker key)
 #define MU_PAD 32          // list padding: the pipeline runs up to 4 passes of 8 rows past the end
+#ifndef MU_NP
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
+#endif
 #define MU_KPCAP 512       // window keypoints staged in LDS
 #define MU_NBY 64          // y buckets of the staged window
 
@@ -40,6 +42,17 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t mu_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
+
+// quad broadcast (every lane has a source: no old value to keep, bound_ctrl spares the compiler its initialisation)
+template <int CTRL>
+__device__ __forceinline__ uint32_t mu_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+// fminf / fmaxf without the canonicalising v_max x, x the compiler puts in front (v_min / v_max return the other operand
+// for a NaN, like fminf / fmaxf)
+__device__ __forceinline__ float mu_fmin(float a, float b) { float r; asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float mu_fmax(float a, float b) { float r; asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // bits of |qx - tx| + |qy - ty| (cvflann::L1 order, see l1_kp); abs as source modifiers of the add
 __device__ __forceinline__ uint32_t mu_l1_bits(float qx, float qy, float2 t) {
@@ -229,31 +242,24 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // d = |dx| + |dy| is +0, positive or NaN (sign bit clear: the add sees |dx| and |dy|): its bit pattern orders like
         // the value and NaNs are above +inf, so (d <= radius && d < d0cut) is one unsigned compare against bits(d0)
         // (target 0 in radius: Q1, src/viso.cpp:693) or bits(radius) + 1 — and, both sides being below 2^31, the SIGN of
-        // bits(d) - thr.  Dead slots (past the tile) get 0: nothing passes.
+        // (thr - 1) - bits(d): CLEAR for a member — masks are kept inverted (bit 7 - k set = query k is NOT a member), which
+        // lets phase 2 turn a non-member's tracker key into "none" with an OR.  Dead slots (past the tile) get 0: nothing passes.
         uint32_t tq = __float_as_uint(radius) + 1u;
         if (has0) {
             const float d0 = l1_kp(pq.x, pq.y, kp0);
             if (d0 <= radius) tq = __float_as_uint(d0);
         }
         if (po < 0) tq = 0u;
+        tq -= 1u;   // dead slots: 0xffffffff - bits(d) has its sign set
         float qx[4], qy[4];
         uint32_t thr[4];
-        qx[0] = __uint_as_float(mu_dpp<0x00>(__float_as_uint(pq.x))); qy[0] = __uint_as_float(mu_dpp<0x00>(__float_as_uint(pq.y))); thr[0] = mu_dpp<0x00>(tq);
-        qx[1] = __uint_as_float(mu_dpp<0x55>(__float_as_uint(pq.x))); qy[1] = __uint_as_float(mu_dpp<0x55>(__float_as_uint(pq.y))); thr[1] = mu_dpp<0x55>(tq);
-        qx[2] = __uint_as_float(mu_dpp<0xAA>(__float_as_uint(pq.x))); qy[2] = __uint_as_float(mu_dpp<0xAA>(__float_as_uint(pq.y))); thr[2] = mu_dpp<0xAA>(tq);
-        qx[3] = __uint_as_float(mu_dpp<0xFF>(__float_as_uint(pq.x))); qy[3] = __uint_as_float(mu_dpp<0xFF>(__float_as_uint(pq.y))); thr[3] = mu_dpp<0xFF>(tq);
-        // y extent of the round's queries: quad min / max, then the two halves
-        float ymn, ymx;
-        {
-            float mn = fminf(fminf(qy[0], qy[1]), fminf(qy[2], qy[3]));
-            float mx = fmaxf(fmaxf(qy[0], qy[1]), fmaxf(qy[2], qy[3]));
-            const float mn0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 0));
-            const float mn1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 32));
-            const float mx0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 0));
-            const float mx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 32));
-            ymn = fminf(mn0, mn1);
-            ymx = fmaxf(mx0, mx1);
-        }
+        qx[0] = __uint_as_float(mu_bcast<0x00>(__float_as_uint(pq.x))); qy[0] = __uint_as_float(mu_bcast<0x00>(__float_as_uint(pq.y))); thr[0] = mu_bcast<0x00>(tq);
+        qx[1] = __uint_as_float(mu_bcast<0x55>(__float_as_uint(pq.x))); qy[1] = __uint_as_float(mu_bcast<0x55>(__float_as_uint(pq.y))); thr[1] = mu_bcast<0x55>(tq);
+        qx[2] = __uint_as_float(mu_bcast<0xAA>(__float_as_uint(pq.x))); qy[2] = __uint_as_float(mu_bcast<0xAA>(__float_as_uint(pq.y))); thr[2] = mu_bcast<0xAA>(tq);
+        qx[3] = __uint_as_float(mu_bcast<0xFF>(__float_as_uint(pq.x))); qy[3] = __uint_as_float(mu_bcast<0xFF>(__float_as_uint(pq.y))); thr[3] = mu_bcast<0xFF>(tq);
+        // y extent of the four queries of the lane's half (the two halves' scan ranges are joined as scalars below)
+        const float ymn = mu_fmin(mu_fmin(qy[0], qy[1]), mu_fmin(qy[2], qy[3]));
+        const float ymx = mu_fmax(mu_fmax(qy[0], qy[1]), mu_fmax(qy[2], qy[3]));
         // the eight query rows: one word per lane and row from global memory (the loads land during the scan), then LDS
         uint32_t qw[MU_G];
 #pragma unroll
@@ -266,15 +272,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // halves read the same 32 entries, each tests its four queries (sign of bits(d) - thr shifted into a 4-bit mask:
         // sub + alignbit, no condition code), one v_permlane32_swap joins the halves' nibbles into the 8-bit membership
         // mask (bit 7 - k = query k) in every lane; targets with a non-zero mask go to the union list (lanes 0..31
-        // write).  entry = mask << 24 | window position << 8.  cnt accumulates the set bits = in-radius (query, target)
-        // cells of the round (the same in both halves)
+        // write).  entry = inverted mask << 24 | window position << 8.  ncnt accumulates the set bits = (query, target)
+        // pairs tested and NOT in radius (the same in both halves)
         int ucnt = 0;
-        uint32_t cnt = 0;
+        uint32_t ncnt = 0, ntest = 0;
 #define MU_TEST4(T)                                                                                       \
         ({                                                                                                \
             uint32_t m_ = 0;                                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-                m_ = __builtin_amdgcn_alignbit(m_, mu_l1_bits(qx[i], qy[i], (T)) - thr[i], 31);           \
+                m_ = __builtin_amdgcn_alignbit(m_, thr[i] - mu_l1_bits(qx[i], qy[i], (T)), 31);           \
             /* swap(A, B): A's lanes 32..63 <-> B's lanes 0..31; with A = B = m_: r_[0] = the low half's nibble everywhere, */ \
             /* r_[1] = the high half's */                                                                 \
             const auto r_ = __builtin_amdgcn_permlane32_swap(m_, m_, false, false);                       \
@@ -282,21 +288,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         })
         {
             const float ys = (fabsf(ymn) + fabsf(ymx) + fabsf(radius)) * 1e-6f + 1e-6f;   // covers the rounding of dy in the test
-            int sc0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)] & ~63;   // steps of 64 stay inside the NaN padded array
-            int sc1 = s_ys[mu_ybucket(ymx + radius + ys, ty0, yscale) + 1];
-            sc0 = __builtin_amdgcn_readfirstlane(sc0);
-            sc1 = __builtin_amdgcn_readfirstlane(sc1);
+            const int h0 = s_ys[mu_ybucket(ymn - radius - ys, ty0, yscale)];
+            const int h1 = s_ys[mu_ybucket(ymx + radius + ys, ty0, yscale) + 1];
+            const int sc0 = min(__builtin_amdgcn_readlane(h0, 0), __builtin_amdgcn_readlane(h0, 32)) & ~63;   // steps of 64 stay inside the NaN padded array
+            const int sc1 = max(__builtin_amdgcn_readlane(h1, 0), __builtin_amdgcn_readlane(h1, 32));
             const int l31 = lane & 31;
+            if (sc1 > sc0) ntest = (uint32_t)((sc1 - sc0 + 63) >> 6) * 16u;   // two steps of eight tests per lane and iteration
             for (int base = sc0; base < sc1; base += 64) {
                 // two steps of 32 targets in flight
                 const float2 ta = s_ykp[base + l31], tb = s_ykp[base + 32 + l31];
                 const uint32_t pa = s_ypos[base + l31], pb = s_ypos[base + 32 + l31];
                 const uint32_t m8a = MU_TEST4(ta), m8b = MU_TEST4(tb);
-                cnt += (uint32_t)__popc(m8a) + (uint32_t)__popc(m8b);
-                const uint32_t ua = (uint32_t)__ballot(m8a != 0), ub = (uint32_t)__ballot(m8b != 0);
+                ncnt += (uint32_t)__popc(m8a) + (uint32_t)__popc(m8b);
+                const uint32_t ua = (uint32_t)__ballot(m8a != 0xffu), ub = (uint32_t)__ballot(m8b != 0xffu);
                 const int ca = __popc(ua);
-                if (m8a != 0 && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(ua, 0u), MU_UCAP - 1)] = (m8a << 24) | (pa << 8);
-                if (m8b != 0 && half == 0) ul[min(ucnt + ca + (int)__builtin_amdgcn_mbcnt_lo(ub, 0u), MU_UCAP - 1)] = (m8b << 24) | (pb << 8);
+                if (m8a != 0xffu && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(ua, 0u), MU_UCAP - 1)] = (m8a << 24) | (pa << 8);
+                if (m8b != 0xffu && half == 0) ul[min(ucnt + ca + (int)__builtin_amdgcn_mbcnt_lo(ub, 0u), MU_UCAP - 1)] = (m8b << 24) | (pb << 8);
                 ucnt += ca + __popc(ub);
             }
             for (int base = wcap; base < W; base += 32) {   // windows wider than MU_KPCAP (dense data only)
@@ -304,9 +311,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 float2 t2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
                 if (w < W) t2 = P.t.skp[lo + w];
                 const uint32_t m8 = MU_TEST4(t2);
-                cnt += (uint32_t)__popc(m8);
-                const uint32_t u = (uint32_t)__ballot(m8 != 0);
-                if (m8 != 0 && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(u, 0u), MU_UCAP - 1)] = (m8 << 24) | ((uint32_t)w << 8);
+                ncnt += (uint32_t)__popc(m8);
+                ntest += 8u;
+                const uint32_t u = (uint32_t)__ballot(m8 != 0xffu);
+                if (m8 != 0xffu && half == 0) ul[min(ucnt + (int)__builtin_amdgcn_mbcnt_lo(u, 0u), MU_UCAP - 1)] = (m8 << 24) | ((uint32_t)w << 8);
                 ucnt += __popc(u);
             }
         }
@@ -314,8 +322,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         const bool list_ovf = ucnt > MU_UCAP;
         const int nu = list_ovf ? 0 : ucnt;
         __builtin_amdgcn_wave_barrier();
-        // padding behind the list: copies of the last entry with an empty mask (scored, never counted)
-        if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] & 0x00ffffffu;
+        // padding behind the list: copies of the last entry with nobody's membership (scored, never counted)
+        if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] | 0xff000000u;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < MU_G; ++k) s_qrow[wave][k][lane] = qw[k];
@@ -333,11 +341,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             asm volatile("" : "+v"(g8));
             g8 >>= 3;
             u32x4 r0[MU_NP], r1[MU_NP];
-            uint32_t ent[MU_NP];
+            uint32_t un[MU_NP];   // the pass's list position for the tracker key, all ones where the lane's query is not a member
 #define MU_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
-                ent[SLOT] = ul[(T) * 8 + g8];                                                              \
-                const grow_t row_ = (grow_t)(wrows + ((ent[SLOT] & 0x00ffffffu) | (uint32_t)(sub << 4)));  \
+                const uint32_t ent_ = ul[(T) * 8 + g8];                                                    \
+                un[SLOT] = (uint32_t)((T) * 8 + g8) | (uint32_t)__builtin_amdgcn_sbfe((int)ent_, (uint32_t)msh, 1u); \
+                const grow_t row_ = (grow_t)(wrows + ((ent_ & 0x00ffffffu) | (uint32_t)(sub << 4)));       \
                 r0[SLOT] = row_[0];                                                                        \
                 r1[SLOT] = row_[8];                                                                        \
             } while (0)
@@ -374,7 +383,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 "v_add_u32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
                 "v_add_u32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa"                              \
                 : "+v"(S0), "+v"(S2), "+v"(S4), "+v"(S6) : "v"(S1), "v"(S3), "v"(S5), "v"(S7))
-#define MU_REDUCE(SLOT, U)                                                                                \
+#define MU_REDUCE(SLOT)                                                                                   \
             do {                                                                                           \
                 uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
                 __builtin_amdgcn_sched_barrier(0);   /* two halves: all sixteen query-row reads in flight at once cost 64 VGPRs */ \
@@ -382,8 +391,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 MU_X4x4(s0_, s1_, s2_, s3_, s4_, s5_, s6_, s7_);   /* s0_ s2_ s4_ s6_: queries (0|1) (2|3) (4|5) (6|7) by bit 2 */ \
                 const uint32_t c0_ = MU_X2(s0_, s2_), c1_ = MU_X2(s4_, s6_);                               \
                 const uint32_t m_ = MU_X1(c0_, c1_);                                                       \
-                const bool member_ = ((ent[SLOT] >> msh) & 1u) != 0;                                       \
-                mu_update(tr, member_ ? ((m_ << 9) | (uint32_t)(U)) : 0xffffffffu);                        \
+                mu_update(tr, (m_ << 9) | un[SLOT]);                                                       \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -393,7 +401,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             for (; t + MU_NP < npass; t += MU_NP) {   // steady state: no branch between reduce and refill (the hardware
 #pragma unroll                                        // counts outstanding loads; a branch would make the compiler drain them)
                 for (int p = 0; p < MU_NP; ++p) {
-                    MU_REDUCE(p, (t + p) * 8 + g8);
+                    MU_REDUCE(p);
                     // keep the refill of this slot HERE: left alone the scheduler sinks all refills to the end of the
                     // loop body, where the next iteration waits for them at once (no load is in flight during a reduce)
                     __builtin_amdgcn_sched_barrier(0);
@@ -401,9 +409,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (npass > 0) {
-#pragma unroll
-                for (int p = 0; p < MU_NP; ++p) MU_REDUCE(p, (t + p) * 8 + g8);
+            if (npass > 0) {   // the last one or two passes (an odd count would otherwise score a pass of padding)
+                MU_REDUCE(0);
+                if (MU_NP > 1 && t + 1 < npass) MU_REDUCE(MU_NP > 1 ? 1 : 0);
             }
 #undef MU_REDUCE
 #undef MU_X4x4
@@ -415,11 +423,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
         // query); lane l (< 8) then holds query myq(l): 0 4 2 6 1 5 3 7 -> bring query k to the lane that carries its
         // data (mu_qlane); fetch the original target index, ratio test, store
-#pragma unroll
-        for (int m = 8; m < VISO_WAVE; m <<= 1) {
+        {   // lane ^ 8: rotation by 8 within the row of 16 (DPP); lane ^ 16: ds_swizzle; lane ^ 32: v_permlane32_swap hands
+            // every lane both halves' values
             MuTrack o;
-            o.m1 = (uint32_t)__shfl_xor((int)tr.m1, m);
-            o.m2 = (uint32_t)__shfl_xor((int)tr.m2, m);
+            o.m1 = mu_dpp<0x128>(tr.m1);
+            o.m2 = mu_dpp<0x128>(tr.m2);
+            mu_merge(tr, o);
+            o.m1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)tr.m1, 0x401F);
+            o.m2 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)tr.m2, 0x401F);
+            mu_merge(tr, o);
+            const auto h1 = __builtin_amdgcn_permlane32_swap(tr.m1, tr.m1, false, false);
+            const auto h2 = __builtin_amdgcn_permlane32_swap(tr.m2, tr.m2, false, false);
+            tr.m1 = h1[0]; tr.m2 = h2[0];
+            o.m1 = h1[1]; o.m2 = h2[1];
             mu_merge(tr, o);
         }
         {
@@ -439,15 +455,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         int my_cnt = 0;
         if (slow) {
             for (int b = 0; b < nu; b += VISO_WAVE) {
-                const uint32_t e = (b + lane) < nu ? ul[b + lane] : 0u;
+                const uint32_t e = (b + lane) < nu ? ul[b + lane] : 0xffffffffu;
 #pragma unroll
                 for (int k = 0; k < MU_G; ++k) {
-                    const int c = __popcll(__ballot(((e >> (31 - k)) & 1u) != 0));
+                    const int c = __popcll(__ballot(((e >> (31 - k)) & 1u) == 0));
                     if (lane == mu_qlane(k)) my_cnt += c;
                 }
             }
         } else if (!list_ovf && half == 0) {
-            scored += cnt;   // every result of the round stands: all its cells count (lanes 0..31 hold partial sums)
+            scored += ntest - ncnt;   // every result of the round stands: all its cells count (lanes 0..31 hold partial sums)
         }
         if (mine) {
             if (list_ovf || my_cnt > K || tie) {
