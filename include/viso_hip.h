@@ -81,7 +81,7 @@ viso_ctx* viso_ctx_create(int device, void* stream);
  * viso_last_error() (everything that can be freed still is).  Destroy batches first, and destroy both before
  * the process starts exiting: not from static destructors that may run after the HIP runtime's own. */
 int viso_ctx_destroy(viso_ctx* ctx);
-/* hipStream_t the context launches on.  Every context also owns a second, high-priority stream for the RANSAC
+/* hipStream_t the context launches on.  Every context also owns a second stream for the RANSAC
  * stage of its batches (it runs beside the next run's matcher; ordered by events, waited for by
  * viso_ctx_synchronize and by every getter): a host that orders its own work against viso_ctx_stream() must
  * use viso_ctx_synchronize (or a result getter) to see poses, not a bare hipStreamSynchronize of that stream. */

@@ -88,7 +88,7 @@ struct viso_ctx {
     bool own_stream;
     int matcher_variant;         // viso_ctx_set_matcher
     int gn_split;                // viso_ctx_set_gn_split
-    // second, high-priority stream of the context: the RANSAC stage of its batches runs here, beside the next run's
+    // second stream of the context: the RANSAC stage of its batches runs here, beside the next run's
     // matcher on `stream` (viso_ctx_synchronize waits for both).  One per CONTEXT, not per batch: the runtime maps
     // streams onto a handful of hardware queues, and two busy RANSAC streams that land on one queue serialise
     // (measured: 9 streams for 3 busy batches -> two chains on one queue, 0.43 -> 0.68 ms per step).

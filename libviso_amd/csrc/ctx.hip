@@ -41,10 +41,10 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
         }
         c->own_stream = true;
     }
-    int lo_p = 0, hi_p = 0;   // numerically lowest value = highest priority
-    if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }
-    if ((e = hipStreamCreateWithPriority(&c->solver_stream, hipStreamNonBlocking, hi_p)) != hipSuccess) {
-        viso_set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    // the RANSAC stream has the matcher stream's priority: a high-priority one made the step slower (its 256-register
+    // waves push matcher waves aside the moment they are ready; measured 351 k against 360 k frames/s end to end)
+    if ((e = hipStreamCreateWithFlags(&c->solver_stream, hipStreamNonBlocking)) != hipSuccess) {
+        viso_set_error("hipStreamCreate (solver stream): %s", hipGetErrorString(e));
         if (c->own_stream) hipStreamDestroy(c->stream);
         delete c;
         return nullptr;

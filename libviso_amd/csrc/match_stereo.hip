@@ -29,7 +29,10 @@
 #define ST_NBY 64            // y buckets
 #define ST_SLOTS 8           // candidates per query and chunk that may reach the scorer
 #define ST_PCAP (ST_QPW * ST_SLOTS)
-#define ST_PAD 16            // the scoring pipeline runs up to 2 passes of 8 pairs past the end
+#ifndef ST_NP
+#define ST_NP 2              // passes of 8 pairs in flight
+#endif
+#define ST_PAD (8 * ST_NP)   // the scoring pipeline runs up to ST_NP passes of 8 pairs past the end
 #define ST_BAND_MAX 6.0f     // wider bands: match_batch_kernel<1>
 
 struct StWaveLds {
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
         {
             const int npass = (ntot + 7) >> 3;
             const gbytes_t wrows = trows + (size_t)(lo + cb) * (VISO_ROW * 2);
-            u32x4 t0[2], t1[2], u0[2], u1[2];
-            int dst[2];
+            u32x4 t0[ST_NP], t1[ST_NP], u0[ST_NP], u1[ST_NP];
+            int dst[ST_NP];
 #define ST_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
                 const int gi_ = (T) * 8 + g8;                                                              \
@@ -254,13 +257,24 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
                 s_ += st_dpp<0x141>(s_);                                                                   \
                 if (sub == 0) L.sads[dst[SLOT]] = s_;   /* slots past ntot are scratch */                  \
             } while (0)
-            if (npass > 0) { ST_ISSUE(0, 0); ST_ISSUE(1, 1); }
-            int t = 0;
-            for (; t + 2 < npass; t += 2) {
-                ST_REDUCE(0); ST_ISSUE(0, t + 2);
-                ST_REDUCE(1); ST_ISSUE(1, t + 3);
+            if (npass > 0) {
+#pragma unroll
+                for (int p = 0; p < ST_NP; ++p) ST_ISSUE(p, p);
             }
-            if (npass > 0) { ST_REDUCE(0); ST_REDUCE(1); }
+            int t = 0;
+            for (; t + ST_NP < npass; t += ST_NP) {
+#pragma unroll
+                for (int p = 0; p < ST_NP; ++p) {
+                    ST_REDUCE(p);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ST_ISSUE(p, t + p + ST_NP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (npass > 0) {
+#pragma unroll
+                for (int p = 0; p < ST_NP; ++p) ST_REDUCE(p);
+            }
 #undef ST_REDUCE
 #undef ST_ISSUE
         }
