@@ -1151,6 +1151,7 @@ void fill_match_params(MatchParamsDev* d, const viso_match_params* h) {
     d->K = h->max_neighbors;
     d->_pad = 0;
     d->radius = (float)h->radius;   // src/viso.cpp:685: double -> float parameter
+    if (d->radius == 0.f) d->radius = 0.f;   // -0.0 -> +0.0: the kernels compare bit patterns of distances with the radius'
     d->_padf = 0;
     for (int i = 0; i < 9; ++i) d->F[i] = h->F[i];
     d->sampson_thresh = h->sampson_thresh;

@@ -1,28 +1,36 @@
 // match_union.hip — temporal (no epipolar gate) matcher: one row load scored against EIGHT y-adjacent queries.
 //
-// The dominant kernel (97 % of the scored pairs).  It is bound by vector-ALU issue, not by memory: VALUBusy 1.04 with
+// The dominant kernel (97 % of the scored pairs).  It is bound by vector-ALU issue, not by memory: VALUBusy 1.0 with
 // 7 waves per SIMD; HBM traffic is the compulsory u16 rows (x 1.05), the row gathers are served by the
-// XCD's L2.  What it spends per useful SAD is what matters, so everything is arranged to share work between queries:
+// XCD's L2.  What it spends per useful SAD is what matters, so everything is arranged to share work between queries
+// and to keep the instructions around the SADs few and free of condition codes:
 //
 //   tile    64 consecutive (column-bucket order) queries of one problem = one 256-thread workgroup; the +-radius column
 //           window of the target image (two loads from the bucket index), its KEYPOINTS (8 B each, not its rows)
 //           bucket-sorted by y in LDS
 //   round   eight y-adjacent queries (ImageView::qord) per wave, two rounds per wave: their L1 diamonds overlap so much
-//           that the union of the candidate sets is ~94 rows for 8 x 51.5 candidates
+//           that the union of the candidate sets is ~94 rows for 8 x 51.5 candidates.  Lane l carries query
+//           (l & 3) + 4 * (l >> 5): a DPP quad broadcast hands every lane the four queries its half tests
 //   phase 1 one scan of the y buckets the round's diamonds touch, 32 targets per step with both lane halves on the same
-//           targets (lanes 0..31 test queries 0..3, lanes 32..63 queries 4..7; Q1 cut and radius as ONE unsigned compare
-//           of the bit pattern of |dx| + |dy|); targets with a non-zero 8-bit membership mask are appended (ballot +
-//           mbcnt) to the round's union list in LDS; per-query in-radius counts (K cap) are bit counts over the list
+//           targets (lanes 0..31 test queries 0..3, lanes 32..63 queries 4..7).  Q1 cut and radius are ONE threshold on
+//           the bit pattern of |dx| + |dy|; the verdict is the SIGN of (thr - 1) - bits(d), shifted into a 4-bit mask
+//           by v_alignbit (no v_cmp, no select); one v_permlane32_swap joins the halves' nibbles; targets with a member
+//           are appended (ballot + mbcnt) to the round's union list in LDS.  Masks are kept INVERTED (set = not a member).
+//           Per-query in-radius counts (K cap) are only taken when the list is longer than K or a minimum is tied
 //   phase 2 rolling pipeline over the union list, 8 lanes per row, 2 passes in flight: two global_load_dwordx4 per lane,
 //           8 x v_sad_u16 against each of the eight query rows (staged per wave in LDS), a transposing reduction (three
 //           exchange steps, each halving the partial sums a lane carries: every lane of the 8-lane group ends with the
-//           total of ITS query) and a packed-key tracker (key = SAD << 9 | list position; m2 = med3, m1 = min) — no SAD
-//           ever goes to memory
-//   phase 3 merge the 8 partial trackers per query across the lane groups, ratio test in double, store
+//           total of ITS query; the first step, on four pairs, is two bank-masked v_add_u32_dpp per pair — a lane's
+//           bit 2 is its DPP bank — instead of two selects and an add) and a packed-key tracker (key = SAD << 9 | list
+//           position, or all ones for a non-member by an OR prepared when the row was requested; m2 = med3, m1 = min)
+//           — no SAD ever goes to memory
+//   phase 3 merge the 8 partial trackers per query across the lane groups (DPP row rotation, ds_swizzle, permlane
+//           swap), ratio test in double, store
 //
 // Same results as the other matcher kernels.  Irregular rounds (a query with more than K in-radius candidates, a union
-// list that does not fit, an exact tie of the minimum) go to match_overflow_kernel.  match_prune.hip is the same tile /
-// scan with exact candidate pruning in front of a cell-granular phase 2 (variant 5: fewer instructions, same time).
+// list that does not fit, an exact tie of the minimum) go to match_overflow_kernel.  match_prune.hip (variant 5) puts
+// exact candidate pruning in front of a cell-granular phase 2; it keeps the tile / scan code this kernel had before
+// its instruction diet and is the slower of the two.
 #include "common.h"
 #include "match_dev.h"
 

@@ -123,6 +123,23 @@ def test_match_list_order_with_piled_up_distances(viso, oracle):
         assert len(want) > 500 and np.array_equal(got, want), variant
 
 
+def test_match_desc_radius_edge_values(viso, oracle, F):
+    """The matcher kernels compare BIT PATTERNS of L1 distances with the radius': zero, minus zero (0 <= -0.0 holds: the
+    coincident targets stay in), a radius between two integers, huge, infinite, negative and NaN radii."""
+    rng = np.random.default_rng(21)
+    kp1, kp2, d1, d2 = rand_problem(rng, 300, 320, width=60, height=40)
+    kp2[:150] = kp1[:150]                      # coincident keypoints: distance exactly 0
+    kp2[0] = (900.0, 900.0)                    # target 0 out of every radius below 1000 (Q1 cuts nothing there)
+    for radius in (0.0, -0.0, 0.5, 1.0, 1.5, 7.999, 80.0, 1e9, float("inf"), -1.0, float("nan")):
+        for mp in (MatchParams.temporal(), MatchParams.stereo(F)):
+            mp.radius = radius
+            want = oracle.match_desc(kp1, kp2, d1, d2, mp)
+            got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
+            assert np.array_equal(got, want), (radius, mp.enforce_epipolar, len(got), len(want))
+            if radius in (0.0, -0.0) and not mp.enforce_epipolar:
+                assert len(want) > 50          # the coincident pairs matched: the case is not vacuous
+
+
 def test_match_desc_extreme_values_and_general_path(viso, oracle):
     rng = np.random.default_rng(9)
     kp1, kp2, d1, d2 = rand_problem(rng, 120, 130, lo=-32768, hi=32768)   # full int16 range (fast path)
