@@ -11,9 +11,11 @@ from libviso_amd.abi import MatchParams
 pytestmark = pytest.mark.gpu
 
 
-def _run_batch(seq, seed=3, full=True):
+def _run_batch(seq, seed=3, full=True, temporal_k=None):
     nf, _, cap, _ = seq["kp"].shape
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    if temporal_k is not None:
+        tm.max_neighbors = temporal_k
     ctx = libviso_amd.Context(0)
     if _VARIANT[0] is not None:
         libviso_amd.set_matcher_variant(_VARIANT[0], ctx)
@@ -53,6 +55,25 @@ def test_config2_3_full_size_vs_oracle(viso, oracle):
         assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-5
     # ~50 candidates per temporal query, ~3 per stereo query
     assert 35 < sc[1, 1] / 2000 < 65 and 1.5 < sc[0, 1] / 2000 < 5
+    b.close(); ctx.close()
+
+
+@pytest.mark.parametrize("k", [45, 60, 93])
+def test_k_cap_between_a_querys_count_and_the_unions_length(viso, oracle, k):
+    """max_neighbors below the length of a round's union list (~94 rows) but around / above a single query's ~50
+    in-radius targets: the temporal kernel cannot tell from the list length that nobody exceeds K and takes the per-query
+    counts — some queries leave for the overflow kernel (K-cap selection), the others stand and must add exactly their
+    own candidates to the scored-pair counter."""
+    seq = synth.make_sequence(107, 2, n_kp=2000)
+    ctx, b, st, tm = _run_batch(seq, full=False, temporal_k=k)
+    sc, _ = b.counters()
+    kq, kt = seq["kp"][1, 0, :seq["n"][1, 0]], seq["kp"][0, 0, :seq["n"][0, 0]]
+    cnt = (np.abs(kq[:, None, :] - kt[None, :, :]).sum(2) <= 80).sum(1)
+    assert (cnt <= k).any() and ((cnt > k).any() or k == 93)   # both kinds of query exist (K = 93: nobody exceeds it,
+                                                               # but many a union list is longer)
+    for which in (1, 2):
+        want, wsc = _per_call(oracle, seq, which, 1, st, tm)
+        assert np.array_equal(b.matches(which, 1), want) and sc[which, 1] == wsc, (which, k)
     b.close(); ctx.close()
 
 
