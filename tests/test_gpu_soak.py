@@ -1,6 +1,6 @@
 """Seeded soak of the full pipeline against the oracle: small sequences with varying keypoint counts, clustering,
 outlier shares, RANSAC seeds and global frame offsets.  A handful of cases by default; VISO_SOAK_CASES=500 for a long
-run on the GPU box."""
+run on the GPU box (VISO_SOAK_SEED: another stream of cases; VISO_SOAK_VARIANT: one matcher kernel only)."""
 import os
 
 import numpy as np
@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_pipeline_soak(viso, oracle):
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(int(os.environ.get("VISO_SOAK_SEED", "4242")))
+    only = os.environ.get("VISO_SOAK_VARIANT")
     for c in range(int(os.environ.get("VISO_SOAK_CASES", "5"))):
         nf = int(rng.integers(3, 8))
         nkp = int(rng.choice([300, 800, 1500, 2000]))
@@ -25,7 +26,7 @@ def test_pipeline_soak(viso, oracle):
         seed, ff = int(rng.integers(0, 1 << 40)), int(rng.integers(0, 1 << 20))
         want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=seed, first_frame=ff)
         ctx = libviso_amd.Context(0)
-        variants = libviso_amd.MATCHER_VARIANTS
+        variants = (int(only),) if only else libviso_amd.MATCHER_VARIANTS
         libviso_amd.set_matcher_variant(variants[c % len(variants)], ctx)      # every matcher kernel of the build takes its turn
         b = libviso_amd.Batch(ctx, nf, seq["kp"].shape[2])
         b.upload(seq["kp"], seq["desc"], seq["n"])
