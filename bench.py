@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--matcher", type=int, default=None, help="kernel for the temporal calls (viso_ctx_set_matcher); default: the build's")
     ap.add_argument("--gn-split", type=int, default=0, help="viso_ctx_set_gn_split (0 = the build's default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="build the process group and run barrier / all_reduce(MAX) / the record all_gather even with ONE rank "
+                         "(the one-GPU box's way through RCCL; the N = 1 default touches no process group)")
     ap.add_argument("--images", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-images", action="store_true",
                     help="skip the resident image-in legs (device-side descriptor extraction / Harris on synthetic images)")
@@ -272,8 +275,16 @@ def main():
     dev_index = 0 if same_device else local_rank
     torch.cuda.set_device(dev_index)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:      # --force-collective outside torchrun: a group of one
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -311,7 +322,7 @@ def main():
 
     def barrier():
         sync_all()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def timed(fn, steps, warmup, objs=None):
@@ -326,7 +337,7 @@ def main():
             fn(objs[i % len(objs)])
         sync_all()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -490,7 +501,7 @@ def main():
         dts2 = timed_regions(lambda b: b.run(), args.steps, n_streams)
         dt2 = float(np.median(dts2))
         tr, ok, n_inl = batch.poses()
-        if world > 1:   # the one exchange step: gather per-frame records {tr[6], ok, n_inl} (RCCL over xGMI)
+        if use_dist:   # the one exchange step: gather per-frame records {tr[6], ok, n_inl} (RCCL over xGMI)
             rec = torch.tensor(np.concatenate([tr, ok[:, None].astype(np.float64), n_inl[:, None].astype(np.float64)], 1),
                                device=coll_dev)
             out = [torch.empty_like(rec) for _ in range(world)]
@@ -694,7 +705,7 @@ def main():
         b.close()
     for c, b in lanes:
         c.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -297,6 +297,12 @@ int viso_batch_get_overflow_count(viso_batch* b, int32_t* n);
  * on the context's stream: average in ms over the runs since the last viso_batch_kernel_ms call. */
 int viso_batch_kernel_timing(viso_batch* b, int enable);
 int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches);
+/* Time stamps of a run (hipEvents on the batch's streams), for hosts that want to know where a chunk's time went
+ * (the KITTI runner's per-rank report): viso_batch_stamp(b, 0) before the run's uploads, viso_batch_stamp(b, 1) after
+ * them; viso_batch_run* stamps the end of the run itself.  viso_batch_stamp_ms waits for the run and returns
+ * ms[0] = the uploads, ms[1] = everything the run launched behind them. */
+int viso_batch_stamp(viso_batch* b, int which);
+int viso_batch_stamp_ms(viso_batch* b, double ms[2]);
 
 #ifdef __cplusplus
 }

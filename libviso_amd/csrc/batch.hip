@@ -57,6 +57,9 @@ struct viso_batch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_next;            // ring position of the oldest outstanding pair
     double ev_ms_sum; int ev_n;
+    // viso_batch_stamp: time stamps of a run (0 = before its uploads, 1 = after them, 2 = behind its last kernel)
+    hipEvent_t ev_stamp[3];
+    bool stamps;
 };
 #define VISO_EVENT_POOL 64
 
@@ -100,6 +103,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     if (b->solver_stream) note(hipStreamSynchronize(b->solver_stream));   // the context's: not destroyed here
     if (b->ev_join) note(hipEventDestroy(b->ev_join));
     if (b->ev_ransac) note(hipEventDestroy(b->ev_ransac));
+    for (int k = 0; k < 3; ++k) if (b->ev_stamp[k]) note(hipEventDestroy(b->ev_stamp[k]));
     for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
     for (int k = 0; k < VISO_NPIN_SLOTS; ++k) if (b->n_pin_ev[k]) note(hipEventDestroy(b->n_pin_ev[k]));
     if (b->n_pin) note(hipHostFree(b->n_pin));
@@ -203,6 +207,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->params_set = false; b->timing = false; b->desc_i16 = false;
     b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     b->solver_stream = nullptr; b->ev_join = nullptr; b->ev_ransac = nullptr; b->ransac_pending = false;
+    b->ev_stamp[0] = b->ev_stamp[1] = b->ev_stamp[2] = nullptr; b->stamps = false;
     if (ctx->solver_stream) {
         if (hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_ransac, hipEventDisableTiming) != hipSuccess) {
@@ -463,6 +468,34 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     }
     if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, b->ovf_q, b->ovf_cnt, from_images ? 0 : 1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
+    if (b->stamps) HIP_TRY(hipEventRecord(b->ev_stamp[2], s));   // re-recorded behind the solver by run_rest
+    return VISO_OK;
+}
+
+// Time stamps of a run: which = 0 before the run's uploads, 1 after them (both on the context's stream); the end of
+// the run is stamped by viso_batch_run* itself once stamping is on (i.e. after the first viso_batch_stamp call).
+extern "C" int viso_batch_stamp(viso_batch* b, int which) {
+    if (!b || which < 0 || which > 1) { viso_set_error("viso_batch_stamp: bad argument"); return VISO_ERR_ARG; }
+    int r;
+    if ((r = enter(b)) < 0) return r;
+    for (int k = 0; k < 3; ++k)
+        if (!b->ev_stamp[k]) HIP_TRY(hipEventCreate(&b->ev_stamp[k]));
+    if (!b->stamps) {   // all three recorded once, so that viso_batch_stamp_ms never meets an unrecorded event
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(b->ev_stamp[k], b->ctx->stream));
+        b->stamps = true;
+    }
+    HIP_TRY(hipEventRecord(b->ev_stamp[which], b->ctx->stream));
+    return VISO_OK;
+}
+
+// Waits for the batch; ms[0] = stamp 0 -> stamp 1 (the uploads), ms[1] = stamp 1 -> behind the run's last kernel.
+extern "C" int viso_batch_stamp_ms(viso_batch* b, double ms[2]) {
+    if (!b || !ms || !b->stamps) { viso_set_error("viso_batch_stamp_ms: no stamps taken"); return VISO_ERR_ARG; }
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
+    float a = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev_stamp[0], b->ev_stamp[1]));
+    HIP_TRY(hipEventElapsedTime(&c, b->ev_stamp[1], b->ev_stamp[2]));
+    ms[0] = a; ms[1] = c;
     return VISO_OK;
 }
 
@@ -580,6 +613,7 @@ static int run_rest(viso_batch* b) {
         HIP_TRY(hipEventRecord(b->ev_ransac, ss));
         b->ransac_pending = true;
     }
+    if (b->stamps) HIP_TRY(hipEventRecord(b->ev_stamp[2], ss));
     return VISO_OK;
 }
 

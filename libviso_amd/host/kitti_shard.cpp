@@ -50,13 +50,15 @@ int kitti_count_frames(const std::string& seq_base, int begin, int end) {
 }
 
 std::vector<FrameRecord> kitti_run_range(const std::string& seq_base, const Matd& P1, const Matd& P2, int begin,
-                                         int first, int last, int device, int chunk, uint64_t ransac_seed) {
+                                         int first, int last, int device, int chunk, uint64_t ransac_seed,
+                                         int decode_threads, OdometryStats* stats) {
     std::vector<FrameRecord> rec;
     if (last <= first) return rec;
     const std::string ext = kitti_image_ext(seq_base, begin);
     StereoImageGenerator images({seq_base + "/image_0/%06d" + ext, seq_base + "/image_1/%06d" + ext},
                                 begin + first, begin + last);
-    OdometryResult res = sequence_odometry(P1, P2, images, chunk, ransac_seed, (uint64_t)(begin + first), device);
+    OdometryResult res = sequence_odometry(P1, P2, images, chunk, ransac_seed, (uint64_t)(begin + first), device, decode_threads);
+    if (stats) *stats = res.stats;
     // res.ok / res.tr / res.n_inliers: one entry per frame read, entry 0 = this range's first frame (no pose)
     for (size_t t = 1; t < res.ok.size(); ++t) {
         FrameRecord r;
@@ -70,7 +72,7 @@ std::vector<FrameRecord> kitti_run_range(const std::string& seq_base, const Matd
     return rec;
 }
 
-std::vector<Matd> chain_records(const FrameRecord* rec, int n) {
+std::vector<Matd> chain_records(const FrameRecord* rec, int n, bool reference_pose_list) {
     std::vector<Matd> poses;
     poses.push_back(Matd::eye(4));                                   // src/viso.cpp:1189-1190
     double pose[16];
@@ -80,7 +82,8 @@ std::vector<Matd> chain_records(const FrameRecord* rec, int n) {
         viso_pose_update(pose, rec[i].tr, pose);                     // :1315-1321
         Matd P(4, 4);
         std::memcpy(P.ptr(), pose, sizeof pose);
-        poses.push_back(P);
+        if (reference_pose_list) poses.back() = P;                   // :1317-1319: the product lands in poses.back()'s buffer
+        poses.push_back(P);                                          // :1321: ... and its clone is pushed
     }
     return poses;
 }
@@ -133,6 +136,8 @@ void mkdirs(const std::string& path) {
 
 // ---- C entry points ---------------------------------------------------------------------------------------
 static thread_local std::string g_host_err;
+static thread_local viso::OdometryStats g_last_stats;
+static thread_local int g_decode_threads = 0;
 
 extern "C" const char* viso_host_last_error(void) { return g_host_err.c_str(); }
 
@@ -154,7 +159,9 @@ extern "C" int viso_kitti_run_range(const char* seq_base, int begin, int first, 
             g_host_err = std::string("cannot read ") + seq_base + "/calib.txt";
             return VISO_ERR_ARG;
         }
-        std::vector<viso::FrameRecord> rec = viso::kitti_run_range(seq_base, P1, P2, begin, first, last, device, chunk, ransac_seed);
+        g_last_stats = viso::OdometryStats();
+        std::vector<viso::FrameRecord> rec = viso::kitti_run_range(seq_base, P1, P2, begin, first, last, device, chunk, ransac_seed,
+                                                                   g_decode_threads, &g_last_stats);
         for (size_t i = 0; i < rec.size(); ++i) {
             for (int j = 0; j < 6; ++j) rec8[i * 8 + (size_t)j] = rec[i].tr[j];
             rec8[i * 8 + 6] = rec[i].ok;
@@ -168,7 +175,20 @@ extern "C" int viso_kitti_run_range(const char* seq_base, int begin, int first, 
     }
 }
 
+extern "C" void viso_kitti_last_stats(double out[9]) {
+    const viso::OdometryStats& s = g_last_stats;
+    const double v[9] = {(double)s.frames, (double)s.decode_threads, s.wall_s, s.decode_wait_s, s.decode_cpu_s, s.issue_s,
+                         s.drain_wait_s, s.upload_ms, s.gpu_ms};
+    for (int i = 0; i < 9; ++i) out[i] = v[i];
+}
+
+extern "C" void viso_kitti_set_decode_threads(int n) { g_decode_threads = n > 0 ? n : 0; }
+
 extern "C" int viso_kitti_write_poses(const char* file_name, const double* rec8, int n, int* n_poses) {
+    return viso_kitti_write_poses2(file_name, rec8, n, 0, n_poses);
+}
+
+extern "C" int viso_kitti_write_poses2(const char* file_name, const double* rec8, int n, int reference_pose_list, int* n_poses) {
     if (!file_name || n < 0 || (n > 0 && !rec8)) { g_host_err = "viso_kitti_write_poses: bad argument"; return VISO_ERR_ARG; }
     std::vector<viso::FrameRecord> rec((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -177,7 +197,7 @@ extern "C" int viso_kitti_write_poses(const char* file_name, const double* rec8,
         rec[(size_t)i].n_inl = (int32_t)rec8[(size_t)i * 8 + 7];
         rec[(size_t)i].frame = rec[(size_t)i].reserved = 0;
     }
-    std::vector<viso::Matd> poses = viso::chain_records(rec.data(), n);
+    std::vector<viso::Matd> poses = viso::chain_records(rec.data(), n, reference_pose_list != 0);
     const std::string f = file_name;
     const size_t slash = f.rfind('/');
     if (slash != std::string::npos && slash > 0) viso::mkdirs(f.substr(0, slash));

@@ -43,11 +43,19 @@ int kitti_count_frames(const std::string& seq_base, int begin, int end);
 // Frames [begin + first, begin + last] of the sequence through the device pipeline (device ordinal `device`):
 // rec[i] = record of the pair ending at frame first + 1 + i.  Fewer than last - first records come back when an
 // image in the range cannot be decoded (the reference's generator stops there, src/viso.h:94-96).
+// stats (may be null): where the range's wall time went (decode / upload / GPU), see OdometryStats.
 std::vector<FrameRecord> kitti_run_range(const std::string& seq_base, const Matd& P1, const Matd& P2, int begin,
-                                         int first, int last, int device, int chunk = 64, uint64_t ransac_seed = 0);
+                                         int first, int last, int device, int chunk = 64, uint64_t ransac_seed = 0,
+                                         int decode_threads = 0, OdometryStats* stats = nullptr);
 
-// poses[0] = I, then pose <- pose * inv(tr2mat(tr)) per solved record (src/viso.cpp:1189-1190, 1315-1321)
-std::vector<Matd> chain_records(const FrameRecord* rec, int n);
+// poses[0] = I, then pose <- pose * inv(tr2mat(tr)) per solved record (src/viso.cpp:1189-1190, 1315-1321): the list
+// [I, P1, ..., Pn] the reference's code reads as.
+// reference_pose_list = true: the list the reference actually WRITES.  `Mat pose = poses.back(); pose =
+// pose*tr_mat.inv(); poses.push_back(pose.clone());` (src/viso.cpp:1317-1321) assigns the product into a header that
+// shares poses.back()'s buffer (cv::Mat is reference counted; the GEMM result is copied into the existing buffer), so
+// the previous entry is overwritten before the clone is pushed: [P1, P2, ..., Pn, Pn] — no identity line, the last
+// pose twice, the same number of lines.
+std::vector<Matd> chain_records(const FrameRecord* rec, int n, bool reference_pose_list = false);
 
 // rank files of `viso_kitti --rank r --world W`: header {magic, first, last, n_done} + n_done records
 bool write_records(const std::string& file_name, int first, int last, const std::vector<FrameRecord>& rec);
@@ -67,7 +75,14 @@ int viso_kitti_count_frames(const char* seq_base, int begin, int end);
 // rec8: [(last - first)][8] doubles = tr[6], ok, n_inl per pair; *n_done = pairs actually solved or failed (not skipped)
 int viso_kitti_run_range(const char* seq_base, int begin, int first, int last, int device, int chunk,
                          uint64_t ransac_seed, double* rec8, int* n_done);
+// OdometryStats of this thread's last viso_kitti_run_range: frames, decode_threads, wall_s, decode_wait_s,
+// decode_cpu_s, issue_s, drain_wait_s, upload_ms, gpu_ms
+void viso_kitti_last_stats(double out[9]);
+// worker threads the next viso_kitti_run_range calls of this thread decode with (0 = default)
+void viso_kitti_set_decode_threads(int n);
 // chain n records and write the KITTI pose file (directories are created); *n_poses = lines written
 int viso_kitti_write_poses(const char* file_name, const double* rec8, int n, int* n_poses);
+// the same with the pose list the reference writes ([P1..Pn, Pn], see chain_records) when reference_pose_list != 0
+int viso_kitti_write_poses2(const char* file_name, const double* rec8, int n, int reference_pose_list, int* n_poses);
 const char* viso_host_last_error(void);
 }

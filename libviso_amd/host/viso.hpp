@@ -121,11 +121,26 @@ struct StereoFeatures {
 // std::nullopt at end of stream.
 using StereoFeatureGenerator = std::function<std::optional<StereoFeatures>()>;
 
+// Where a run's wall time went (the image-driven sequence_odometry fills all of it; the feature-driven one the GPU
+// side only).  A rank of the KITTI runner is bound by PNG decoding, not by the GPU: these are the numbers that say so.
+struct OdometryStats {
+    int frames = 0;               // frames read
+    int decode_threads = 0;       // worker threads that decoded the images
+    double wall_s = 0;            // whole call
+    double decode_wait_s = 0;     // calling thread blocked until a chunk's images were decoded (the runner's critical path)
+    double decode_cpu_s = 0;      // decode time summed over the worker threads (file read + inflate + unfilter)
+    double issue_s = 0;           // calling thread inside upload / detect / run calls (asynchronous: issue cost)
+    double drain_wait_s = 0;      // calling thread blocked in result read-back (GPU not done yet)
+    double upload_ms = 0;         // GPU time stamps: host -> device copies of all chunks
+    double gpu_ms = 0;            // GPU time stamps: detection + description + matching + solver of all chunks
+};
+
 struct OdometryResult {
     std::vector<Matd> poses;        // what the reference returns: poses[0] = I, then one per solved frame
     std::vector<int> frame_of_pose; // frame index of poses[i] (0 for the identity) — the reference drops failed frames silently (:1287,:1323)
     std::vector<int> ok, n_inliers; // per frame
     std::vector<std::array<double, 6>> tr;
+    OdometryStats stats;
 };
 
 // sequence_odometry, src/viso.cpp:1167-1330, minus the front-end and the debug
@@ -191,6 +206,15 @@ public:
     StereoImageGenerator(const std::pair<std::string, std::string>& mask, int begin = 0, int end = 2147483647)
         : m_mask(mask), m_index(begin), m_end(end) {}
     result_type operator()();
+    // Frame `index` alone — what operator() does for its current index.  const and thread safe: the image-driven
+    // sequence_odometry decodes the frames of a chunk on worker threads through these.
+    bool read(int index, Image& left, Image& right) const;
+    // One image of frame `index` (side 0 = left) into caller memory of a known geometry (a pinned upload buffer);
+    // false if it cannot be read or has another size.
+    bool read_to(int index, int side, int rows, int cols, uint8_t* dst) const;
+    int index() const { return m_index; }
+    int end() const { return m_end; }
+    void seek(int index) { m_index = index; }
 private:
     std::pair<std::string, std::string> m_mask;
     int m_index, m_end;
@@ -199,8 +223,11 @@ private:
 // sequence_odometry(P1, P2, images, dbg_dir), src/viso.h:138-139 / src/viso.cpp:1167-1330, without the
 // debug dumps: detection (MAX_FEATURE_NUM 1200, radius 5, :1171-1174), description, matching and the
 // solver all run on the device, `chunk` frames per batch.
+// decode_threads: worker threads that decode a chunk's images while the GPU works on the previous chunk
+// (0 = $VISO_DECODE_THREADS, else min(16, hardware threads)).  The frames are consumed in order and the sequence ends
+// at the first pair that cannot be decoded, exactly like the reference's generator (src/viso.h:94-96).
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images,
                                  int chunk = 64, uint64_t ransac_seed = 0, uint64_t first_frame_index = 0,
-                                 int device = 0);
+                                 int device = 0, int decode_threads = 0);
 
 }  // namespace viso

@@ -4,8 +4,15 @@
 #include "viso.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace viso {
 
@@ -288,9 +295,21 @@ struct ChunkPipeline {
         int nf = 0, cap = 0, dlen = 0;      // shape the batch was created for
         int global0 = 0;                    // global frame index of the chunk's first frame (its halo)
         bool busy = false;
+        bool stamped = false;               // the chunk in flight carries time stamps (viso_batch_stamp)
+        uint8_t* pin = nullptr;             // pinned staging buffer of the image-driven path: [frames][2][rows][cols]
+        size_t pin_bytes = 0;
         explicit Slot(int device) : ctx(device) {}
         Slot(const Slot&) = delete;
-        ~Slot() { if (b) viso_batch_destroy(b); }
+        ~Slot() { if (b) viso_batch_destroy(b); if (pin) viso_host_free(pin); }
+        uint8_t* pinned(size_t bytes) {
+            if (pin_bytes < bytes) {
+                if (pin) viso_host_free(pin);
+                pin = static_cast<uint8_t*>(viso_host_alloc(bytes));
+                pin_bytes = pin ? bytes : 0;
+                if (!pin) throw std::runtime_error(std::string("viso_host_alloc: ") + viso_last_error());
+            }
+            return pin;
+        }
     };
     Slot slot[2];
     int next = 0;
@@ -314,11 +333,22 @@ struct ChunkPipeline {
         return s.b;
     }
     void submitted() { slot[next].busy = true; next ^= 1; }
+    Slot& current() { return slot[next]; }
+    Slot& previous() { return slot[next ^ 1]; }
     void drain(Slot& s) {
         const int nf = s.nf;
         std::vector<double> tr((size_t)nf * 6);
         std::vector<int32_t> ok((size_t)nf), ninl((size_t)nf);
+        const auto t0 = std::chrono::steady_clock::now();
         hip_check(viso_batch_get_poses(s.b, tr.data(), ok.data(), ninl.data()), "sequence_odometry");
+        out.stats.drain_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (s.stamped) {
+            double ms[2] = {0, 0};
+            hip_check(viso_batch_stamp_ms(s.b, ms), "sequence_odometry");
+            out.stats.upload_ms += ms[0];
+            out.stats.gpu_ms += ms[1];
+            s.stamped = false;
+        }
         s.busy = false;
         for (int t = (s.global0 == 0 ? 0 : 1); t < nf; ++t) {
             out.ok.push_back(t == 0 ? 0 : ok[(size_t)t]);
@@ -489,16 +519,98 @@ static std::string format_mask(const std::string& mask, int index) {
     return buf;
 }
 
+bool StereoImageGenerator::read(int index, Image& left, Image& right) const {
+    left = imread_gray(format_mask(m_mask.first, index));
+    if (left.empty()) return false;
+    right = imread_gray(format_mask(m_mask.second, index));
+    return !right.empty();
+}
+
+bool StereoImageGenerator::read_to(int index, int side, int rows, int cols, uint8_t* dst) const {
+    const std::string name = format_mask(side ? m_mask.second : m_mask.first, index);
+    const size_t n = name.size();
+    if (n >= 4 && (name.compare(n - 4, 4, ".png") == 0 || name.compare(n - 4, 4, ".PNG") == 0))
+        return read_png_gray_to(name, rows, cols, dst);
+    Image im = imread_pgm(name);
+    if (im.empty() || im.rows != rows || im.cols != cols) return false;
+    std::memcpy(dst, im.data.data(), (size_t)rows * cols);
+    return true;
+}
+
 StereoImageGenerator::result_type StereoImageGenerator::operator()() {
     if (m_index > m_end) return std::nullopt;
-    Image a = imread_gray(format_mask(m_mask.first, m_index)), b = imread_gray(format_mask(m_mask.second, m_index));
+    Image a, b;
+    const bool ok = read(m_index, a, b);
     m_index++;
-    if (a.empty() || b.empty()) return std::nullopt;
+    if (!ok) return std::nullopt;
     return std::make_pair(std::move(a), std::move(b));
 }
 
+namespace {
+// Worker threads for the image decoding of one rank.  Tasks of a chunk are independent (one image each); the calling
+// thread waits for the whole chunk, the GPU meanwhile works on the previous one.
+class DecodePool {
+public:
+    explicit DecodePool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { work(); });
+    }
+    ~DecodePool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> l(m); q.push_back(std::move(f)); ++pending; }
+        cv_work.notify_one();
+    }
+    void wait_all() {
+        std::unique_lock<std::mutex> l(m);
+        cv_done.wait(l, [this] { return pending == 0; });
+    }
+    double busy_seconds() { std::lock_guard<std::mutex> l(m); return busy_s; }
+    int size() const { return (int)th.size(); }
+private:
+    void work() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv_work.wait(l, [this] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                f = std::move(q.front());
+                q.pop_front();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            f();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> l(m); busy_s += dt; --pending; }
+            cv_done.notify_all();
+        }
+    }
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::function<void()>> q;
+    int pending = 0;
+    bool stop = false;
+    double busy_s = 0;
+};
+
+int default_decode_threads() {
+    if (const char* e = std::getenv("VISO_DECODE_THREADS")) { const int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+}  // namespace
+
+// Chunks of `chunk` frames (plus the one-frame halo), two in flight: while the GPU runs chunk c (its own context,
+// asynchronous uploads from the slot's pinned buffer), the worker threads decode chunk c + 1 straight into the other
+// slot's pinned buffer.  The halo frame is copied from the previous slot's buffer, not decoded twice.
 OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGenerator& images, int chunk,
-                                 uint64_t ransac_seed, uint64_t first_frame_index, int device) {
+                                 uint64_t ransac_seed, uint64_t first_frame_index, int device, int decode_threads) {
+    using clock = std::chrono::steady_clock;
+    auto since = [](clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); };
+    const auto t_start = clock::now();
     if (P1.rows != 3 || P1.cols != 4 || P2.rows != 3 || P2.cols != 4) throw std::invalid_argument("sequence_odometry: P1,P2 must be 3x4");
     if (chunk < 1) chunk = 1;
     const int MAX_FEATURE_NUM = 1200;                                   // :1171
@@ -512,39 +624,82 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
     OdometryResult out;
     out.poses.push_back(Matd::eye(4));
     out.frame_of_pose.push_back(0);
+    if (images.index() > images.end()) return out;
+    // the first frame fixes the geometry of the sequence
+    Image first_l, first_r;
+    {
+        const auto t0 = clock::now();
+        const bool ok = images.read(images.index(), first_l, first_r);
+        out.stats.decode_wait_s += since(t0);
+        out.stats.decode_cpu_s += since(t0);
+        if (!ok) { images.seek(images.index() + 1); return out; }      // the generator stops at an unreadable pair (src/viso.h:94-96)
+    }
+    const int rows = first_l.rows, cols = first_l.cols;
+    if (first_r.rows != rows || first_r.cols != cols) throw std::invalid_argument("sequence_odometry: image size changes inside a sequence");
+    const size_t per = (size_t)rows * cols;
+    const int first_index = images.index();
+    images.seek(first_index + 1);
+    DecodePool pool(decode_threads > 0 ? decode_threads : default_decode_threads());
+    out.stats.decode_threads = pool.size();
     ChunkPipeline pipe(out, device);
-    std::vector<std::pair<Image, Image>> buf;
-    int global0 = 0;
+    int global0 = 0;                 // frame (relative to first_index) of the current chunk's halo
+    int frames_read = 1;
     bool eos = false;
+    bool have_halo_in_prev = false;  // false only for the first chunk (its frame 0 is first_l / first_r)
+    std::vector<uint8_t> ok_flag;
     while (!eos) {
-        while ((int)buf.size() < chunk + 1) {
-            StereoImageGenerator::result_type f = images();
-            if (!f) { eos = true; break; }
-            buf.push_back(std::move(*f));
+        // frames global0 + 1 .. global0 + want of this chunk still have to be decoded
+        const long left = (long)images.end() - (long)(first_index + global0);
+        const int want = (int)std::min<long>(chunk, std::max<long>(0, left));
+        if (want == 0 && global0 > 0) break;
+        ChunkPipeline::Slot& s = pipe.current();
+        if (s.busy) pipe.drain(s);                                      // its previous chunk (two steps ago)
+        uint8_t* pin = s.pinned((size_t)(chunk + 1) * 2 * per);
+        if (!have_halo_in_prev) {
+            std::memcpy(pin, first_l.data.data(), per);
+            std::memcpy(pin + per, first_r.data.data(), per);
+        } else {
+            ChunkPipeline::Slot& p = pipe.previous();
+            std::memcpy(pin, p.pin + (size_t)(p.nf - 1) * 2 * per, 2 * per);   // the previous chunk's last frame
         }
-        const int nf = (int)buf.size();
-        if (nf == 0 || (nf == 1 && global0 > 0)) break;
-        const int rows = buf[0].first.rows, cols = buf[0].first.cols;
-        std::vector<uint8_t> img((size_t)nf * 2 * rows * cols);
-        for (int t = 0; t < nf; ++t)
+        ok_flag.assign((size_t)want * 2, 0);
+        const auto t0 = clock::now();
+        for (int j = 0; j < want; ++j)
             for (int side = 0; side < 2; ++side) {
-                const Image& im = side ? buf[(size_t)t].second : buf[(size_t)t].first;
-                if (im.rows != rows || im.cols != cols) throw std::invalid_argument("sequence_odometry: image size changes inside a sequence");
-                std::memcpy(img.data() + ((size_t)t * 2 + side) * rows * cols, im.data.data(), (size_t)rows * cols);
+                uint8_t* dst = pin + ((size_t)(j + 1) * 2 + side) * per;
+                uint8_t* flag = &ok_flag[(size_t)j * 2 + side];
+                const int index = first_index + global0 + 1 + j;
+                pool.submit([&images, index, side, rows, cols, dst, flag] { *flag = images.read_to(index, side, rows, cols, dst) ? 1 : 0; });
             }
+        pool.wait_all();
+        out.stats.decode_wait_s += since(t0);
+        int got = 0;
+        while (got < want && ok_flag[(size_t)got * 2] && ok_flag[(size_t)got * 2 + 1]) ++got;
+        if (got < want || first_index + global0 + got >= images.end()) eos = true;
+        images.seek(first_index + global0 + got + (got < want ? 2 : 1));   // where operator() would stand now
+        frames_read += got;
+        const int nf = got + 1;
+        if (nf == 1 && global0 > 0) break;
+        const auto t1 = clock::now();
         viso_batch* b = pipe.acquire(nf, MAX_FEATURE_NUM, VISO_DESC_LEN, global0);
-        int r = viso_batch_upload_images(b, 0, nf, img.data(), rows, cols, nullptr, nullptr);
+        int r = viso_batch_upload_images(b, 0, 0, nullptr, rows, cols, nullptr, nullptr);          // device buffers for this geometry
         if (r >= 0) r = viso_batch_set_params(b, &st, &tm, &vp, ransac_seed, first_frame_index + (uint64_t)global0);
+        if (r >= 0) r = viso_batch_stamp(b, 0);
+        if (r >= 0) r = viso_batch_upload_images_async(b, 0, nf, pin, rows, cols, nullptr, nullptr);
+        if (r >= 0) r = viso_batch_stamp(b, 1);
         if (r >= 0) r = viso_batch_detect(b, detector.n(), detector.nbinx(), detector.nbiny(), (double)detector.k());   // :1226-1227
         if (r >= 0) r = viso_batch_run_images(b, 0);                                                                    // :1230-1313, asynchronous
         hip_check(r, "sequence_odometry");
+        s.stamped = true;
+        out.stats.issue_s += since(t1);
         pipe.submitted();
-        std::pair<Image, Image> last = std::move(buf.back());
-        buf.clear();
-        buf.push_back(std::move(last));
+        have_halo_in_prev = true;
         global0 += nf - 1;
     }
     pipe.finish();
+    out.stats.frames = frames_read;
+    out.stats.decode_cpu_s += pool.busy_seconds();
+    out.stats.wall_s = since(t_start);
     return out;
 }
 

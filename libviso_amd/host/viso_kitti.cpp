@@ -14,12 +14,19 @@
 //   --device d          HIP device ordinal of this process (default: the rank, 0 without --rank)
 //   --same-device       with --gpus: every rank on device 0 (rehearsal on a one-GPU box)
 //   --chunk n           frames per device batch (default 64)      --seed s   RANSAC stream seed (default 0)
+//   --decode-threads n  PNG decoding threads per rank (default: min(16, hardware threads / ranks))
+//   --reference-pose-list   write the list the reference's code actually produces, [P1, ..., Pn, Pn] (src/viso.cpp:1317-1321
+//                       overwrites poses.back() before pushing the clone), instead of [I, P1, ..., Pn]
+// Every rank reports where its wall time went: decode (PNG inflate on the worker threads; the calling thread's wait for
+// it is the runner's critical path), upload and GPU seconds from time stamps on the device.
 // libviso_amd/kitti_shard.py is the same runner with the gather as an RCCL all-gather (torch.distributed).
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -34,8 +41,8 @@ struct Args {
     const char* result_sha = nullptr;
     std::string seq_name;
     int begin = 0, end = INT_MAX;
-    int gpus = 0, rank = -1, world = 0, gather = 0, device = -1, chunk = 64;
-    bool same_device = false;
+    int gpus = 0, rank = -1, world = 0, gather = 0, device = -1, chunk = 64, decode_threads = 0;
+    bool same_device = false, reference_pose_list = false;
     unsigned long long seed = 0;
 };
 
@@ -50,6 +57,8 @@ bool parse(int argc, char** argv, Args& a) {
         else if (s == "--gather") { if (!val(a.gather)) return false; }
         else if (s == "--device") { if (!val(a.device)) return false; }
         else if (s == "--chunk") { if (!val(a.chunk)) return false; }
+        else if (s == "--decode-threads") { if (!val(a.decode_threads)) return false; }
+        else if (s == "--reference-pose-list") a.reference_pose_list = true;
         else if (s == "--seed") { if (i + 1 >= argc) return false; a.seed = std::strtoull(argv[++i], nullptr, 10); }
         else if (s == "--same-device") a.same_device = true;
         else if (s.rfind("--", 0) == 0) return false;
@@ -71,13 +80,26 @@ bool parse(int argc, char** argv, Args& a) {
 std::string rank_file(const std::string& result_dir, const std::string& seq, int r, int w) {
     return result_dir + "/shards/" + seq + "." + std::to_string(r) + "of" + std::to_string(w) + ".rec";
 }
+
+void print_stats(const char* who, const viso::OdometryStats& s) {
+    std::printf("%s: %d frames in %.3f s (%.0f frames/s) | decode: %d threads, %.3f s of thread time, runner waited %.3f s | "
+                "GPU stamps: upload %.3f s, kernels %.3f s | host: issue %.3f s, waiting for results %.3f s\n",
+                who, s.frames, s.wall_s, s.wall_s > 0 ? s.frames / s.wall_s : 0.0, s.decode_threads, s.decode_cpu_s, s.decode_wait_s,
+                s.upload_ms * 1e-3, s.gpu_ms * 1e-3, s.issue_s, s.drain_wait_s);
+}
+
+int threads_per_rank(int ranks) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int share = (int)(hw ? hw : 1) / (ranks > 0 ? ranks : 1);
+    return share < 1 ? 1 : (share > 16 ? 16 : share);
+}
 }  // namespace
 
 int main(int argc, char** argv) {
     Args a;
     if (!parse(argc, argv, a)) {
         std::printf("usage: demo result_sha seq_name begin end [--gpus W | --rank r --world W | --gather W] "
-                    "[--device d] [--same-device] [--chunk n] [--seed s]\n");                       // :81-85
+                    "[--device d] [--same-device] [--chunk n] [--seed s] [--decode-threads n] [--reference-pose-list]\n");   // :81-85
         return 1;
     }
     const char* home = std::getenv("KITTI_HOME");                                              // :96
@@ -92,6 +114,9 @@ int main(int argc, char** argv) {
     // ---- --gpus W: fork the ranks BEFORE this process touches the GPU (the parent never does: nothing above makes a
     // HIP call), each child carries on below as `--rank r --world W`; the parent waits and gathers.  fork without exec:
     // a child initialises its own HIP runtime on its first call ----
+    const auto t_start = std::chrono::steady_clock::now();
+    if (a.decode_threads <= 0 && !std::getenv("VISO_DECODE_THREADS"))
+        a.decode_threads = threads_per_rank(a.gpus > 1 ? a.gpus : 1);
     if (a.gpus > 1) {
         std::fflush(nullptr);
         std::vector<pid_t> kids;
@@ -134,37 +159,46 @@ int main(int argc, char** argv) {
                 }
             }
             const std::vector<viso::FrameRecord> all = viso::stitch_records(parts, ranges);
-            const std::vector<viso::Matd> poses = viso::chain_records(all.data(), (int)all.size());
+            const std::vector<viso::Matd> poses = viso::chain_records(all.data(), (int)all.size(), a.reference_pose_list);
             viso::mkdirs(result_dir + "/data");
             if (!viso::savePoses(out, poses)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 3; }
             int solved = 0;
             for (const auto& r : all) solved += r.ok;
-            std::printf("frames %zu solved %d poses %zu ranks %d -> %s\n", all.size() + (n_frames > 0), solved, poses.size(), a.gather, out.c_str());
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            std::printf("frames %zu solved %d poses %zu ranks %d -> %s (%.3f s, %.0f frames/s of the runner)\n", all.size() + (n_frames > 0),
+                        solved, poses.size(), a.gather, out.c_str(), wall, wall > 0 ? (double)(all.size() + (n_frames > 0)) / wall : 0.0);
             return 0;
         }
         // ---- --rank r --world W: this rank's range -> its rank file ----
         if (a.world > 0) {
             const auto range = viso::partition(n_frames, a.world)[(size_t)a.rank];
             const int device = a.device >= 0 ? a.device : a.rank;
+            viso::OdometryStats stats;
             std::vector<viso::FrameRecord> rec = viso::kitti_run_range(seq_base, P1, P2, a.begin, range.first, range.second,
-                                                                       device, a.chunk, a.seed);
+                                                                       device, a.chunk, a.seed, a.decode_threads, &stats);
             viso::mkdirs(result_dir + "/shards");
             const std::string f = rank_file(result_dir, a.seq_name, a.rank, a.world);
             if (!viso::write_records(f, range.first, range.second, rec)) { std::fprintf(stderr, "cannot write %s\n", f.c_str()); return 3; }
             std::printf("rank %d/%d device %d frames %d..%d pairs %zu -> %s\n", a.rank, a.world, device, a.begin + range.first,
                         a.begin + range.second, rec.size(), f.c_str());
+            print_stats(("rank " + std::to_string(a.rank)).c_str(), stats);
             return 0;
         }
         // ---- one process, one GPU: the reference's flow (:108-116) ----
         const std::string ext = viso::kitti_image_ext(seq_base, a.begin);
         viso::StereoImageGenerator images({seq_base + "/image_0/%06d" + ext, seq_base + "/image_1/%06d" + ext}, a.begin, a.end);
         viso::OdometryResult res = viso::sequence_odometry(P1, P2, images, a.chunk, a.seed, (uint64_t)a.begin,
-                                                           a.device >= 0 ? a.device : 0);      // :111
+                                                           a.device >= 0 ? a.device : 0, a.decode_threads);      // :111
         viso::mkdirs(result_dir + "/data");                                                    // :112-113
+        if (a.reference_pose_list && res.poses.size() > 1) {                                   // [P1, ..., Pn, Pn], see kitti_shard.hpp
+            res.poses.erase(res.poses.begin());
+            res.poses.push_back(res.poses.back());
+        }
         if (!viso::savePoses(out, res.poses)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 3; }
         int solved = 0;
         for (int v : res.ok) solved += v;
         std::printf("frames %zu solved %d poses %zu -> %s\n", res.ok.size(), solved, res.poses.size(), out.c_str());
+        print_stats("one process", res.stats);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 4;

@@ -16,6 +16,14 @@ W contiguous ranges with a one-frame halo, one rank per GPU:
 
 With --gpus W > 1 and no WORLD_SIZE in the environment this module starts its own ranks
 (`python -m torch.distributed.run --nproc-per-node W`, as a child process, before anything touches the GPU).
+`--force-collective` builds the process group and runs the all-gather even at W = 1 (the one-GPU box's way through
+RCCL: init_process_group("nccl", device_id=...), a float64 CUDA tensor through all_gather, an all_reduce(MAX) of the
+wall time, destroy_process_group).
+
+Failure handling (no collective is ever entered on one side only): a rank whose range fails still contributes its
+block to the ONE all-gather, with a status word set; every rank sees it and all of them exit non-zero after the
+collective.  A rank that fails before it knows the block shape (no calib, no frames) exits at once without joining
+anything; torchrun then tears the others down.
 This file is host plumbing: no arithmetic of the hot path happens in Python.
 """
 import argparse
@@ -24,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -51,8 +60,23 @@ def load_host():
     L.viso_kitti_run_range.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.viso_kitti_write_poses.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    L.viso_kitti_write_poses2.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.viso_kitti_last_stats.argtypes = [C.POINTER(C.c_double)]
+    L.viso_kitti_last_stats.restype = None
+    L.viso_kitti_set_decode_threads.argtypes = [C.c_int]
+    L.viso_kitti_set_decode_threads.restype = None
     L.viso_host_last_error.restype = C.c_char_p
     return L
+
+
+STAT_NAMES = ("frames", "decode_threads", "wall_s", "decode_wait_s", "decode_cpu_s", "issue_s", "drain_wait_s", "upload_ms", "gpu_ms")
+
+
+def last_stats(L):
+    """OdometryStats of this thread's last viso_kitti_run_range (host/viso.hpp): where the range's time went."""
+    v = (C.c_double * 9)()
+    L.viso_kitti_last_stats(v)
+    return dict(zip(STAT_NAMES, [float(x) for x in v]))
 
 
 def hip_engine(L, device, chunk=64, seed=0):
@@ -75,20 +99,29 @@ def count_frames(L, seq_base, begin, end):
     return n
 
 
-def gather_records(rec, n_pairs, first, rank, world, dist=None, device="cpu"):
+def gather_records(rec, n_pairs, first, rank, world, dist=None, device="cpu", failed=False):
     """The one exchange step.  Every rank contributes a fixed-size block [n_pairs + 1, 8]: its records at the rows of
     its pairs, and in the last row how many it solved (a rank comes back short when an image of its range cannot be
-    decoded).  Returns the blocks of all ranks, rank order."""
+    decoded) and a status word (1 = this rank's range failed: the block carries no records).  Returns the blocks of
+    all ranks, rank order.  With dist=None and world == 1 nothing is exchanged."""
     block = np.zeros((n_pairs + 1, REC), np.float64)
-    block[first:first + len(rec)] = rec
-    block[n_pairs, 0] = len(rec)
-    if world == 1:
+    if not failed:
+        block[first:first + len(rec)] = rec
+        block[n_pairs, 0] = len(rec)
+    block[n_pairs, 1] = 1.0 if failed else 0.0
+    if dist is None:
+        if world != 1:
+            raise RuntimeError("gather_records: world > 1 needs a process group")
         return [block]
     import torch
     t = torch.from_numpy(block).to(device)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)                          # fixed-size records, one collective
     return [o.cpu().numpy() for o in out]
+
+
+class RankFailed(RuntimeError):
+    """Raised on EVERY rank, after the all-gather, when some rank's range failed."""
 
 
 def stitch(blocks, n_frames):
@@ -105,29 +138,44 @@ def stitch(blocks, n_frames):
     return np.concatenate(rows, 0) if rows else np.zeros((0, REC))
 
 
-def write_poses(L, file_name, rec):
+def write_poses(L, file_name, rec, reference_pose_list=False):
+    """reference_pose_list: the list the reference's code actually writes, [P1, ..., Pn, Pn] (src/viso.cpp:1317-1321,
+    see host/kitti_shard.hpp), instead of [I, P1, ..., Pn]."""
     rec = np.ascontiguousarray(rec, np.float64)
     n_poses = C.c_int(0)
-    r = L.viso_kitti_write_poses(file_name.encode(), rec.ctypes.data_as(C.POINTER(C.c_double)), len(rec), C.byref(n_poses))
+    r = L.viso_kitti_write_poses2(file_name.encode(), rec.ctypes.data_as(C.POINTER(C.c_double)), len(rec),
+                                  1 if reference_pose_list else 0, C.byref(n_poses))
     if r != 1:
         raise RuntimeError(f"viso_kitti_write_poses failed with {r}: {L.viso_host_last_error().decode()}")
     return n_poses.value
 
 
-def run_rank(home, result_sha, seq_name, begin, end, rank, world, L, engine, dist=None, coll_device="cpu"):
+def run_rank(home, result_sha, seq_name, begin, end, rank, world, L, engine, dist=None, coll_device="cpu",
+             reference_pose_list=False):
     """One rank's whole job; returns (n_frames, records of the sequence, pose file or None).  `engine` is what
-    turns a frame range into records (hip_engine here; the CPU tests inject the oracle)."""
+    turns a frame range into records (hip_engine here; the CPU tests inject the oracle).  An engine that raises does
+    not keep this rank out of the collective: its block carries the failure, and every rank raises RankFailed behind
+    the all-gather."""
     seq_base = os.path.join(home, "sequences", seq_name)
-    n_frames = count_frames(L, seq_base, begin, end)
+    n_frames = count_frames(L, seq_base, begin, end)      # may raise: BEFORE any collective, see main()
     n_pairs = max(0, n_frames - 1)
     first, last = partition(n_frames, world)[rank]
-    rec = engine(seq_base, begin, first, last) if last > first else np.zeros((0, REC))
-    blocks = gather_records(rec, n_pairs, first, rank, world, dist, coll_device)
+    rec, err = np.zeros((0, REC)), None
+    try:
+        if last > first:
+            rec = engine(seq_base, begin, first, last)
+    except Exception as e:                                # noqa: BLE001  reported through the collective
+        err = e
+        print(f"kitti_shard: rank {rank} failed on frames {begin + first}..{begin + last}: {e}", file=sys.stderr, flush=True)
+    blocks = gather_records(rec, n_pairs, first, rank, world, dist, coll_device, failed=err is not None)
+    bad = [r for r, b in enumerate(blocks) if b[n_pairs, 1] != 0]
+    if bad:
+        raise RankFailed(f"rank(s) {bad} failed; no pose file written") from err
     full = stitch(blocks, n_frames)
     out = None
     if rank == 0:
         out = os.path.join(home, "results", seq_name, result_sha, "data", seq_name + ".txt")   # src/kitti.cpp:100,112-114
-        write_poses(L, out, full)
+        write_poses(L, out, full, reference_pose_list)
     return n_frames, full, out
 
 
@@ -150,6 +198,11 @@ def main(argv=None):
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--same-device", action="store_true", help="every rank on device 0 (rehearsal on a one-GPU box; use --backend gloo)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="build the process group and run the all-gather even with one rank (RCCL on a one-GPU box)")
+    ap.add_argument("--decode-threads", type=int, default=0, help="PNG decoding threads per rank (0: min(16, cpus / ranks))")
+    ap.add_argument("--reference-pose-list", action="store_true",
+                    help="write the list the reference's code actually produces, [P1..Pn, Pn] (src/viso.cpp:1317-1321)")
     args = ap.parse_args(argv)
     home = os.environ.get("KITTI_HOME")
     if not home:
@@ -174,10 +227,15 @@ def main(argv=None):
     device = 0 if args.same_device else local_rank
     dist = None
     coll_device = "cpu"
-    if world > 1:
+    t_start = time.perf_counter()
+    if world > 1 or args.force_collective:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:               # --force-collective outside torchrun: a group of one
+            os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -185,16 +243,59 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
     L = load_host()
+    threads = args.decode_threads or int(os.environ.get("VISO_DECODE_THREADS", "0")) or max(1, min(16, (os.cpu_count() or 1) // world))
+    L.viso_kitti_set_decode_threads(threads)
+
+    def die(code, what):
+        # a failure that the peers cannot learn about through the collective: leave WITHOUT joining one (no barrier,
+        # no destroy_process_group: the peers may be inside the all-gather); torchrun sees the exit code and stops them
+        print(f"kitti_shard: rank {rank}: {what}", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(code)
+
     try:
         n_frames, full, out = run_rank(home, args.result_sha, args.seq_name, args.begin, args.end, rank, world, L,
-                                       hip_engine(L, device, args.chunk, args.seed), dist, coll_device)
-        if rank == 0:
-            print(f"frames {len(full) + (n_frames > 0)} solved {int(full[:, 6].sum()) if len(full) else 0} ranks {world} "
-                  f"backend {args.backend if world > 1 else 'none'} -> {out}", flush=True)
-    finally:
-        if world > 1:
-            dist.barrier()
+                                       hip_engine(L, device, args.chunk, args.seed), dist, coll_device,
+                                       args.reference_pose_list)
+    except RankFailed as e:                                # every rank is here, behind the same all-gather
+        print(f"kitti_shard: rank {rank}: {e}", file=sys.stderr, flush=True)
+        if dist is not None:
             dist.destroy_process_group()
+        return 8
+    except Exception as e:                                 # noqa: BLE001  before / outside the collective
+        if dist is not None:
+            die(9, f"{type(e).__name__}: {e}")
+        raise
+    st = last_stats(L)
+    wall = time.perf_counter() - t_start
+    coll = None
+    if dist is not None:
+        import torch
+        # per-rank stats to rank 0's report: one all_gather of 9 doubles; the job's wall time is the slowest rank's
+        t = torch.tensor([st[k] for k in STAT_NAMES], dtype=torch.float64, device=coll_device)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        w = torch.tensor([wall], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+        per_rank = [dict(zip(STAT_NAMES, o.cpu().tolist())) for o in outs]
+        coll = {"backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": dist.get_world_size(),
+                "device": str(coll_device)}
+    else:
+        per_rank = [st]
+    if rank == 0:
+        n_all = len(full) + (n_frames > 0)
+        print(f"frames {n_all} solved {int(full[:, 6].sum()) if len(full) else 0} ranks {world} "
+              f"backend {coll['backend'] if coll else 'none'} -> {out}", flush=True)
+        for r, s in enumerate(per_rank):
+            print(f"rank {r}: {int(s['frames'])} frames in {s['wall_s']:.3f} s | decode: {int(s['decode_threads'])} threads, "
+                  f"{s['decode_cpu_s']:.3f} s of thread time, runner waited {s['decode_wait_s']:.3f} s | GPU stamps: upload "
+                  f"{s['upload_ms'] * 1e-3:.3f} s, kernels {s['gpu_ms'] * 1e-3:.3f} s | host: issue {s['issue_s']:.3f} s, waiting "
+                  f"for results {s['drain_wait_s']:.3f} s", flush=True)
+        print(f"runner: {n_all} frames in {wall:.3f} s = {n_all / wall:.0f} frames/s (process group + decode + GPU + gather + pose file"
+              f"{'; collective ' + str(coll) if coll else ''})", flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
     return 0
 
 

@@ -183,3 +183,126 @@ def test_broken_rank_files_are_refused(host, tmp_path):
     os.remove(bad)
     r = subprocess.run([EXE, "x", "05", "--gather", "3"], capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode == 3 and not os.path.exists(out)
+
+
+def _raising_engine(bad_rank, rank):
+    def run(seq_base, begin, first, last):
+        if rank == bad_rank:
+            raise RuntimeError("viso_kitti_run_range failed with -2: no HIP device (injected)")
+        return _fake_engine()(seq_base, begin, first, last)
+    return run
+
+
+def _failing_worker(rank, world, port, home, bad_rank, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from libviso_amd import kitti_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = kitti_shard.load_host()
+    try:
+        kitti_shard.run_rank(home, "bad", "09", 4, 2**31 - 1, rank, world, L, _raising_engine(bad_rank, rank), dist)
+        q.put((rank, "no error"))
+        code = 0
+    except kitti_shard.RankFailed as e:
+        q.put((rank, str(e)))
+        code = 8
+    dist.destroy_process_group()          # every rank is behind the same all-gather: a clean teardown is possible
+    sys.exit(code)
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_whose_range_fails_takes_every_rank_down_without_a_hang(host, tmp_path):
+    """ADVICE r3 / VERDICT r3 1(b): a rank that fails before its all_gather used to wait in a barrier its peers never
+    reach.  Now the failure travels in the rank's block of the one all-gather: every rank raises RankFailed behind the
+    collective, no pose file is written, the processes end (exit code 8) instead of hanging."""
+    from libviso_amd import kitti_shard
+    home = str(tmp_path)
+    _tree(home, "09", 23, begin=4)
+    with pytest.raises(kitti_shard.RankFailed):                     # one rank, no process group
+        kitti_shard.run_rank(home, "bad", "09", 4, 2**31 - 1, 0, 1, host, _raising_engine(0, 0))
+    for world, bad_rank in ((2, 1), (3, 0)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_failing_worker, args=(r, world, port, home, bad_rank, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 8, p.exitcode
+        assert all(f"[{bad_rank}]" in msg for msg in res.values()), res
+    assert not os.path.exists(os.path.join(home, "results", "09", "bad", "data", "09.txt"))
+
+
+def test_cli_error_paths_exit_nonzero_and_never_wait_for_a_collective(tmp_path):
+    """main(): (a) every rank's range fails (no HIP device in this container, or undecodable images on a GPU box would
+    come back short instead) -> exit 8 through the collective; (b) a failure before the block shape is known
+    (begin > end is refused by viso_kitti_count_frames) -> the rank leaves at once with code 9, joining nothing."""
+    import pngutil
+    home = str(tmp_path)
+    base = os.path.join(home, "sequences", "00")
+    rng = np.random.default_rng(0)
+    for side in (0, 1):
+        os.makedirs(os.path.join(base, f"image_{side}"))
+        for t in range(3):
+            pngutil.write_gray_png(os.path.join(base, f"image_{side}", "%06d.png" % t), rng.integers(0, 255, (40, 64)).astype(np.uint8))
+    with open(os.path.join(base, "calib.txt"), "w") as f:
+        f.write(f"P0: {P1}\nP1: {P2}\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(KITTI_HOME=home, PYTHONPATH=ROOT)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, "-m", "libviso_amd.kitti_shard", "x", "00", "--gpus", "2", "--backend", "gloo", "--same-device"],
+                           capture_output=True, text=True, env=env, cwd=ROOT, timeout=240)
+        assert r.returncode != 0 and "failed" in r.stderr, r.stdout + r.stderr
+        assert not os.path.exists(os.path.join(home, "results", "00", "x", "data", "00.txt"))
+    r = subprocess.run([sys.executable, "-m", "libviso_amd.kitti_shard", "x", "00", "5", "3", "--gpus", "1", "--backend", "gloo", "--force-collective"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=240)
+    assert r.returncode == 9 and "bad argument" in r.stderr, r.stdout + r.stderr
+
+
+def test_a_group_of_one_goes_through_the_collective(host, tmp_path):
+    """--force-collective at W = 1 (gloo here, RCCL in tests/test_gpu_kitti_shard.py): the records come back from a real
+    all_gather and are what the no-group path returns."""
+    import torch.distributed as dist
+    from libviso_amd import kitti_shard
+    home = str(tmp_path)
+    _tree(home, "09", 9, begin=4)
+    n0, full0, out0 = kitti_shard.run_rank(home, "plain", "09", 4, 2**31 - 1, 0, 1, host, _fake_engine())
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        n1, full1, out1 = kitti_shard.run_rank(home, "group", "09", 4, 2**31 - 1, 0, 1, host, _fake_engine(), dist)
+    finally:
+        dist.destroy_process_group()
+    assert n0 == n1 and np.array_equal(full0, full1) and open(out0, "rb").read() == open(out1, "rb").read()
+
+
+def test_reference_pose_list(host, tmp_path):
+    """`Mat pose = poses.back(); pose = pose*tr_mat.inv(); poses.push_back(pose.clone());`
+    (reference src/viso.cpp:1317-1321) overwrites poses.back() before pushing, so the reference's file is
+    [P1, ..., Pn, Pn]; the default here stays [I, P1, ..., Pn].  Both against hostmath.chain_poses, through the Python
+    writer and through `viso_kitti --gather --reference-pose-list`."""
+    from libviso_amd import hostmath, kitti_shard
+    rec = np.array([_fake_record(t) for t in range(1, 30)])
+    for quirk in (False, True):
+        out = str(tmp_path / f"p{int(quirk)}.txt")
+        n = kitti_shard.write_poses(host, out, rec, reference_pose_list=quirk)
+        poses, _ = hostmath.chain_poses(rec[:, :6], rec[:, 6], aliasing_quirk=quirk)
+        got = np.loadtxt(out).reshape(-1, 12)
+        assert n == len(poses) == len(got)
+        assert np.abs(got - np.array([p[:3].reshape(-1) for p in poses])).max() < 2e-6
+    a, b = np.loadtxt(str(tmp_path / "p0.txt")), np.loadtxt(str(tmp_path / "p1.txt"))
+    assert np.array_equal(a[1:], b[:-1]) and np.array_equal(b[-1], b[-2]) and not np.array_equal(a[0], b[0])
+    home = str(tmp_path)
+    _tree(home, "07", 30)
+    for r, (f0, f1) in enumerate(kitti_shard.partition(30, 2)):
+        _write_rank_file(os.path.join(home, "results", "07", "x", "shards", f"07.{r}of2.rec"), f0, f1, [_fake_record(t) for t in range(f0 + 1, f1 + 1)])
+    r = subprocess.run([EXE, "x", "07", "--gather", "2", "--reference-pose-list"], capture_output=True, text=True,
+                       env=dict(os.environ, KITTI_HOME=home), timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.loadtxt(os.path.join(home, "results", "07", "x", "data", "07.txt")), b)
