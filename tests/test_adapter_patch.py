@@ -95,9 +95,11 @@ def test_with_the_macro_the_hot_path_comes_from_the_adapter(patched):
     assert pos(r"^struct MatchParams")[0] < inc[0] and pos(r"^kp2mat\(const KeyPoints& kp\)")[0] < inc[0]
     # the call sites are the reference's own, unchanged (5-argument match_desc needs the adapter's default argument)
     assert sum("match_desc(kp1,kp1_prev,d1,d1_prev,match11);" in ln for ln in lines) == 1
-    assert sum("param.frame_index = iter_num;" in ln for ln in lines) == 1
+    # RANSAC stream key = the frame's FILE NUMBER (what viso_kitti / kitti_shard key on), read off the generator
+    assert sum("param.frame_index = images.index() - 1;" in ln for ln in lines) == 1
     h = view(_read(patched, "src/viso.h"), defined=True)
     assert "unsigned long long ransac_seed = 0, frame_index = 0;" in h
+    assert "int index() const { return m_index; }" in h
     assert "VISO_USE_HIP" in _read(patched, "src/CMakeLists.txt")
 
 

@@ -74,7 +74,8 @@ def patched_viso_cpp(text):
     it = [i for i in it if so[0] < i < function_end(L, so[0])]                            # :1207 (not calibratedSFM's :1350)
     if len(it) != 1:
         raise SystemExit("sequence_odometry loop head not found")
-    L[it[0]] += "#ifdef VISO_USE_HIP\n        param.frame_index = iter_num; /* RANSAC stream key of this frame */\n#endif\n"
+    L[it[0]] += ("#ifdef VISO_USE_HIP\n        param.frame_index = images.index() - 1; /* RANSAC stream key of this frame: its file number (begin + iter_num) */\n"
+                 "#endif\n")
     guard(L, r"^ransac_minimize_reproj\(const Mat& X, /\* 3d points \*/")                 # :1543-1580
     guard(L, r"^minimize_reproj\(const Mat& X, const Mat& observe, vector<double>& tr,")  # :1583-1623
     return "".join(L)
@@ -87,6 +88,12 @@ def patched_viso_h(text):
         raise SystemExit("struct param not found")
     L[i[0]] += ("#ifdef VISO_USE_HIP\n    /* deterministic replacement for randomsample's random_device: stream key of the RANSAC triples */\n"
                 "    unsigned long long ransac_seed = 0, frame_index = 0;\n#endif\n")
+    # the generator's file index, so that the stream key can be the ABSOLUTE frame number (what viso_kitti keys on)
+    c = [k for k, ln in enumerate(L) if re.match(r"^class StereoImageGenerator\s*$", ln)]
+    if len(c) != 1:
+        raise SystemExit("class StereoImageGenerator not found")
+    pr = [k for k in range(c[0], len(L)) if re.match(r"^private:", L[k])]
+    L[pr[0]] = ("#ifdef VISO_USE_HIP\n    int index() const { return m_index; } /* file number of the NEXT frame */\n#endif\n" + L[pr[0]])
     return "".join(L)
 
 
