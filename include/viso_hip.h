@@ -159,6 +159,11 @@ int viso_ransac_minimize_reproj(const double* X3xM, const double* obs4xM, int m,
                                 const viso_param* p, const int32_t* samples,
                                 uint64_t seed, uint64_t frame);
 
+/* Support sizes of n_h given motions tr_h[n_h][6] over one point set, through the RANSAC stage's counting kernel
+ * (diagnostics / tests): cnt[h] = number of inliers get_inliers (src/viso.cpp:1509-1537) finds for tr_h[h]. */
+int viso_support_sizes(const double* X3xM, const double* obs4xM, int m, const double* tr_h, int n_h,
+                       const viso_param* p, int32_t* cnt);
+
 /* Deterministic replacement for randomsample's per-call random_device
  * (src/viso.cpp:87-107): selection sampling (same algorithm) driven by a
  * splitmix64 stream keyed on (seed, frame, hypothesis).  out: iters x 3. */

@@ -293,6 +293,18 @@ def get_inliers(X, obs, tr, param):
     return inl[:n.value].copy(), rms.value
 
 
+def support_sizes(X, obs, tr_h, param):
+    """Support size of every motion tr_h[k] over (X, obs), through the RANSAC stage's counting kernel."""
+    L = load()
+    X, obs, tr_h = _f64(X), _f64(obs), _f64(np.atleast_2d(tr_h))
+    cnt = np.zeros(max(len(tr_h), 1), np.int32)
+    r = L.viso_support_sizes(ptr(X, C.c_double), ptr(obs, C.c_double), X.shape[1], ptr(tr_h, C.c_double), len(tr_h),
+                             C.byref(param), ptr(cnt, C.c_int32))
+    if r != 1:
+        _err("viso_support_sizes", r)
+    return cnt[:len(tr_h)].copy()
+
+
 def ransac_samples(seed, frame, iters, m):
     out = np.empty((iters, 3), np.int32)
     load().viso_ransac_samples(seed, frame, iters, m, ptr(out, C.c_int32))

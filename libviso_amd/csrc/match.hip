@@ -848,17 +848,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(GENERAL ? 4 : 8, 8))) __launch_bou
 // exact K-cap selection + streaming, reading the window from global memory.  ONE queue for the whole launch
 // (MatchProblem::ovf): a fixed grid of waves strides over it, so the work is shared evenly whichever problems it comes
 // from; a handful of entries for ordinary data.
-#define VISO_OVF_GRID 1024
+#define VISO_OVF_GRID 4096   // one-wave workgroups
 #define VISO_OVF_STAGE 768   // in-radius targets of one query staged in LDS (12 KB per wave); more: the window is re-walked
 
+// One wave per workgroup: the kernel has a few microseconds of work but sits on the batch's critical path behind the
+// tile kernels, usually while ANOTHER batch's tile kernel owns the GPU (7 workgroups of 4 x 72 registers and 21 KB of
+// LDS per CU, refilled the moment one leaves).  A workgroup only starts when its whole footprint is free on one CU: a
+// 4-wave workgroup with 57 KB of LDS waited for milliseconds (kernel trace), a single wave with 14 KB
+// takes the first slot any finishing tile workgroup leaves.
 template <bool GENERAL>
-__global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(MatchArgs a) {
-    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_MATCH_WAVES][VISO_QCAP];
-    __shared__ __attribute__((aligned(16))) uint4 s_stage[VISO_MATCH_WAVES][VISO_OVF_STAGE];
+__global__ __launch_bounds__(VISO_WAVE) void match_overflow_kernel(MatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint2 s_queue[VISO_QCAP];
+    __shared__ __attribute__((aligned(16))) uint4 s_stage[VISO_OVF_STAGE];
     if (GENERAL && *a.bad == 0) return;
     const int n_ovf = *a.ovf_cnt;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = (int)blockIdx.x * VISO_MATCH_WAVES + wave; k < n_ovf; k += (int)gridDim.x * VISO_MATCH_WAVES) {
+    const int lane = threadIdx.x;
+    for (int k = (int)blockIdx.x; k < n_ovf; k += (int)gridDim.x) {
         const int2 e = a.ovf_q[k];
         const MatchProblem P = a.probs[e.x];
         if (((*P.q.bad | *P.t.bad) != 0) != GENERAL) continue;   // the other instantiation's
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(VISO_MATCH_THREADS) void match_overflow_kernel(Matc
             }
         }
         QueryResult r;
-        match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue[wave], lane, a.dlen, scored, r, s_stage[wave], VISO_OVF_STAGE);
+        match_query<GENERAL, true, -1>(P, mp, j, win, kp0, has0, s_queue, lane, a.dlen, scored, r, s_stage, VISO_OVF_STAGE);
         if (lane == 0) {
             bool accept = r.idx >= 0;
             if (accept && mp.second) accept = r.bd1 < r.bd2 * mp.ratio;
@@ -941,10 +946,10 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3(VISO_OVF_GRID), dim3(VISO_MATCH_THREADS), 0, s, a);
+    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3(VISO_OVF_GRID), dim3(VISO_WAVE), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (general_possible) {
-        hipLaunchKernelGGL(match_overflow_kernel<true>, dim3(VISO_OVF_GRID), dim3(VISO_MATCH_THREADS), 0, s, a);
+        hipLaunchKernelGGL(match_overflow_kernel<true>, dim3(VISO_OVF_GRID), dim3(VISO_WAVE), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     return VISO_OK;

@@ -10,6 +10,8 @@
 // memory (check with -Rpass-analysis=kernel-resource-usage after any change).
 #include "solver_dev.h"
 
+#include <vector>
+
 struct SolverArgs {
     const SolverItem* items;
     int n_items;
@@ -273,12 +275,45 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
 // Workgroup = one frame x INL_H hypotheses.  Lanes 0..INL_H-1 build the rotations (make_rot once per hypothesis, not
 // once per lane of a wave per hypothesis) into LDS; then every thread keeps one point of the frame in registers and
 // walks the hypotheses, reading R as LDS broadcasts: ballot + popcount per wave, one LDS atomic per (wave, hypothesis).
+//
+// This is the one RANSAC kernel that is bound by arithmetic, not latency (25 600 hypotheses x ~1 200 points per 512
+// frame pairs: 43 M fp64 wave-instructions = 80 us of the whole GPU's fp64 issue), and the GPU it shares is saturated by
+// the matcher's vector work.  The verdict "err2 < inlier_threshold^2" is therefore taken in three tiers, the same
+// verdicts bit for bit:
+//   1. fp32 (full-rate FMAs, ~50 instructions) with a rigorous bound of its own error (below): decides every point
+//      whose err2 is further from the threshold than that bound (~0.5 % of the threshold for KITTI-like numbers);
+//   2. fp64 with one refined reciprocal of Z and its error band (is_inlier_pt);
+//   3. the reference's expression with its three divisions.
+// Tier-1 error bound, u = 2^-24.  Inputs rounded to float: relative error u each.  |R_ij| <= 1, so every camera
+// coordinate (three nested FMAs over products of rounded inputs) is off by at most D = 8u (|X|+|Y|+|Z| + T), T = the
+// largest |t_i| of the workgroup's hypotheses; and |Xc|, |Yc|, |Xc - base| <= N = |X|+|Y|+|Z| + T + base + D.  With
+// z = 1 / |Zc| and D z <= 1/64, g = f / Zc (v_rcp_f32: 1 ulp) has relative error <= 1.1 D z + 4u, so a projection
+// g * n + c is off by at most |g| (D + 1.2 N (1.1 D z + 4u)) + u (|c| + |p|) = |g| (c1 + c2 z) + u (|c| + |p|) with
+// c1 = D + 4.8 u N, c2 = 1.32 D N, and a residual e = o - p by that + u (|o| + |e|).  Summed over the four residuals
+// (|p_k| <= |o_k| + |e_k|): every residual is off by at most de = |g| (c1 + c2 z) + u (Cm + 2 sum|e|), Cm = |cu| + |cv| +
+// 2 sum|o|, and err2 = sum e^2 by at most de (2 sum|e| + 4 de) + 4u err2.  Added to it: what the rounding of the
+// REFERENCE's own fp64 evaluation can move its err2 (tier 2's band, generously: 2e-12 Cm^2 + 8e-12 err2).  The bound is
+// itself evaluated in float: inflated by 1/16 and an absolute 1e-30; anything not finite is "undecided".  D, N, c1, c2,
+// Cm are per point, outside the hypothesis loop: ~45 float instructions per (point, hypothesis).
 #define INL_H 10
+struct InlF32 {   // what tier 1 keeps per hypothesis in LDS (floats) next to the fp64 rotation
+    float r[12];  // R row-major, then t
+    float tmax;   // max |t_i|, rounded up
+    float pad[3];
+};
 __global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a, int groups) {
     __shared__ double s_R[INL_H][12];
+    __shared__ __attribute__((aligned(16))) InlF32 s_F[INL_H];
     __shared__ int s_ok[INL_H];
     __shared__ int s_cnt[INL_H];
-    const int item = blockIdx.x / groups, h0 = (blockIdx.x % groups) * INL_H;
+    __shared__ float s_tm;
+    const float U = 5.9604645e-8f;                       // 2^-24
+    const float ff = (float)a.sp.f, cuf = (float)a.sp.cu, cvf = (float)a.sp.cv, basef = (float)a.sp.base;
+    const float thr2f = (float)(a.sp.inlier_threshold * a.sp.inlier_threshold);
+    const float thr_lo = thr2f * (1.f - 4.f * U), thr_hi = thr2f * (1.f + 4.f * U);   // float brackets of the double threshold
+    const float cabs = fabsf(cuf) + fabsf(cvf);
+    for (int unit = blockIdx.x; unit < a.n_items * groups; unit += gridDim.x) {
+    const int item = unit / groups, h0 = (unit % groups) * INL_H;
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     const int nh = min(INL_H, a.iters - h0);
@@ -297,28 +332,72 @@ __global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a, int gro
             double* o = s_R[threadIdx.x];
             o[0] = R.r00; o[1] = R.r01; o[2] = R.r02; o[3] = R.r10; o[4] = R.r11; o[5] = R.r12;
             o[6] = R.r20; o[7] = R.r21; o[8] = R.r22; o[9] = R.tx; o[10] = R.ty; o[11] = R.tz;
+            InlF32& F = s_F[threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) F.r[j] = (float)o[j];
+            F.tmax = fmaxf(fmaxf(fabsf(F.r[9]), fabsf(F.r[10])), fabsf(F.r[11])) * (1.f + 4.f * U);
+        } else {
+            s_F[threadIdx.x].tmax = 0.f;
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {   // T: the largest |t_i| of this workgroup's hypotheses
+        float t = 0.f;
+        for (int k = 0; k < nh; ++k) t = fmaxf(t, s_F[k].tmax);
+        s_tm = t;
+    }
+    __syncthreads();
+    const float tmax_wg = s_tm;
     for (int base = 0; base < m; base += 256) {
         const int i = base + threadIdx.x;
         const bool have = i < m;
         const int ii = have ? i : 0;
         const double X0 = S.X[0 * S.ld + ii], X1 = S.X[1 * S.ld + ii], X2 = S.X[2 * S.ld + ii];
         const double o0 = S.obs[0 * S.ld + ii], o1 = S.obs[1 * S.ld + ii], o2 = S.obs[2 * S.ld + ii], o3 = S.obs[3 * S.ld + ii];
+        // tier-1 operands: the point in float, and the per-point constants of its error bound
+        const float x0 = (float)X0, x1 = (float)X1, x2 = (float)X2;
+        const float q0 = (float)o0, q1 = (float)o1, q2 = (float)o2, q3 = (float)o3;
+        const float pabs = (fabsf(x0) + fabsf(x1) + fabsf(x2)) * (1.f + 8.f * U) + tmax_wg;
+        const float D = fmaf(8.f * U, pabs, 1e-30f);
+        const float N = (pabs + basef + D) * (1.f + 8.f * U);
+        const float c1 = fmaf(4.8f * U, N, D) * 1.0625f, c2 = 1.32f * D * N * 1.0625f;
+        const float zlim = 0.015625f / D;                                   // D z <= 1/64
+        const float Cm = (cabs + 2.f * (fabsf(q0) + fabsf(q1) + fabsf(q2) + fabsf(q3))) * (1.f + 8.f * U);
+        const float k1 = U * Cm * 1.0625f, kmag = fmaf(2e-12f * Cm, Cm, 1e-30f);
         for (int k = 0; k < nh; ++k) {
             if (!s_ok[k]) continue;   // uniform
-            RotDev R;                 // only the entries predict_point reads
-            const double* r = s_R[k];
-            R.r00 = r[0]; R.r01 = r[1]; R.r02 = r[2]; R.r10 = r[3]; R.r11 = r[4]; R.r12 = r[5];
-            R.r20 = r[6]; R.r21 = r[7]; R.r22 = r[8]; R.tx = r[9]; R.ty = r[10]; R.tz = r[11];
-            const bool in = have && is_inlier_pt(R, a.sp, X0, X1, X2, o0, o1, o2, o3, nullptr);
-            const int c = __popcll(__ballot(in));
+            const InlF32& F = s_F[k];
+            const float xc = fmaf(F.r[0], x0, fmaf(F.r[1], x1, fmaf(F.r[2], x2, F.r[9])));
+            const float yc = fmaf(F.r[3], x0, fmaf(F.r[4], x1, fmaf(F.r[5], x2, F.r[10])));
+            const float zc = fmaf(F.r[6], x0, fmaf(F.r[7], x1, fmaf(F.r[8], x2, F.r[11])));
+            const float rz = __builtin_amdgcn_rcpf(zc);
+            const float g = ff * rz;
+            const float p0 = fmaf(xc, g, cuf), p1 = fmaf(yc, g, cvf), p2 = fmaf(xc - basef, g, cuf);
+            const float e0 = q0 - p0, e1 = q1 - p1, e2 = q2 - p2, e3 = q3 - p1;
+            const float s2 = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, e3 * e3)));
+            const float z = fabsf(rz);
+            const float esum2 = 2.f * (fabsf(e0) + fabsf(e1) + fabsf(e2) + fabsf(e3));
+            const float de = fmaf(fabsf(g), fmaf(c2, z, c1), fmaf(2.125f * U, esum2 * 0.5f, k1));   // 2u sum|e|, inflated
+            const float ds = fmaf(fmaf(de, fmaf(4.f, de, esum2), 5.f * U * s2), 1.0625f, kmag);
+            const bool ok1 = z <= zlim;
+            const bool sure_in = ok1 && s2 + ds < thr_lo;
+            const bool sure_out = ok1 && s2 - ds > thr_hi;
+            bool in = sure_in;
+            if (!(sure_in || sure_out)) {   // tiers 2 and 3 (also everything that is not finite)
+                RotDev R;                   // only the entries predict_point reads
+                const double* r = s_R[k];
+                R.r00 = r[0]; R.r01 = r[1]; R.r02 = r[2]; R.r10 = r[3]; R.r11 = r[4]; R.r12 = r[5];
+                R.r20 = r[6]; R.r21 = r[7]; R.r22 = r[8]; R.tx = r[9]; R.ty = r[10]; R.tz = r[11];
+                in = is_inlier_pt(R, a.sp, X0, X1, X2, o0, o1, o2, o3, nullptr);
+            }
+            const int c = __popcll(__ballot(in && have));
             if (lane == 0 && c) atomicAdd(&s_cnt[k], c);
         }
     }
     __syncthreads();
     if ((int)threadIdx.x < nh) S.cnt_h[h0 + threadIdx.x] = s_cnt[threadIdx.x];   // 0 for failed hypotheses
+    __syncthreads();   // s_R / s_ok / s_cnt are rewritten by the next unit
+    }
 }
 
 // ---- workgroup helpers ------------------------------------------------------
@@ -352,77 +431,98 @@ __device__ int block_inliers(const double* tr, const SolverParamsDev& sp, const 
     return running;
 }
 
+// A wave-uniform double into scalar registers (the compiler cannot know a value that came back from LDS or from a
+// cross-lane read is uniform): v_readfirstlane of both halves.
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // minimize_reproj over an arbitrary active list, one workgroup.  Every thread
 // accumulates its points' contribution to the 21+6 sums, the workgroup reduces
-// them (wave shuffles, then a fixed-order sum over the waves in LDS), lane 0
-// solves the 6x6 system and broadcasts the step.  tr_s: 6 doubles in LDS
-// (in/out).  red: >= 4*27+8 doubles of LDS.  Returns 1/0 to every thread.
+// them (wave shuffles, then a fixed-order sum over the waves in LDS), the first
+// wave solves the 6x6 system with ONE ENTRY PER LANE (lu_lane_step: bit-identical
+// to lu_solve6, see ransac_coop_kernel) and publishes the step.  tr_s: 6 doubles
+// in LDS (in/out).  red: >= 4*27+8 doubles of LDS.  Returns 1/0 to every thread.
+// The rotation table is wave uniform: lanes 0..2 take the three sincos, the 36
+// entries live in SCALAR registers while the points are accumulated (round 3
+// kept them, the Jacobian rows, the 27 sums and lane 0's 6x6 matrix in 254
+// vector registers: two waves per SIMD, and a workgroup that only starts where
+// half a SIMD's registers are free on all four SIMDs of a CU).
 __device__ int gn_block(const double* X, const double* obs, int ld, const int* active, int n,
                         double* tr_s, const SolverParamsDev& sp, double* red) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane >> 3, col = lane & 7;       // wave 0: this lane's entry of [A | b] (row < 6, col < 7)
     if (n <= 0) return 0;
     for (int it = 0; it < 100; ++it) {
         double tr[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
+        for (int j = 0; j < 6; ++j) tr[j] = uni(tr_s[j]);
         RotDev R;
-        make_rot(tr, R);
-        double A[6][6], B[6];
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            B[p] = 0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) A[p][q] = 0;
+        {
+            double sv, cv;
+            const int l3 = lane % 3;
+            sincos(l3 == 0 ? tr[0] : l3 == 1 ? tr[1] : tr[2], &sv, &cv);
+            const double sx = rdlane(sv, 0), cx = rdlane(cv, 0), sy = rdlane(sv, 1), cy = rdlane(cv, 1), sz = rdlane(sv, 2), cz = rdlane(cv, 2);
+            rot_from_sincos(sx, cx, sy, cy, sz, cz, tr, R);   // scalar operands in, uniform values out
+            R.r00 = uni(R.r00); R.r01 = uni(R.r01); R.r02 = uni(R.r02); R.r10 = uni(R.r10); R.r11 = uni(R.r11); R.r12 = uni(R.r12);
+            R.r20 = uni(R.r20); R.r21 = uni(R.r21); R.r22 = uni(R.r22);
+            R.rdrx10 = uni(R.rdrx10); R.rdrx11 = uni(R.rdrx11); R.rdrx12 = uni(R.rdrx12);
+            R.rdrx20 = uni(R.rdrx20); R.rdrx21 = uni(R.rdrx21); R.rdrx22 = uni(R.rdrx22);
+            R.rdry00 = uni(R.rdry00); R.rdry01 = uni(R.rdry01); R.rdry02 = uni(R.rdry02);
+            R.rdry10 = uni(R.rdry10); R.rdry11 = uni(R.rdry11); R.rdry12 = uni(R.rdry12);
+            R.rdry20 = uni(R.rdry20); R.rdry21 = uni(R.rdry21); R.rdry22 = uni(R.rdry22);
+            R.rdrz00 = uni(R.rdrz00); R.rdrz01 = uni(R.rdrz01); R.rdrz10 = uni(R.rdrz10); R.rdrz11 = uni(R.rdrz11);
+            R.rdrz20 = uni(R.rdrz20); R.rdrz21 = uni(R.rdrz21);
         }
+        double S[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) S[k] = 0;
         for (int i = threadIdx.x; i < n; i += REFIT_THREADS)
-            accumulate_point(R, sp, X, obs, ld, active[i], i, A, B);
+            accumulate_point_rows(R, sp, X, obs, ld, active[i], i, S);
         // wave reduction of the 27 sums
-        int c = 0;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-#pragma unroll
-            for (int q = p; q < 6; ++q) {
-                double v = A[p][q];
-#pragma unroll
-                for (int mk = 32; mk >= 1; mk >>= 1) v += __shfl_xor(v, mk);
-                if (lane == 0) red[wave * 27 + c] = v;
-                ++c;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            double v = B[p];
+        for (int k = 0; k < 27; ++k) {
+            double v = S[k];
 #pragma unroll
             for (int mk = 32; mk >= 1; mk >>= 1) v += __shfl_xor(v, mk);
-            if (lane == 0) red[wave * 27 + 21 + p] = v;
+            if (lane == 0) red[wave * 27 + k] = v;
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four chains in flight, not 27: registers
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double S[27];
+        if (wave == 0) {
+            // entry (row, col) of the augmented system [J^T J | J^T r]: the sum of upper-triangle slot (min, max), or of
+            // slot 21 + row for the right-hand side; lanes outside the 6 x 7 grid carry a copy of a valid entry
+            const int r6 = min(row, 5), c7 = min(col, 6);
+            const int lo = min(r6, c7), hi = max(r6, c7);
+            const int k = c7 == 6 ? 21 + r6 : lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+            double acc = ((red[k] + red[27 + k]) + red[54 + k]) + red[81 + k];
+            bool regular = lu_lane_step<0>(acc, lane, row, col);              // cv::solve(DECOMP_LU), :1602-1606
+            regular = regular && lu_lane_step<1>(acc, lane, row, col);
+            regular = regular && lu_lane_step<2>(acc, lane, row, col);
+            regular = regular && lu_lane_step<3>(acc, lane, row, col);
+            regular = regular && lu_lane_step<4>(acc, lane, row, col);
+            regular = regular && lu_lane_step<5>(acc, lane, row, col);
+            int status = 2;   // 0 = continue, 1 = converged, 2 = singular
+            if (regular) {
+                double Bs[6];
 #pragma unroll
-            for (int k = 0; k < 27; ++k) S[k] = ((red[k] + red[27 + k]) + red[54 + k]) + red[81 + k];
-            int cc = 0;
+                for (int i = 5; i >= 0; --i) {
+                    double sacc = rdlane(acc, i * 8 + 6);
 #pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int q = p; q < 6; ++q) A[p][q] = S[cc++];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) B[p] = S[21 + p];
-            symmetrize(A);
-            int status;   // 0 = continue, 1 = converged, 2 = singular
-            if (!lu_solve6(A, B)) status = 2;
-            else {
+                    for (int cc = i + 1; cc < 6; ++cc) sacc -= rdlane(acc, i * 8 + cc) * Bs[cc];
+                    Bs[i] = sacc * rdlane(acc, i * 8 + i);
+                }
                 bool converged = true;
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
-                    if (B[j] > sp.thresh) converged = false;
+                    if (Bs[j] > sp.thresh) converged = false;                 // Q7, :1610
                 status = converged ? 1 : 0;
-                if (!converged) {
+                if (!converged && lane == 0) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) tr_s[j] = tr[j] + B[j];
+                    for (int j = 0; j < 6; ++j) tr_s[j] = tr[j] + Bs[j];
                 }
             }
-            reinterpret_cast<int*>(red + 4 * 27)[0] = status;
+            if (lane == 0) reinterpret_cast<int*>(red + 4 * 27)[0] = status;
         }
         __syncthreads();
         const int status = reinterpret_cast<int*>(red + 4 * 27)[0];
@@ -434,13 +534,7 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
 }
 
 // ---- stage 3: best hypothesis -> support set -> refit -> final support ------
-__global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs a) {
-    __shared__ double tr_s[6];
-    __shared__ double red[4 * 27 + 8];
-    __shared__ int scratch[8];
-    const int item = blockIdx.x;
-    if (item >= a.n_items) return;
-    __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
+__device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* red, int* scratch) {
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
@@ -483,6 +577,19 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
         for (int j = 0; j < 6; ++j) S.tr[j] = tr_s[j];
         *S.ok = ok;
         *S.n_inl = n;
+    }
+}
+
+// Grid-stride over the frames (the launch gives every frame its own workgroup; thinner grids that last longer were
+// measured and lose: the chain's latency then limits the batches in flight).
+__global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs a) {
+    __shared__ double tr_s[6];
+    __shared__ double red[4 * 27 + 8];
+    __shared__ int scratch[8];
+    __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        refit_item(a, item, tr_s, red, scratch);
+        __syncthreads();
     }
 }
 
@@ -631,6 +738,44 @@ extern "C" int viso_get_inliers(const double* X, const double* obs, int m, const
     if (n > 0) HIP_TRY(hipMemcpy(inliers, dinl, sizeof(int) * n, hipMemcpyDeviceToHost));
     *n_inliers = n;
     if (rms) *rms = rmsv;
+    return VISO_OK;
+}
+
+// Support sizes of given motions (diagnostics / tests): inlier_count_kernel, the RANSAC stage's counting kernel, on n_h
+// motions tr_h[n_h][6] over one point set -- cnt[h] must equal the length of get_inliers(X, obs, tr_h[h]) (:1509-1537).
+extern "C" int viso_support_sizes(const double* X, const double* obs, int m, const double* tr_h, int n_h,
+                                  const viso_param* p, int32_t* cnt) {
+    if (!X || !obs || !tr_h || !p || !cnt || m < 0 || n_h < 0) { viso_set_error("viso_support_sizes: bad argument"); return VISO_ERR_ARG; }
+    if (n_h == 0) return VISO_OK;
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    double *dX, *dobs, *dtrh; int *dmisc; SolverItem* ditem;
+    int r;
+    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * (size_t)(m + 1), (void**)&dX)) < 0) return r;
+    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * (size_t)(m + 1), (void**)&dobs)) < 0) return r;
+    if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)n_h), (void**)&dmisc)) < 0) return r;
+    if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)n_h, (void**)&dtrh)) < 0) return r;
+    if ((r = ctx_scratch(c, 6, sizeof(SolverItem), (void**)&ditem)) < 0) return r;
+    std::vector<int> hm(4 + 2 * (size_t)n_h, 1);   // m, -, -, -, ok_h = 1 ..., cnt_h
+    hm[0] = m;
+    if (m > 0) {
+        HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dtrh, tr_h, sizeof(double) * 6 * n_h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dmisc, hm.data(), sizeof(int) * hm.size(), hipMemcpyHostToDevice, c->stream));
+    SolverItem it{};
+    it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + n_h;
+    HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    SolverArgs a{};
+    a.items = ditem; a.n_items = 1; a.iters = n_h;
+    fill_solver_params(&a.sp, p);
+    const int groups = (n_h + INL_H - 1) / INL_H;
+    hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)groups), dim3(256), 0, c->stream, a, groups);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(cnt, dmisc + 4 + n_h, sizeof(int) * n_h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return VISO_OK;
 }
 

@@ -63,8 +63,9 @@ __device__ __forceinline__ void predict_point(const RotDev& R, const SolverParam
 // get_inliers' test of one point (src/viso.cpp:1527-1533): sum_k (observe_k - predict_k)^2 < inlier_threshold^2, strict.
 // The reference's three divisions by Z (:1486-1489) cost ~30 fp64 instructions each here.  The verdict only needs them
 // when the sum is within rounding distance of the threshold: first the sum with ONE reciprocal of Z (refined to < 1 ulp)
-// and its error bound — every prediction is then off by < 4 ulps of its magnitude, the sum by far less than
-// 1e-12 (S + 1), S = sum_k (|observe_k| + |predict_k|)^2 —, and only a sum inside that band (or not a number) is decided
+// and its error bound — f X rz is off by < 4 ulps of ITS magnitude (<= |predict| + |c|, c the principal point: the sum
+// cancels near the image origin), the sum of squares by far less than 1e-12 (S + 1), S = sum_k (|observe_k| + |predict_k|
+// + |c_k|)^2 —, and only a sum inside that band (or not a number) is decided
 // by the reference's own expression.  Same verdicts, bit for bit; err2_out (the Q8 rms, :1535) always takes the exact path.
 __device__ __forceinline__ bool is_inlier_pt(const RotDev& R, const SolverParamsDev& sp, double X0, double X1, double X2,
                                              double o0, double o1, double o2, double o3, double* err2_out) {
@@ -79,7 +80,10 @@ __device__ __forceinline__ bool is_inlier_pt(const RotDev& R, const SolverParams
         const double p0 = sp.f * X1c * rz + sp.cu, p1 = sp.f * Y1c * rz + sp.cv, p2 = sp.f * (X1c - sp.base) * rz + sp.cu;
         const double e0 = o0 - p0, e1 = o1 - p1, e2 = o2 - p2, e3 = o3 - p1;
         const double approx = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-        const double a0 = fabs(o0) + fabs(p0), a1 = fabs(o1) + fabs(p1), a2 = fabs(o2) + fabs(p2), a3 = fabs(o3) + fabs(p1);
+        // |cu|, |cv|: p = f X rz + c cancels when the projection lies near the image origin, and the rounding of
+        // f X rz is relative to ITS magnitude (<= |p| + |c|), not to |p|
+        const double acu = fabs(sp.cu), acv = fabs(sp.cv);
+        const double a0 = fabs(o0) + fabs(p0) + acu, a1 = fabs(o1) + fabs(p1) + acv, a2 = fabs(o2) + fabs(p2) + acu, a3 = fabs(o3) + fabs(p1) + acv;
         const double band = 1e-12 * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + 1.0);
         if (approx < thr2 - band) return true;         // any NaN / inf makes both tests false: the exact path decides
         if (approx > thr2 + band) return false;
@@ -156,6 +160,50 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
             B[p] += Jr[jr][p] * res[r];
         }
     }
+}
+
+// The same sums for the all-inlier refit (gn_block), arranged for fewer live registers: the 21 + 6 sums as one flat
+// array S (upper triangle row by row, then J^T r), ONE Jacobian row alive at a time, rows in the order u_left, u_right,
+// v_left, v_right so that the row the two v observations share (src/viso.cpp:1479,1481) is built once and used twice.
+// Every product and every Jacobian entry is the expression accumulate_point evaluates; only the order in which a
+// point's four rows enter a sum differs (the refit's sums go through a workgroup reduction tree anyway: this path is
+// compared with the CPU within the 1e-5 pose tolerance, not bit for bit — the 3-point hypotheses keep accumulate_point).
+__device__ __forceinline__ void accumulate_point_rows(const RotDev& R, const SolverParamsDev& sp,
+                                                      const double* X, const double* obs, int ld,
+                                                      int a, int pos, double (&S)[27]) {
+    const double X1p = X[0 * ld + a], Y1p = X[1 * ld + a], Z1p = X[2 * ld + a];
+    double pred[4], X1c, Y1c, Z1c, X2c;
+    predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
+    const double weight = 1.0 / (fabs(obs[0 * ld + pos] - sp.cu) / fabs(sp.cu) + 0.05);   // Q6: position, not index
+    const double wf = weight * sp.f, zz = Z1c * Z1c;
+    const double res0 = weight * (obs[0 * ld + a] - pred[0]), res1 = weight * (obs[1 * ld + a] - pred[1]);
+    const double res2 = weight * (obs[2 * ld + a] - pred[2]), res3 = weight * (obs[3 * ld + a] - pred[3]);
+    // d(X1c, Y1c, Z1c) / d(rx, ry, rz, tx, ty, tz), the switch of accumulate_point
+    const double Xd[6] = {0.0, R.rdry00 * X1p + R.rdry01 * Y1p + R.rdry02 * Z1p, R.rdrz00 * X1p + R.rdrz01 * Y1p, 1.0, 0.0, 0.0};
+    const double Yd[6] = {R.rdrx10 * X1p + R.rdrx11 * Y1p + R.rdrx12 * Z1p, R.rdry10 * X1p + R.rdry11 * Y1p + R.rdry12 * Z1p,
+                          R.rdrz10 * X1p + R.rdrz11 * Y1p, 0.0, 1.0, 0.0};
+    const double Zd[6] = {R.rdrx20 * X1p + R.rdrx21 * Y1p + R.rdrx22 * Z1p, R.rdry20 * X1p + R.rdry21 * Y1p + R.rdry22 * Z1p,
+                          R.rdrz20 * X1p + R.rdrz21 * Y1p, 0.0, 0.0, 1.0};
+    double J[6];
+    auto add_row = [&](double res) {
+        int c = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+            for (int q = p; q < 6; ++q) S[c++] += J[p] * J[q];
+            S[21 + p] += J[p] * res;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) J[j] = wf * (Xd[j] * Z1c - X1c * Zd[j]) / zz;   // u_left, :1478
+    add_row(res0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) J[j] = wf * (Xd[j] * Z1c - X2c * Zd[j]) / zz;   // u_right, :1480
+    add_row(res2);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) J[j] = wf * (Yd[j] * Z1c - Y1c * Zd[j]) / zz;   // v_left = v_right, :1479,1481
+    add_row(res1);
+    add_row(res3);
 }
 
 // cv::solve(A, b, x, DECOMP_LU) for 6x6 (OpenCV 3.0 LUImpl: first strict

@@ -92,6 +92,74 @@ def test_get_inliers_at_the_threshold(viso, oracle):
     assert ok0 == ok1 and np.array_equal(in0, in1)
 
 
+def _grazing_case(param, m=4000, seed=8):
+    """Points whose err2 at tr = 0 is exactly thr^2, one ulp below, one ulp above (the construction of the test above)."""
+    X, obs, _, _ = synth.make_solver_case(4, m=m, outlier_frac=0.0, noise=0.0)
+    f, cu, cv, base = param.f, param.cu, param.cv, param.base
+    pred = np.stack([f * X[0] / X[2] + cu, f * X[1] / X[2] + cv, f * (X[0] - base) / X[2] + cu, f * X[1] / X[2] + cv])
+    thr2 = param.inlier_threshold * param.inlier_threshold
+    targets = [np.nextafter(thr2, 0.0), thr2, np.nextafter(thr2, np.inf)]
+    rng = np.random.default_rng(seed)
+    obs = pred + rng.choice([-1.0, 1.0], pred.shape)
+    ob = obs.view(np.int64)
+    hit = 0
+    for i in range(X.shape[1]):
+        k = rng.integers(-40, 41, (4, 3000))
+        o = (ob[:, i, None] + k).view(np.float64)
+        e = o - pred[:, i, None]
+        e2 = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]
+        j = np.flatnonzero(e2 == targets[i % 3])
+        if len(j):
+            obs[:, i] = o[:, j[0]]
+            hit += 1
+    assert hit > 100
+    return X, obs
+
+
+def test_support_sizes_of_the_counting_kernel_equal_get_inliers(viso, oracle):
+    """inlier_count_kernel decides err2 < thr^2 in three tiers (fp32 with a bound of its own error, fp64 with one
+    reciprocal and a band, the reference's expression): the counts must be get_inliers' (src/viso.cpp:1509-1537) for
+    every motion, on ordinary data, on points that graze the threshold to the ulp, and on numbers chosen against the
+    error bounds (a principal point far from the image centre with projections near the origin, far and near points,
+    points behind the camera, Zc ~ 0, NaN)."""
+    rng = np.random.default_rng(5)
+    X, obs, tr_gt, param = synth.make_solver_case(9, m=3000, outlier_frac=0.3, noise=0.6)
+    motions = [np.zeros(6), tr_gt]
+    for scale in (1e-6, 1e-4, 1e-3, 1e-2, 0.1, 1.0):
+        for _ in range(8):
+            motions.append(tr_gt + rng.normal(0, scale, 6) * np.array([0.05, 0.05, 0.05, 1, 1, 1]))
+    motions = np.array(motions)
+    want = np.array([len(oracle.get_inliers(X, obs, t, param)[0]) for t in motions])
+    got = libviso_amd.support_sizes(X, obs, motions, param)
+    assert np.array_equal(got, want), (got - want)
+    assert want.max() > 1500 and want.min() < 100            # good and bad motions both present
+    # grazing points: thr^2 exactly, one ulp either side, at tr = 0 (sin 0 / cos 0 exact on both sides)
+    Xg, og = _grazing_case(param)
+    small = np.array([np.zeros(6)] + [rng.normal(0, 1e-9, 6) for _ in range(9)])
+    want = np.array([len(oracle.get_inliers(Xg, og, t, param)[0]) for t in small])
+    assert np.array_equal(libviso_amd.support_sizes(Xg, og, small, param), want)
+    # numbers chosen against the bounds
+    from libviso_amd.abi import Param
+    hard = Param.default(base=0.54, f=2500.0, cu=5000.0, cv=4000.0)
+    m = 2048
+    Z = np.concatenate([rng.uniform(0.05, 2.0, 512), rng.uniform(2, 80, 1024), rng.uniform(80, 1e4, 384), -rng.uniform(1, 50, 128)])
+    u = rng.uniform(-20, 20, m); v = rng.uniform(-20, 20, m)          # projections near the image ORIGIN: p = f X / Z + c cancels
+    Xh = np.stack([(u - hard.cu) * Z / hard.f, (v - hard.cv) * Z / hard.f, Z])
+    Xh[2, :8] = rng.normal(0, 1e-9, 8)                                # Zc ~ 0
+    Xh[0, 8] = np.nan
+    tr_h = np.array([np.zeros(6)] + [np.r_[rng.normal(0, 0.01, 3), rng.normal(0, 0.3, 3)] for _ in range(29)])
+    p0 = np.stack([hard.f * Xh[0] / Xh[2] + hard.cu, hard.f * Xh[1] / Xh[2] + hard.cv,
+                   hard.f * (Xh[0] - hard.base) / Xh[2] + hard.cu, hard.f * Xh[1] / Xh[2] + hard.cv])
+    with np.errstate(all="ignore"):
+        oh = p0 + rng.normal(0, 1.0, p0.shape) * rng.choice([0.1, 1.0, 1.0000001, 3.0], (1, m))
+    oh[:, 8:16] = np.where(np.isfinite(oh[:, 8:16]), oh[:, 8:16], 0.0)
+    oh = np.where(np.isfinite(oh), oh, 1e30)
+    want = np.array([len(oracle.get_inliers(Xh, oh, t, hard)[0]) for t in tr_h])
+    got = libviso_amd.support_sizes(Xh, oh, tr_h, hard)
+    assert np.array_equal(got, want), (got - want)
+    assert want.max() > 200
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_first_gn_step_at_the_convergence_threshold(viso, oracle, seed):
     """src/viso.cpp:1610 (Q7): "converged" iff no component of the step exceeds thresh.  thresh is set to the largest
