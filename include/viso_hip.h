@@ -184,7 +184,9 @@ void viso_F_from_P(const double P1[12], const double P2[12], double F[9]);
 int viso_extract_descriptors(const uint8_t* img, int rows, int cols,
                              const float* kp, int n, int radius, float* desc);
 
-/* cv::cornerHarris(img, R, 3, 5, k, BORDER_DEFAULT) restated; resp: rows x cols float. */
+/* cv::cornerHarris(img, R, 3, 5, k, BORDER_DEFAULT) restated in OpenCV's evaluation order (scale folded into the float
+ * smoothing taps, row pass then column pass with the symmetric grouping, box filter as row sums then column sums; what
+ * an algorithm-level restatement cannot pin is listed in oracle/viso_oracle.c); resp: rows x cols float. */
 int viso_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp);
 /* HarrisBinnedFeatureDetector::detectImpl, src/viso.cpp:926-975 (reference defaults:
  * n_features 1200, nbinx 24, nbiny 5).  kp: up to n_features x 2 (x,y);
@@ -264,7 +266,9 @@ int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t*
                                    const float* kp, const int32_t* n);
 /* HarrisBinnedFeatureDetector::detectImpl (src/viso.cpp:926-975) on every
  * uploaded image (pass kp = n = NULL to viso_batch_upload_images): fills the
- * batch's keypoints on the device.  cv::cornerHarris(blockSize 3, ksize 5, k)
+ * batch's keypoints on the device, one workgroup per (image, bin), without a response image in memory (bins up to
+ * 62 pixels wide with up to 32 corners each; larger ones take a response image + a selection kernel).
+ * cv::cornerHarris(blockSize 3, ksize 5, k)
  * restated; the reference leaves k uninitialised (:915-919,978) — its intended
  * default is 0.04f — and the order inside a bin unspecified (:963); here:
  * (|response| desc, push order asc).  n_features/(nbinx*nbiny) corners per bin. */

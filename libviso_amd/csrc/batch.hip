@@ -560,7 +560,8 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
     int r0;
     if ((r0 = enter(b)) < 0) return r0;
     hipStream_t s = b->ctx->stream;
-    if (!b->h_resp) HIP_TRY(hipMalloc((void**)&b->h_resp, sizeof(float) * (size_t)n_img * b->img_rows * b->img_cols));
+    const bool fused = harris_fused_lds(b->img_rows, b->img_cols, nbinx, nbiny, per) != 0;   // no response image then
+    if (!fused && !b->h_resp) HIP_TRY(hipMalloc((void**)&b->h_resp, sizeof(float) * (size_t)n_img * b->img_rows * b->img_cols));
     const size_t slots = (size_t)nbins * (per > 0 ? per : 1);
     if (slots > b->h_slots) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -574,8 +575,11 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
         b->h_slots = slots;
     }
     int r;
-    if ((r = launch_harris_response(s, b->images, n_img, b->img_rows, b->img_cols, k, b->h_resp)) < 0) return r;
     if (per == 0) { HIP_TRY(hipMemsetAsync(b->n, 0, sizeof(int) * (size_t)n_img, s)); return VISO_OK; }
+    if (fused)
+        return launch_harris_detect(s, b->images, n_img, b->img_rows, b->img_cols, n_features, nbinx, nbiny, k, b->h_tmp_kp,
+                                    b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap);
+    if ((r = launch_harris_response(s, b->images, n_img, b->img_rows, b->img_cols, k, b->h_resp)) < 0) return r;
     return launch_harris_bins(s, b->h_resp, n_img, b->img_rows, b->img_cols, n_features, nbinx, nbiny, b->h_tmp_kp,
                               b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap);
 }

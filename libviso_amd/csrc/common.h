@@ -190,6 +190,10 @@ int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols, int with_sums);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
+size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per);
+int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,
+                         int nbiny, double k, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
+                         int* n_out, int cap, size_t kp_stride);
 int launch_harris_bins(hipStream_t s, const float* resp, int n_img, int rows, int cols, int n_features, int nbinx,
                        int nbiny, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
                        int* n_out, int cap, size_t kp_stride);

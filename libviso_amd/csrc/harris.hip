@@ -5,16 +5,31 @@
 // (src/viso.cpp:915-919,978) and leaves the order inside a bin to
 // std::nth_element (:963); here k is an explicit argument and a bin's corners
 // are ordered by (|response| desc, push order asc).  Arithmetic contract (shared
-// with the oracle): exact integer 5x5 Sobel sums, dx = (float)Dx * (float)scale,
-// cov products in float, 3x3 box sums added row-major in float with
-// BORDER_REFLECT_101 on the cov image, R = (float)((double)(a*c - b*b) - k*(a+c)*(a+c)).
+// with the oracle, oracle/viso_oracle.c): cv::cornerHarris in OpenCV's evaluation
+// order — Sobel with the scale folded into the float smoothing taps, row pass then
+// column pass (symmetric grouping), cov products in float, box filter as row sums then
+// column sums with BORDER_REFLECT_101 on the cov image, R = (float)((double)(a*c - b*b)
+// - k*(a+c)*(a+c)).  OpenCV's running column sums are the one thing an algorithm-level
+// restatement cannot pin (see the oracle's header): parity with a real OpenCV is unpinned.
 #include "common.h"
 
-#define HT_X 64
-#define HT_Y 32
-#define HT_THREADS 256
-#define HT_IW (HT_X + 8)   // LDS row pitch of the uint8 tile (HT_X + 6 used)
-#define HT_CW (HT_X + 2)   // cov tile width (tile + 1 ring)
+// ---- the response of a tile, one pass, registers only ---------------------------------------------------------
+// Arithmetic contract = the oracle's restatement of cv::cornerHarris in OpenCV's evaluation order (oracle/viso_oracle.c,
+// harris_cov / oracle_harris_response): scale folded into the float smoothing taps, row pass then column pass with
+// the symmetric / anti-symmetric grouping of SymmColumnFilter, cov products in float, box filter as row sums then
+// column sums, BORDER_REFLECT_101 on the source for the Sobel passes and on the cov image for the box.
+//
+// Work decomposition.  A tile is tw <= 62 columns wide and th rows tall.  Its uint8 pixels (+ 3-pixel halo) go to LDS
+// once.  Then wave b walks DOWN band b of the tile's rows with lane = column (lane lx <-> image column tx0 - 1 + lx, so
+// the tile plus its one-column cov ring fits one wave), keeping everything a column needs in registers: a five-row
+// window of the two row-pass results (H: derivative taps, exact; G: scaled smoothing taps, the float chain), from which
+// each step yields Dx, Dy and the three cov products of one more row; the row sums of the box filter come from the
+// neighbouring lanes (two wave shifts per channel); a three-row window of those gives the box sums and the response.
+// No intermediate image (Dx, Dy, cov, row sums) ever exists in memory; per output pixel the walk costs ~75 vector
+// instructions plus 6 / rows_per_band of warm-up.
+#define HW_MAXW 62                  // tile width limit: tw + 2 ring columns = one wave
+#define HW_PITCH 72                 // LDS row pitch of the uint8 tile (tw + 6 <= 68 used)
+#define HW_THREADS 256
 
 __device__ __forceinline__ int h_reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -22,125 +37,171 @@ __device__ __forceinline__ int h_reflect101(int p, int len) {
     return p;
 }
 
-// One workgroup = one 64x32 tile of the response map.
-//   stage 1  uint8 tile + 3-pixel halo -> LDS (BORDER tiles: BORDER_REFLECT_101 per pixel)
-//   stage 2  thread = one column of the cov tile and a band of its rows: horizontal 5-tap sums (derivative and
-//            smoothing) of each image row from 5 LDS bytes, vertical 5-tap sums by a sliding register window
-//            -> Dx, Dy -> the three cov products -> LDS
-//   stage 3  thread = one output column and a strip of 8 rows: 3x3 box sums (row-major float additions, the
-//            contract shared with the oracle) over a sliding window of cov rows -> response
-// BORDER tiles (touching the image edge) take BORDER_REFLECT_101 of the cov image tap by tap.
-template <bool BORDER>
-__device__ __forceinline__ void harris_tile(const uint8_t* __restrict__ im, int rows, int cols, int tx0, int ty0,
-                                            double k, float* __restrict__ out, unsigned char (*s_img)[HT_IW],
-                                            float (*s_cov)[HT_Y + 2][HT_CW]) {
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < (HT_Y + 6) * (HT_X + 6); idx += HT_THREADS) {
-        const int ly = idx / (HT_X + 6), lx = idx - ly * (HT_X + 6);
-        int gy = ty0 - 3 + ly, gx = tx0 - 3 + lx;
-        if (BORDER) { gy = h_reflect101(gy, rows); gx = h_reflect101(gx, cols); }
-        s_img[ly][lx] = im[(size_t)gy * cols + gx];
-    }
-    __syncthreads();
-    {
-        // column lx of the cov tile = global x tx0 - 1 + lx; rows ly = global y ty0 - 1 + ly, in 3 bands
-        const int band = tid / HT_CW, lx = tid - band * HT_CW;
-        if (band < 3) {
-            const int r0 = band * 12, r1 = band == 2 ? HT_Y + 2 : r0 + 12;
-            const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
-            int hd[5], hs[5];
+// uint8 tile rows ty0-3 .. ty0+th+2, columns tx0-3 .. tx0+tw+2 -> s_img (BORDER_REFLECT_101 outside the image)
+__device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im, int rows, int cols, int tx0, int ty0,
+                                                 int tw, int th, unsigned char* s_img) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool inside = tx0 >= 3 && ty0 >= 3 && tx0 + tw + 3 <= cols && ty0 + th + 3 <= rows;
+    const int ndw = (tw + 6 + 3) / 4;                             // dwords per LDS row
+    if (tx0 >= 3 && ndw <= 16 && tx0 - 3 + 4 * ndw <= cols) {
+        // interior in x (rows may still reflect): dword loads straight from the tile's first byte (KITTI's 1241-pixel
+        // rows put that at any alignment: the hardware takes unaligned dword loads), 16 lanes per row, four rows per
+        // wave instruction, eight instructions in flight
+        const int sub = lane >> 4, dw = lane & 15;
+        for (int base = wave * 4 + sub; base < th + 6; base += 8 * 16) {
+            uint32_t v[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned char* p = &s_img[r0 + t][lx];
-                hd[t + 1] = -(int)p[0] - 2 * (int)p[1] + 2 * (int)p[3] + (int)p[4];
-                hs[t + 1] = (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
-            }
-            for (int ly = r0; ly < r1; ++ly) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { hd[t] = hd[t + 1]; hs[t] = hs[t + 1]; }
-                const unsigned char* p = &s_img[ly + 4][lx];
-                hd[4] = -(int)p[0] - 2 * (int)p[1] + 2 * (int)p[3] + (int)p[4];
-                hs[4] = (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
-                const int Dx = hd[0] + 4 * hd[1] + 6 * hd[2] + 4 * hd[3] + hd[4];
-                const int Dy = -hs[0] - 2 * hs[1] + 2 * hs[3] + hs[4];
-                const float dx = (float)Dx * scale, dy = (float)Dy * scale;
-                s_cov[0][ly][lx] = dx * dx;
-                s_cov[1][ly][lx] = dx * dy;
-                s_cov[2][ly][lx] = dy * dy;
-            }
-        }
-    }
-    __syncthreads();
-    const int ox = tid & (HT_X - 1), strip = tid >> 6;   // 4 strips of 8 rows
-    const int gx = tx0 + ox;
-    if (gx >= cols) return;
-    if (!BORDER) {
-        // cov rows oy-1, oy, oy+1 of output row oy are local rows oy, oy+1, oy+2; columns ox, ox+1, ox+2
-        float ra[3][3], rb[3][3], rc[3][3];   // [row in window][column]
-        const int oy0 = strip * 8;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                ra[r + 1][j] = s_cov[0][oy0 + r][ox + j];
-                rb[r + 1][j] = s_cov[1][oy0 + r][ox + j];
-                rc[r + 1][j] = s_cov[2][oy0 + r][ox + j];
-            }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int oy = oy0 + i, gy = ty0 + oy;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                ra[0][j] = ra[1][j]; ra[1][j] = ra[2][j]; ra[2][j] = s_cov[0][oy + 2][ox + j];
-                rb[0][j] = rb[1][j]; rb[1][j] = rb[2][j]; rb[2][j] = s_cov[1][oy + 2][ox + j];
-                rc[0][j] = rc[1][j]; rc[1][j] = rc[2][j]; rc[2][j] = s_cov[2][oy + 2][ox + j];
-            }
-            float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { a += ra[r][j]; b += rb[r][j]; c += rc[r][j]; }
-            const float t1 = a * c, t2 = b * b;
-            const float t3 = t1 - t2;
-            const float tr = a + c;
-            if (gy < rows) out[(size_t)gy * cols + gx] = (float)((double)t3 - k * (double)tr * (double)tr);
-        }
-    } else {
-        for (int i = 0; i < 8; ++i) {
-            const int oy = strip * 8 + i, gy = ty0 + oy;
-            if (gy >= rows) break;
-            float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-            for (int di = -1; di <= 1; ++di) {
-                const int ly = h_reflect101(gy + di, rows) - (ty0 - 1);
-#pragma unroll
-                for (int dj = -1; dj <= 1; ++dj) {
-                    const int lx = h_reflect101(gx + dj, cols) - (tx0 - 1);
-                    a += s_cov[0][ly][lx];
-                    b += s_cov[1][ly][lx];
-                    c += s_cov[2][ly][lx];
+            for (int u = 0; u < 8; ++u) {
+                const int ly = base + u * 16;
+                v[u] = 0;
+                if (ly < th + 6 && dw < ndw) {
+                    int gy = ty0 - 3 + ly;
+                    if (!inside) gy = h_reflect101(gy, rows);
+                    uint32_t w;
+                    __builtin_memcpy(&w, im + (size_t)gy * cols + (tx0 - 3) + 4 * dw, 4);
+                    v[u] = w;
                 }
             }
-            const float t1 = a * c, t2 = b * b;
-            const float t3 = t1 - t2;
-            const float tr = a + c;
-            out[(size_t)gy * cols + gx] = (float)((double)t3 - k * (double)tr * (double)tr);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ly = base + u * 16;
+                if (ly < th + 6 && dw < ndw) reinterpret_cast<uint32_t*>(s_img + ly * HW_PITCH)[dw] = v[u];
+            }
+        }
+        return;
+    }
+    // wave per row, lane per byte (tw + 6 <= 68: lanes 0..3 take a second byte); eight rows of loads in flight before
+    // the first LDS store (one row per round trip made the tile load the longest stage of the kernel)
+    int gx0 = tx0 - 3 + lane, gx1 = tx0 - 3 + 64 + lane;
+    if (!inside) { gx0 = h_reflect101(gx0, cols); gx1 = h_reflect101(gx1, cols); }
+    const bool second = lane + 64 < tw + 6;
+    const bool first = lane < tw + 6;
+    for (int base = wave; base < th + 6; base += 8 * (HW_THREADS / 64)) {
+        unsigned char v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ly = base + u * (HW_THREADS / 64);
+            v0[u] = 0; v1[u] = 0;
+            if (ly < th + 6) {
+                int gy = ty0 - 3 + ly;
+                if (!inside) gy = h_reflect101(gy, rows);
+                const uint8_t* row = im + (size_t)gy * cols;
+                if (first) v0[u] = row[gx0];
+                if (second) v1[u] = row[gx1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ly = base + u * (HW_THREADS / 64);
+            if (ly < th + 6) {
+                if (first) s_img[ly * HW_PITCH + lane] = v0[u];
+                if (second) s_img[ly * HW_PITCH + 64 + lane] = v1[u];
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(HT_THREADS) void harris_response_kernel(const uint8_t* __restrict__ images, int rows,
+// lane i <- lane i - 1 / lane i + 1 of the whole wave (gfx9 DPP wave_shr:1 / wave_shl:1); the end lanes get 0
+__device__ __forceinline__ float wave_shr1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// Wave `band` of the workgroup walks output rows [y0, y1) of the tile (relative to ty0); sink(y, lx - 1, R) is called
+// by the lanes that own an output column (0 <= lx - 1 < tw) for every row, in row order.
+template <class Sink>
+__device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
+                                                 int tw, int y0, int y1, double k, Sink sink) {
+    const int lx = threadIdx.x & 63;
+    const int gx = tx0 - 1 + lx;                       // this lane's cov column
+    const bool col_used = lx < tw + 2;
+    const int lxc = col_used ? lx : 0;                 // idle lanes read a valid address
+    const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
+    const float t0 = 1.f * scale, t1 = 4.f * scale, t2 = 6.f * scale;   // tap_i = fl32(s_i * fl32(scale)), symmetric
+    // a lane whose cov column lies outside the image takes the cov of the reflected column (BORDER_REFLECT_101 of the
+    // cov IMAGE, not of the source: the derivative of a mirrored image has the other sign): gx = -1 <- gx = 1, gx = cols
+    // <- gx = cols - 2 (lanes two up / two down; one for a one-column image)
+    const bool ring_tile = tx0 == 0 || tx0 + tw == cols;
+    const int ring_src = (gx == -1 || gx == cols) ? lx + (h_reflect101(gx, cols) - gx) : lx;
+    float H[5], G[5];                                  // rows q-4 .. q of the two row passes
+    float ra[3], rb[3], rc[3];                         // box row sums of cov rows r-2 .. r
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { H[i] = 0.f; G[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ra[i] = 0.f; rb[i] = 0.f; rc[i] = 0.f; }
+    for (int q = y0 - 3; q < y1 + 3; ++q) {            // row-pass row q (relative to ty0) = LDS row q + 3
+        const unsigned char* p = s_img + (q + 3) * HW_PITCH + lxc;
+        const float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2], p3 = (float)p[3], p4 = (float)p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { H[i] = H[i + 1]; G[i] = G[i + 1]; }
+        // RowFilter: k0*S0, += k1*S1, ... left to right.  Derivative taps -1,-2,0,2,1: small integers, exact in any order
+        H[4] = (p4 - p0) + 2.f * (p3 - p1);
+        float g = t0 * p0;
+        g += t1 * p1; g += t2 * p2; g += t1 * p3; g += t0 * p4;
+        G[4] = g;
+        const int r = q - 2;                           // cov row now complete (needs rows r-2 .. r+2 = q-4 .. q)
+        if (r < y0 - 1) continue;                      // uniform: still warming up
+        // SymmColumnFilter, symmetric: f0*S0 + delta, += f1*(S1 + S-1), += f2*(S2 + S-2)
+        float dx = t2 * H[2] + 0.f;
+        dx += t1 * (H[3] + H[1]);
+        dx += t0 * (H[4] + H[0]);
+        // SymmColumnFilter, anti-symmetric (taps 0, 2, 1): delta, += 2*(S1 - S-1), += 1*(S2 - S-2)
+        float dy = 0.f;
+        dy += 2.f * (G[3] - G[1]);
+        dy += 1.f * (G[4] - G[0]);
+        float ca = dx * dx, cb = dx * dy, cc = dy * dy;
+        if (ring_tile) {                               // uniform: this tile touches the left or right image edge
+            const float ua = __shfl(ca, ring_src), ub = __shfl(cb, ring_src), uc = __shfl(cc, ring_src);
+            if (ring_src != lx) { ca = ua; cb = ub; cc = uc; }
+        }
+        // box filter, row sums: (S[x-1] + S[x]) + S[x+1]; the neighbours by DPP wave shifts (one instruction each, folded
+        // into the adds by the compiler; a ds_bpermute shuffle costs four)
+        const float sa = (wave_shr1(ca) + ca) + wave_shl1(ca);
+        const float sb = (wave_shr1(cb) + cb) + wave_shl1(cb);
+        const float sc = (wave_shr1(cc) + cc) + wave_shl1(cc);
+        ra[0] = ra[1]; ra[1] = ra[2]; ra[2] = sa;
+        rb[0] = rb[1]; rb[1] = rb[2]; rb[2] = sb;
+        rc[0] = rc[1]; rc[1] = rc[2]; rc[2] = sc;
+        const int y = r - 1;                           // output row now complete (needs row sums y-1 .. y+1 = r-2 .. r)
+        if (y < y0) continue;                          // uniform
+        const int gy = ty0 + y;
+        if (gy >= rows) break;                         // uniform: rows below the image are nobody's
+        // BORDER_REFLECT_101 of the cov image in y: row -1 is row 1, row `rows` is row rows - 2
+        float ua = ra[0], ub = rb[0], uc = rc[0], da = ra[2], db = rb[2], dc = rc[2];
+        if (rows > 1) {
+            if (gy == 0) { ua = da; ub = db; uc = dc; }
+            if (gy == rows - 1) { da = ra[0]; db = rb[0]; dc = rc[0]; }
+        } else { ua = ra[1]; ub = rb[1]; uc = rc[1]; da = ra[1]; db = rb[1]; dc = rc[1]; }
+        // column sums: (rs[y-1] + rs[y]) + rs[y+1]
+        const float a = (ua + ra[1]) + da, b = (ub + rb[1]) + db, c = (uc + rc[1]) + dc;
+        const float m1 = a * c, m2 = b * b;
+        const float m3 = m1 - m2;
+        const float tr = a + c;
+        const float R = (float)((double)m3 - k * (double)tr * (double)tr);
+        if (lx >= 1 && lx <= tw && gx < cols) sink(y, lx - 1, R);
+    }
+}
+
+// ---- cv::cornerHarris as an image (plain API, and bins too large for the fused detector) -----------------------
+#define HR_TW 62
+#define HR_TH 76
+__global__ __launch_bounds__(HW_THREADS) void harris_response_kernel(const uint8_t* __restrict__ images, int rows,
                                                                      int cols, double k, float* __restrict__ resp) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_img[HT_Y + 6][HT_IW];
-    __shared__ float s_cov[3][HT_Y + 2][HT_CW];
+    __shared__ __attribute__((aligned(16))) unsigned char s_img[(HR_TH + 6) * HW_PITCH];
     const int img = blockIdx.z;
-    const int tx0 = blockIdx.x * HT_X, ty0 = blockIdx.y * HT_Y;
+    const int tx0 = blockIdx.x * HR_TW, ty0 = blockIdx.y * HR_TH;
+    const int tw = min(HR_TW, cols - tx0), th = min(HR_TH, rows - ty0);
     const uint8_t* im = images + (size_t)img * rows * cols;
     float* out = resp + (size_t)img * rows * cols;
-    // interior: the tile's 3-pixel halo (image) and 1-pixel ring (cov) lie inside the image
-    const bool interior = tx0 >= 3 && ty0 >= 3 && tx0 + HT_X + 3 <= cols && ty0 + HT_Y + 3 <= rows;
-    if (interior) harris_tile<false>(im, rows, cols, tx0, ty0, k, out, s_img, s_cov);
-    else harris_tile<true>(im, rows, cols, tx0, ty0, k, out, s_img, s_cov);
+    harris_load_tile(im, rows, cols, tx0, ty0, tw, th, s_img);
+    __syncthreads();
+    const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rb = (th + 3) / 4;   // wave uniform: scalar loop control
+    const int y0 = band * rb, y1 = min(th, y0 + rb);
+    if (y0 < y1)
+        harris_walk_band(s_img, rows, cols, tx0, ty0, tw, y0, y1, k,
+                         [&](int y, int x, float R) { out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
 }
 
 struct BinArgs {
@@ -158,162 +219,231 @@ struct BinArgs {
 // over the lanes' heads.  That is exact unless some lane's third-best key is
 // still above the last pick (a fourth could hide behind it); such bins (a few
 // percent) are redone by the exact multi-pass loop.
+// max over the wave of a u32, to every lane as a scalar: DPP row shifts inside the 16-lane rows, two row broadcasts, the
+// total lands in lane 63 (gfx9 reduction idiom; six v_max_u32_dpp + a readlane instead of six ds_bpermute round trips)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define HMAX_DPP(ctrl, rmask) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    HMAX_DPP(0x111, 0xf);   // row_shr:1
+    HMAX_DPP(0x112, 0xf);   // row_shr:2
+    HMAX_DPP(0x114, 0xf);   // row_shr:4
+    HMAX_DPP(0x118, 0xf);   // row_shr:8   -> lane 15 of every row = the row's max
+    HMAX_DPP(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    HMAX_DPP(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 = the wave's max
+#undef HMAX_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max over the wave of a u64 key (|response| bits : ~position): the high words first, then the low words of the lanes
+// that hold the maximal high word (ties of |response| are rare, the second reduction is still cheap)
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = __shfl_xor(v, m);
-        v = o > v ? o : v;
-    }
-    return v;
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_max_u32(hi);
+    const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
+#define HD_MAXPER 32  // corners per bin the fused detector merges (4 x per keys; the reference has 10)
+#define HD_LIST 128   // fallback list of a wave of the fused detector (its quarter of the bin), in the dead pixel tile
 #define HB_LIST 256   // keys >= the last optimistic pick collected by the one-walk exact path (per wave)
 
-__global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
-    __shared__ unsigned long long s_list[4][HB_LIST];
+// The `per` largest keys, descending, of the bin pixels idx = first + lane + step * i < P (idx in MEMORY order: x
+// fastest), by ONE wave.  key = (|response| bits << 32) | ~push position, push position = xo * stridey + yo (the
+// reference pushes x outer, y inner, :953-955): larger is better, ties of |response| go to the earlier push, keys are
+// unique.  fetch(xo, yo) = |response| (0 where the bin reaches past the image; zeros are skipped like the reference's
+// isEqual(response, 0) test).  emit(n, key) is called with wave-uniform arguments for the n-th best key.  Returns the
+// count.  `list`: LIST keys of LDS scratch of this wave.
+// Fast path: ONE pass in which every lane keeps its three largest keys, then `per` rounds of wave-max over the lanes'
+// heads.  That is exact unless some lane's third-best key is still above the last pick (a fourth could hide behind
+// it); such subsets (a few percent) collect all keys >= the last optimistic pick in one more walk and select among
+// them, with the pick-by-pick multi-pass loop as the last resort.
+__device__ __forceinline__ unsigned long long harris_key(float v, int pos) {
+    if (fabsf(v - 0.f) <= 1e-6f * fabsf(v)) return 0ull;   // isEqual(response, .0f), src/misc.cpp:10-14
+    return ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
+}
+
+template <int LIST, class Fetch, class Emit>
+__device__ __forceinline__ int harris_top_keys(int stridex, int stridey, int P, int per, int first, int step,
+                                               Fetch fetch, Emit emit, unsigned long long* list) {
     const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nbins = a.nbinx * a.nbiny;
-    if (wave >= (long long)a.n_img * nbins) return;
-    const int img = (int)(wave / nbins), bin = (int)(wave % nbins);
-    const int bx = bin / a.nbiny, by = bin % a.nbiny;      // bins in (binx outer, biny inner) order, :949-951
-    const int x0 = bx * a.stridex, y0 = by * a.stridey;
-    const int P = a.stridex * a.stridey;
-    const float* r = a.resp + (size_t)img * a.rows * a.cols;
-    const size_t obase = ((size_t)img * nbins + bin) * a.per;
-    // ---- pass 1: per-lane top 3
-    unsigned long long k0 = 0, k1 = 0, k2 = 0;             // k0 >= k1 >= k2
-    {
-        // lanes walk the bin in MEMORY order (x fastest: coalesced rows); the key carries the
-        // reference's push position pos = xo * stridey + yo (x outer, y inner, :953-955).
-        // Four independent loads per step: the walk is latency bound (60 steps per bin otherwise).
-        int yo = lane / a.stridex, xo = lane % a.stridex;
-        for (int idx = lane; idx < P; idx += 4 * 64) {
+    const int sq = step / stridex, sr = step % stridex;    // idx += step  <=>  (xo, yo) += (sr, sq) with one carry
+    const int f0 = first + lane;
+    auto walk = [&](auto visit) {                          // visit(key) for every pixel of the subset, four loads in flight
+        int yo = f0 / stridex, xo = f0 % stridex;
+        for (int idx = f0; idx < P; idx += 4 * step) {
             float v[4];
             int pos[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int x = x0 + xo, y = y0 + yo;
-                pos[u] = xo * a.stridey + yo;
-                v[u] = 0.f;   // 0 is skipped by the isEqual test below
-                if (idx + 64 * u < P && x < a.cols && y < a.rows) v[u] = fabsf(r[(size_t)y * a.cols + x]);
-                xo += 64;
-                while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
+                pos[u] = xo * stridey + yo;
+                v[u] = idx + step * u < P ? fetch(xo, yo) : 0.f;
+                xo += sr; yo += sq;
+                if (xo >= stridex) { xo -= stridex; ++yo; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!(fabsf(v[u] - 0.f) <= 1e-6f * fabsf(v[u]))) {   // isEqual(response, .0f), src/misc.cpp:10-14
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(v[u]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos[u]);
-                    if (key > k2) {
-                        if (key > k1) { k2 = k1; if (key > k0) { k1 = k0; k0 = key; } else k1 = key; }
-                        else k2 = key;
-                    }
-                }
-            }
+            for (int u = 0; u < 4; ++u) visit(harris_key(v[u], pos[u]));
         }
-    }
+    };
+    // ---- pass 1: per-lane top 3
+    unsigned long long k0 = 0, k1 = 0, k2 = 0;             // k0 >= k1 >= k2
+    walk([&](unsigned long long key) {
+        if (key > k2) {
+            if (key > k1) { k2 = k1; if (key > k0) { k1 = k0; k0 = key; } else k1 = key; }
+            else k2 = key;
+        }
+    });
     // ---- merge: `per` rounds over the lanes' heads
     const unsigned long long third = k2;                   // what this lane might be hiding behind
     unsigned long long last = 0;
+    unsigned long long picked = 0;                         // lane n keeps the n-th pick until the verdict (per <= 64)
     int n = 0;
-    for (int round = 0; round < a.per; ++round) {
+    for (int round = 0; round < per; ++round) {
         const unsigned long long best = wave_max_u64(k0);
         if (best == 0) break;
         if (k0 == best) { k0 = k1; k1 = k2; k2 = 0; }      // keys are unique: exactly one lane pops
         last = best;
-        if (lane == 0) {
+        if (per <= 64) { if (lane == n) picked = best; } else emit(n, best);
+        ++n;
+    }
+    // exact iff no lane used up all three of its keys while more picks could lie below them
+    const bool suspicious = (n == per) ? (third > last) : (third != 0 && k0 == 0 && n < per);
+    if (!__any(suspicious)) {
+        if (per <= 64)
+            for (int i = 0; i < n; ++i) emit(i, __shfl(picked, i));
+        return n;
+    }
+    // The optimistic picks are `per` real keys of the subset, so every key of the true top `per` is >= the last
+    // optimistic pick: ONE more walk collects all keys >= last (a handful more than `per`) into LDS and the exact top
+    // `per` is selected among them.  Subsets where that does not apply (fewer than `per` picks, or an implausibly long
+    // list) take the multi-pass path below.
+    if (n == per) {
+        int cnt = 0;
+        walk([&](unsigned long long key) {
+            const bool take = key >= last;                 // last != 0 here
+            const unsigned long long m = __ballot(take);
+            const int at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (take && at < LIST) list[at] = key;
+            cnt += __popcll(m);
+        });
+        __builtin_amdgcn_wave_barrier();
+        if (cnt <= LIST) {
+            unsigned long long mine[LIST / 64];
+#pragma unroll
+            for (int u = 0; u < LIST / 64; ++u) mine[u] = (lane + 64 * u < cnt) ? list[lane + 64 * u] : 0ull;
+            n = 0;
+            for (int round = 0; round < per; ++round) {
+                unsigned long long loc = mine[0];
+#pragma unroll
+                for (int u = 1; u < LIST / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
+                const unsigned long long best = wave_max_u64(loc);
+                if (best == 0) break;
+#pragma unroll
+                for (int u = 0; u < LIST / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
+                emit(n, best);
+                ++n;
+            }
+            return n;
+        }
+    }
+    // ---- exact path: `per` rounds of "largest key below the previous pick"
+    unsigned long long prev = ~0ull;
+    n = 0;
+    for (int round = 0; round < per; ++round) {
+        unsigned long long best = 0;
+        walk([&](unsigned long long key) { if (key < prev && key > best) best = key; });
+        best = wave_max_u64(best);
+        if (best == 0) break;
+        prev = best;
+        emit(n, best);
+        ++n;
+    }
+    return n;
+}
+
+// emit of the final corners of (img, bin): key -> keypoint + |response| in the bin's slots
+struct BinEmit {
+    const BinArgs& a; size_t obase; int x0, y0;
+    __device__ __forceinline__ void operator()(int n, unsigned long long best) const {
+        if ((threadIdx.x & 63) == 0) {
             const int pos = (int)(0xffffffffu - (uint32_t)best);
             a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
             a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
         }
-        ++n;
     }
-    // exact iff no lane used up all three of its keys while more picks could lie below them
-    const bool suspicious = (n == a.per) ? (third > last) : (third != 0 && k0 == 0 && n < a.per);
-    if (__any(suspicious)) {
-        // The optimistic picks are `per` real keys of the bin, so every key of the true top `per` is >= the last
-        // optimistic pick: ONE more walk collects all keys >= last (a handful more than `per`) into LDS and the
-        // exact top `per` is selected among them.  Bins where that does not apply (fewer than `per` picks, or an
-        // implausibly long list) take the multi-pass path below.
-        bool done = false;
-        if (n == a.per) {
-            unsigned long long* list = s_list[threadIdx.x >> 6];
-            int cnt = 0;
-            int yo = lane / a.stridex, xo = lane % a.stridex;
-            for (int idx = lane; idx < P; idx += 64) {
-                const int x = x0 + xo, y = y0 + yo;
-                const int pos = xo * a.stridey + yo;
-                unsigned long long key = 0;
-                if (x < a.cols && y < a.rows) {
-                    const float v = fabsf(r[(size_t)y * a.cols + x]);
-                    if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v)))
-                        key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
-                }
-                const bool take = key >= last;   // last != 0 here
-                const unsigned long long m = __ballot(take);
-                const int at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (take && at < HB_LIST) list[at] = key;
-                cnt += __popcll(m);
-                xo += 64;
-                while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (cnt <= HB_LIST) {
-                unsigned long long mine[HB_LIST / 64];
+};
+
+// Bins from a response image in memory (bins too large for the fused detector below): one wave per (image, bin).
+__global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
+    __shared__ unsigned long long s_list[4][HB_LIST];
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nbins = a.nbinx * a.nbiny;
+    if (wave >= (long long)a.n_img * nbins) return;
+    const int img = (int)(wave / nbins), bin = (int)(wave % nbins);
+    const int x0 = (bin / a.nbiny) * a.stridex, y0 = (bin % a.nbiny) * a.stridey;
+    const float* r = a.resp + (size_t)img * a.rows * a.cols;
+    const BinEmit emit{a, ((size_t)img * nbins + bin) * a.per, x0, y0};
+    const int n = harris_top_keys<HB_LIST>(a.stridex, a.stridey, a.stridex * a.stridey, a.per, 0, 64, [&](int xo, int yo) {
+        const int x = x0 + xo, y = y0 + yo;
+        return (x < a.cols && y < a.rows) ? fabsf(r[(size_t)y * a.cols + x]) : 0.f;
+    }, emit, s_list[threadIdx.x >> 6]);
+    if ((threadIdx.x & 63) == 0) a.cnt[(size_t)img * nbins + bin] = n;
+}
+
+// The fused detector: one workgroup per (image, bin).  The bin IS the tile: its responses are computed by the band
+// walk above straight into LDS (stridex * stridey floats), and wave 0 then selects the bin's corners from there.  The
+// response image (4 bytes per pixel written and read back by the two-kernel path) never exists; per image the only
+// HBM traffic is the uint8 pixels in and the corners out.
+__global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, const uint8_t* __restrict__ images, double k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char h_smem[];
+    __shared__ unsigned long long s_cand[4 * HD_MAXPER];
+    __shared__ int s_ncand[4];
+    const int nbins = a.nbinx * a.nbiny;
+    const int img = blockIdx.x / nbins, bin = blockIdx.x % nbins;
+    const int tx0 = (bin / a.nbiny) * a.stridex, ty0 = (bin % a.nbiny) * a.stridey;
+    const int tw = a.stridex, th = a.stridey;              // bins never reach past the image: stride * nbin <= size
+    unsigned char* s_img = h_smem;
+    size_t tile_bytes = ((size_t)(th + 6) * HW_PITCH + 15) & ~(size_t)15;
+    if (tile_bytes < 4 * HD_LIST * sizeof(unsigned long long)) tile_bytes = 4 * HD_LIST * sizeof(unsigned long long);
+    float* s_resp = reinterpret_cast<float*>(h_smem + tile_bytes);
+    harris_load_tile(images + (size_t)img * a.rows * a.cols, a.rows, a.cols, tx0, ty0, tw, th, s_img);
+    __syncthreads();
+    const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rb = (th + 3) / 4;   // wave uniform: scalar loop control
+    const int y0 = band * rb, y1 = min(th, y0 + rb);
+    if (y0 < y1)
+        harris_walk_band(s_img, a.rows, a.cols, tx0, ty0, tw, y0, y1, k,
+                         [&](int y, int x, float R) { s_resp[y * tw + x] = fabsf(R); });
+    __syncthreads();
+    // selection: every wave takes the pixels idx = wave * 64 + lane (mod 256) of the bin and finds ITS `per` largest keys
+    // (all four waves busy; one wave walking the whole bin while three wait held the workgroup for twice the walk's time),
+    // then wave 0 picks the bin's `per` largest among the 4 * per survivors -- the true top `per` are among them
+    const int per = a.per;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long* cand = s_cand;                     // [4][per] (per <= HD_MAXPER)
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(s_img) + wave * HD_LIST;   // the pixels are dead by now
+    const int nw = harris_top_keys<HD_LIST>(tw, th, tw * th, per, wave * 64, HW_THREADS, [&](int xo, int yo) { return s_resp[yo * tw + xo]; },
+                                            [&](int n, unsigned long long key) { if (lane == 0) cand[wave * per + n] = key; }, list);
+    if (lane == 0) s_ncand[wave] = nw;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long mine[(4 * HD_MAXPER + 63) / 64];
 #pragma unroll
-                for (int u = 0; u < HB_LIST / 64; ++u) mine[u] = (lane + 64 * u < cnt) ? list[lane + 64 * u] : 0ull;
-                n = 0;
-                for (int round = 0; round < a.per; ++round) {
-                    unsigned long long loc = mine[0];
-#pragma unroll
-                    for (int u = 1; u < HB_LIST / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
-                    const unsigned long long best = wave_max_u64(loc);
-                    if (best == 0) break;
-#pragma unroll
-                    for (int u = 0; u < HB_LIST / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
-                    if (lane == 0) {
-                        const int pos = (int)(0xffffffffu - (uint32_t)best);
-                        a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
-                        a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
-                    }
-                    ++n;
-                }
-                done = true;
-            }
+        for (int u = 0; u < (4 * HD_MAXPER + 63) / 64; ++u) {
+            const int e = lane + 64 * u, w = e / per, i = e % per;
+            mine[u] = (e < 4 * per && i < s_ncand[w]) ? cand[e] : 0ull;
         }
-        if (!done) {
-        // ---- exact path: `per` rounds of "largest key below the previous pick"
-            unsigned long long prev = ~0ull;
-            n = 0;
-            for (int round = 0; round < a.per; ++round) {
-                unsigned long long best = 0;
-                int yo = lane / a.stridex, xo = lane % a.stridex;
-                for (int idx = lane; idx < P; idx += 64) {
-                    const int x = x0 + xo, y = y0 + yo;
-                    const int pos = xo * a.stridey + yo;
-                    if (x < a.cols && y < a.rows) {
-                        const float v = fabsf(r[(size_t)y * a.cols + x]);
-                        if (!(fabsf(v - 0.f) <= 1e-6f * fabsf(v))) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)pos);
-                            if (key < prev && key > best) best = key;
-                        }
-                    }
-                    xo += 64;
-                    while (xo >= a.stridex) { xo -= a.stridex; ++yo; }
-                }
-                best = wave_max_u64(best);
-                if (best == 0) break;
-                prev = best;
-                if (lane == 0) {
-                    const int pos = (int)(0xffffffffu - (uint32_t)best);
-                    a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
-                    a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
-                }
-                ++n;
-            }
+        const BinEmit emit{a, ((size_t)img * nbins + bin) * a.per, tx0, ty0};
+        int n = 0;
+        for (int round = 0; round < per; ++round) {
+            unsigned long long loc = mine[0];
+#pragma unroll
+            for (int u = 1; u < (4 * HD_MAXPER + 63) / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
+            const unsigned long long best = wave_max_u64(loc);
+            if (best == 0) break;
+#pragma unroll
+            for (int u = 0; u < (4 * HD_MAXPER + 63) / 64; ++u) if (mine[u] == best) mine[u] = 0;
+            emit(n, best);
+            ++n;
         }
+        if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
     }
-    if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
 }
 
 // One workgroup per image: concatenate the bins' corners in bin order.
@@ -342,13 +472,47 @@ __global__ __launch_bounds__(256) void harris_compact_kernel(BinArgs a, float2* 
 
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp) {
     if (n_img <= 0) return VISO_OK;
-    dim3 grid((cols + HT_X - 1) / HT_X, (rows + HT_Y - 1) / HT_Y, n_img);
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(HT_THREADS), 0, s, images, rows, cols, k, resp);
+    dim3 grid((cols + HR_TW - 1) / HR_TW, (rows + HR_TH - 1) / HR_TH, n_img);
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(HW_THREADS), 0, s, images, rows, cols, k, resp);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
 
 // kp_out: [n_img][kp_stride] float2, n_out: [n_img]; tmp_*: scratch sized n_img*nbins*per, cnt n_img*nbins.
+// bytes of dynamic LDS the fused detector needs for this bin geometry, or 0 when it does not apply (bins wider than a
+// wave's columns, or beyond 64 KB of responses + pixels)
+size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per) {
+    const int sx = cols / nbinx, sy = rows / nbiny;
+    if (sx <= 0 || sy <= 0 || sx > HW_MAXW || per > HD_MAXPER) return 0;
+    size_t tile = ((size_t)(sy + 6) * HW_PITCH + 15) & ~(size_t)15;
+    if (tile < 4 * HD_LIST * sizeof(unsigned long long)) tile = 4 * HD_LIST * sizeof(unsigned long long);   // the fallback lists live there
+    const size_t b = tile + sizeof(float) * (size_t)sx * sy;
+    return b <= 64 * 1024 ? b : 0;
+}
+
+// images -> corners without a response image (callers check harris_fused_lds first)
+int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,
+                         int nbiny, double k, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
+                         int* n_out, int cap, size_t kp_stride) {
+    if (n_img <= 0) return VISO_OK;
+    BinArgs a;
+    a.resp = nullptr; a.rows = rows; a.cols = cols; a.n_img = n_img;
+    a.nbinx = nbinx; a.nbiny = nbiny; a.stridex = cols / nbinx; a.stridey = rows / nbiny;
+    a.per = n_features / (nbinx * nbiny);
+    a.tmp_kp = tmp_kp; a.tmp_resp = tmp_resp; a.cnt = cnt;
+    const int nbins = nbinx * nbiny;
+    const size_t lds = harris_fused_lds(rows, cols, nbinx, nbiny, a.per);
+    if (!lds) { viso_set_error("harris: bin geometry does not fit the fused detector"); return VISO_ERR_UNSUPPORTED; }
+    if (lds > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(harris_detect_kernel, dim3((unsigned)((long long)n_img * nbins)), dim3(HW_THREADS), lds, s, a, images, k);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(harris_compact_kernel, dim3(n_img), dim3(256), sizeof(int) * (size_t)(nbins + 1), s, a, kp_out,
+                       resp_out, n_out, cap, kp_stride);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
 int launch_harris_bins(hipStream_t s, const float* resp, int n_img, int rows, int cols, int n_features, int nbinx,
                        int nbiny, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
                        int* n_out, int cap, size_t kp_stride) {
@@ -413,9 +577,14 @@ extern "C" int viso_detect_harris_binned(const uint8_t* img, int rows, int cols,
     if ((r = ctx_scratch(c, 5, sizeof(float2) * slots, (void**)&dko)) < 0) return r;
     if ((r = ctx_scratch(c, 6, sizeof(float) * slots, (void**)&dro)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(dimg, img, px, hipMemcpyHostToDevice, c->stream));
-    if ((r = launch_harris_response(c->stream, dimg, 1, rows, cols, k, dr)) < 0) return r;
-    if ((r = launch_harris_bins(c->stream, dr, 1, rows, cols, n_features, nbinx, nbiny, dtk, dtr, dcnt, dko, dro,
-                                dcnt + nbins, (int)slots, slots)) < 0) return r;
+    if (harris_fused_lds(rows, cols, nbinx, nbiny, per)) {
+        if ((r = launch_harris_detect(c->stream, dimg, 1, rows, cols, n_features, nbinx, nbiny, k, dtk, dtr, dcnt, dko, dro,
+                                      dcnt + nbins, (int)slots, slots)) < 0) return r;
+    } else {
+        if ((r = launch_harris_response(c->stream, dimg, 1, rows, cols, k, dr)) < 0) return r;
+        if ((r = launch_harris_bins(c->stream, dr, 1, rows, cols, n_features, nbinx, nbiny, dtk, dtr, dcnt, dko, dro,
+                                    dcnt + nbins, (int)slots, slots)) < 0) return r;
+    }
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, dcnt + nbins, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

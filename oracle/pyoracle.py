@@ -47,6 +47,8 @@ def lib():
         L.oracle_lu_solve6.argtypes = [f64p, f64p]
         L.oracle_harris_response.restype = C.c_int
         L.oracle_harris_response.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
+        L.oracle_harris_response_v1.restype = C.c_int
+        L.oracle_harris_response_v1.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
         L.oracle_detect_harris_binned.restype = C.c_int
         L.oracle_detect_harris_binned.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.c_double, f32p, f32p, intp]
@@ -223,6 +225,14 @@ def harris_response(img, k=HARRIS_K):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     r = np.empty(img.shape, np.float32)
     assert lib().oracle_harris_response(ptr(img, C.c_uint8), img.shape[0], img.shape[1], k, ptr(r, C.c_float)) == 1
+    return r
+
+
+def harris_response_v1(img, k=HARRIS_K):
+    """The rounds 1-3 restatement (exact integer Sobel sums times the scale): kept for comparison."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    r = np.empty(img.shape, np.float32)
+    assert lib().oracle_harris_response_v1(ptr(img, C.c_uint8), img.shape[0], img.shape[1], k, ptr(r, C.c_float)) == 1
     return r
 
 

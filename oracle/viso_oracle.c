@@ -606,18 +606,105 @@ int oracle_extract_descriptors(const uint8_t* img, int rows, int cols,
 
 /* ------------------------------------------------------- Harris (binned) */
 /* HarrisBinnedFeatureDetector::detectImpl, reference src/viso.cpp:926-975, with
- * cv::cornerHarris(image, R, blockSize=3, ksize=5, k, BORDER_DEFAULT) restated
- * (OpenCV imgproc corner.cpp, un-vendored): Dx, Dy = 5x5 Sobel (deriv
- * [-1,-2,0,2,1] x smooth [1,4,6,4,1], BORDER_REFLECT_101) scaled by
- * 1/(2^(ksize-1) * blockSize * 255); cov = (dx*dx, dx*dy, dy*dy) in float;
- * unnormalised 3x3 box sum of cov with BORDER_REFLECT_101 on the cov image;
- * R = (float)(a*c - b*b - k*(a+c)*(a+c)) with k double.  The reference never
- * initialises its k (src/viso.cpp:915-919,978): k is an explicit input here.
- * Evaluation order (this restatement's definition, shared with the HIP kernel):
- * integer Sobel sums are exact, dx = (float)Dx * (float)scale, box sums add the
- * nine taps row-major in float. */
+ * cv::cornerHarris(image, R, blockSize=3, ksize=5, k, BORDER_DEFAULT) restated from OpenCV's published algorithm
+ * (imgproc corner.cpp / deriv.cpp / filter.cpp / smooth.cpp of the 3.0 line; un-vendored, the reference's CMake points at
+ * an OpenCV 3.0 tree), IN OPENCV'S EVALUATION ORDER as far as that order is a function of the pixel's neighbourhood:
+ *   scale = 1 / (2^(ksize-1) * blockSize * 255) (double), handed to Sobel(..., CV_32F, ..., scale), which multiplies
+ *     the SMOOTHING kernel by it (deriv.cpp: "if( dx == 0 ) kx *= scale; else ky *= scale;", Mat *= double on a CV_32F
+ *     kernel = convertTo with the factor cast to float: tap_i = fl32(s_i * fl32(scale)), s = [1,4,6,4,1]);
+ *   sepFilter2D, 8U -> 32F, float row buffer, BORDER_REFLECT_101 on the source:
+ *     Dx: row pass with the derivative kernel [-1,-2,0,2,1] (RowFilter<uchar,float>: k0*S0, += k1*S1, ... left to right;
+ *         exact, the values are small integers), column pass with the scaled symmetric smoothing kernel
+ *         (SymmColumnFilter: f0*S0 + delta, += f1*(S1 + S-1), += f2*(S2 + S-2));
+ *     Dy: row pass with the scaled smoothing kernel (five float products added left to right), column pass with the
+ *         anti-symmetric derivative kernel (SymmColumnFilter: delta, += 2*(S1 - S-1), += 1*(S2 - S-2));
+ *   cov = (dx*dx, dx*dy, dy*dy) in float;
+ *   boxFilter(cov, 3x3, normalize = false, BORDER_REFLECT_101 on cov): row sums (S[x-1] + S[x]) + S[x+1], then column
+ *     sums (rs[y-1] + rs[y]) + rs[y+1];
+ *   R = (float)(a*c - b*b - k*(a+c)*(a+c)): a*c, b*b and their difference in float, k double.
+ * What is NOT reproducible from the algorithm alone: OpenCV's ColumnSum keeps RUNNING column sums down the image
+ * (SUM += new row; out = SUM; SUM -= old row), so its float rounding depends on every row above in the stripe its
+ * thread was given; the restatement takes the local sum.  Harris parity with a real OpenCV stays unpinned (no OpenCV
+ * here); the previous restatement (exact integer Sobel sums times the scale, nine taps row-major) is kept as
+ * oracle_harris_response_v1 for comparison: the two agree to ~1e-6 relative.
+ * The reference never initialises its k (src/viso.cpp:915-919,978): k is an explicit input here. */
+static void harris_taps(float tap[5]) {
+    static const float sm[5] = {1.f, 4.f, 6.f, 4.f, 1.f};
+    const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
+    for (int i = 0; i < 5; ++i) tap[i] = sm[i] * scale;
+}
+
 static void harris_cov(const uint8_t* img, int rows, int cols, float* cov /* rows*cols*3 */) {
+    float tap[5];
+    harris_taps(tap);
+    float* H = (float*)malloc(sizeof(float) * (size_t)rows * cols);   /* row pass, derivative kernel */
+    float* G = (float*)malloc(sizeof(float) * (size_t)rows * cols);   /* row pass, scaled smoothing kernel */
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t* r = img + (size_t)y * cols;
+        for (int x = 0; x < cols; ++x) {
+            float p[5];
+            for (int j = 0; j < 5; ++j) p[j] = (float)r[reflect101(x + j - 2, cols)];
+            float h = -1.f * p[0];
+            h += -2.f * p[1]; h += 0.f * p[2]; h += 2.f * p[3]; h += 1.f * p[4];
+            float g = tap[0] * p[0];
+            g += tap[1] * p[1]; g += tap[2] * p[2]; g += tap[3] * p[3]; g += tap[4] * p[4];
+            H[(size_t)y * cols + x] = h;
+            G[(size_t)y * cols + x] = g;
+        }
+    }
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const size_t y0 = (size_t)y * cols + x;
+            const size_t ym1 = (size_t)reflect101(y - 1, rows) * cols + x, yp1 = (size_t)reflect101(y + 1, rows) * cols + x;
+            const size_t ym2 = (size_t)reflect101(y - 2, rows) * cols + x, yp2 = (size_t)reflect101(y + 2, rows) * cols + x;
+            float dx = tap[2] * H[y0] + 0.f;
+            dx += tap[3] * (H[yp1] + H[ym1]);
+            dx += tap[4] * (H[yp2] + H[ym2]);
+            float dy = 0.f;
+            dy += 2.f * (G[yp1] - G[ym1]);
+            dy += 1.f * (G[yp2] - G[ym2]);
+            float* c = cov + y0 * 3;
+            c[0] = dx * dx; c[1] = dx * dy; c[2] = dy * dy;
+        }
+    free(H); free(G);
+}
+
+int oracle_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp) {
+    if (rows <= 0 || cols <= 0) return VISO_ERR_ARG;
+    float* cov = (float*)malloc(sizeof(float) * (size_t)rows * cols * 3);
+    float* rs = (float*)malloc(sizeof(float) * (size_t)rows * cols * 3);
+    if (!cov || !rs) { free(cov); free(rs); return VISO_ERR_NOMEM; }
+    harris_cov(img, rows, cols, cov);
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float* l = cov + ((size_t)y * cols + reflect101(x - 1, cols)) * 3;
+            const float* m = cov + ((size_t)y * cols + x) * 3;
+            const float* r = cov + ((size_t)y * cols + reflect101(x + 1, cols)) * 3;
+            float* o = rs + ((size_t)y * cols + x) * 3;
+            for (int ch = 0; ch < 3; ++ch) o[ch] = (l[ch] + m[ch]) + r[ch];
+        }
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float* u = rs + ((size_t)reflect101(y - 1, rows) * cols + x) * 3;
+            const float* m = rs + ((size_t)y * cols + x) * 3;
+            const float* d = rs + ((size_t)reflect101(y + 1, rows) * cols + x) * 3;
+            const float a = (u[0] + m[0]) + d[0], b = (u[1] + m[1]) + d[1], c = (u[2] + m[2]) + d[2];
+            const float t1 = a * c, t2 = b * b;
+            const float t3 = t1 - t2;
+            const float tr = a + c;
+            resp[(size_t)y * cols + x] = (float)((double)t3 - k * (double)tr * (double)tr);
+        }
+    free(cov); free(rs);
+    return VISO_OK;
+}
+
+/* The previous restatement (rounds 1-3): exact integer 5x5 Sobel sums, dx = (float)Dx * (float)scale, the nine box
+ * taps added row-major.  Kept for the cross-check in tests/test_oracle.py. */
+int oracle_harris_response_v1(const uint8_t* img, int rows, int cols, double k, float* resp) {
     static const int d[5] = {-1, -2, 0, 2, 1}, sm[5] = {1, 4, 6, 4, 1};
+    if (rows <= 0 || cols <= 0) return VISO_ERR_ARG;
+    float* cov = (float*)malloc(sizeof(float) * (size_t)rows * cols * 3);
+    if (!cov) return VISO_ERR_NOMEM;
     const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
@@ -637,13 +724,6 @@ static void harris_cov(const uint8_t* img, int rows, int cols, float* cov /* row
             float* c = cov + ((size_t)y * cols + x) * 3;
             c[0] = dx * dx; c[1] = dx * dy; c[2] = dy * dy;
         }
-}
-
-int oracle_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp) {
-    if (rows <= 0 || cols <= 0) return VISO_ERR_ARG;
-    float* cov = (float*)malloc(sizeof(float) * (size_t)rows * cols * 3);
-    if (!cov) return VISO_ERR_NOMEM;
-    harris_cov(img, rows, cols, cov);
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
             float a = 0.f, b = 0.f, c = 0.f;

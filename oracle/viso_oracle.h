@@ -86,6 +86,8 @@ int oracle_extract_descriptors(const uint8_t* img, int rows, int cols,
 
 /* cv::cornerHarris(blockSize 3, ksize 5, k, BORDER_DEFAULT) restated; resp: rows x cols float. */
 int oracle_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp);
+/* the rounds 1-3 restatement (exact integer Sobel sums times the scale, nine box taps row-major), for comparison */
+int oracle_harris_response_v1(const uint8_t* img, int rows, int cols, double k, float* resp);
 /* HarrisBinnedFeatureDetector::detectImpl, src/viso.cpp:926-975 (k explicit). */
 int oracle_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_features, int nbinx, int nbiny,
                                 double k, float* kp, float* resp_out, int* n_out);

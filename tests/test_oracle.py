@@ -317,6 +317,48 @@ def test_harris_response_vs_scipy(oracle):
     a, b, c = box(Dx * Dx), box(Dx * Dy), box(Dy * Dy)
     R = a * c - b * b - oracle.HARRIS_K * (a + c) ** 2
     assert np.abs(r - R).max() <= 2e-6 * np.abs(R).max()
+    # the two evaluation orders (OpenCV's: scaled float smoothing kernel, symmetric grouping, row sums then column
+    # sums; and the rounds 1-3 one: exact integer Sobel sums times the scale) are the same function up to float rounding
+    r1 = oracle.harris_response_v1(img)
+    assert np.abs(r1 - R).max() <= 2e-6 * np.abs(R).max() and np.abs(r - r1).max() <= 2e-6 * np.abs(R).max()
+    assert not np.array_equal(r, r1)                      # ... and they do differ in the last bits: the order matters
+
+
+def test_harris_order_by_hand(oracle):
+    """oracle_harris_response against a numpy float32 transcription of OpenCV's evaluation order, written from the
+    OpenCV sources' description (deriv.cpp: the scale goes into the smoothing kernel; filter.cpp: RowFilter adds left to
+    right, SymmColumnFilter groups f1*(S1 + S-1); smooth.cpp: row sums, then column sums), every operation rounded to
+    float32 in that order."""
+    f = np.float32
+    img = synth.make_images(11, 23, 31)
+    rows, cols = img.shape
+    pad = lambda A, n: np.pad(A, n, mode="reflect")
+    scale = f(1.0 / (16.0 * 3.0 * 255.0))
+    tap = [f(s) * scale for s in (1, 4, 6, 4, 1)]
+    P = pad(img.astype(f), 2)
+    px = lambda j: P[2:2 + rows, j:j + cols]                     # column x + j - 2
+    H = f(-1) * px(0); H = H + f(-2) * px(1); H = H + f(0) * px(2); H = H + f(2) * px(3); H = H + f(1) * px(4)
+    G = tap[0] * px(0)
+    for j in range(1, 5):
+        G = (G + tap[j] * px(j)).astype(f)
+    Hp, Gp = pad(H.astype(f), ((2, 2), (0, 0))), pad(G, ((2, 2), (0, 0)))
+    ry = lambda A, i: A[2 + i:2 + i + rows]
+    dx = (tap[2] * ry(Hp, 0) + f(0)).astype(f)
+    dx = (dx + tap[3] * (ry(Hp, 1) + ry(Hp, -1)).astype(f)).astype(f)
+    dx = (dx + tap[4] * (ry(Hp, 2) + ry(Hp, -2)).astype(f)).astype(f)
+    dy = (f(2) * (ry(Gp, 1) - ry(Gp, -1)).astype(f)).astype(f)
+    dy = (dy + (ry(Gp, 2) - ry(Gp, -2)).astype(f)).astype(f)
+    out = []
+    for cv in ((dx * dx).astype(f), (dx * dy).astype(f), (dy * dy).astype(f)):
+        C1 = pad(cv, ((0, 0), (1, 1)))
+        rs = ((C1[:, 0:cols] + C1[:, 1:cols + 1]).astype(f) + C1[:, 2:cols + 2]).astype(f)
+        R1 = pad(rs, ((1, 1), (0, 0)))
+        out.append(((R1[0:rows] + R1[1:rows + 1]).astype(f) + R1[2:rows + 2]).astype(f))
+    a, b, c = out
+    t3 = ((a * c).astype(f) - (b * b).astype(f)).astype(f)
+    tr = (a + c).astype(f)
+    want = (t3.astype(np.float64) - oracle.HARRIS_K * tr.astype(np.float64) * tr.astype(np.float64)).astype(f)
+    assert np.array_equal(oracle.harris_response(img), want)
 
 
 def test_harris_binned_selection(oracle):
