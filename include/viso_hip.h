@@ -88,11 +88,13 @@ int viso_ctx_destroy(viso_ctx* ctx);
 void* viso_ctx_stream(viso_ctx* ctx);
 int viso_ctx_synchronize(viso_ctx* ctx);
 /* Which kernel takes the temporal match_desc calls of this context (ctx == NULL: the default context of the
- * plain family): 3 = match_union_kernel (rows gathered from the XCD's L2; a wave scores every row it loads against
- * eight y-adjacent queries; vector-ALU bound).  Further variants (2 = match_batch_kernel<0>,
- * 4 = match_strip_kernel) exist in -DVISO_DEBUG_VARIANTS builds only; every variant gives identical results, and
- * the parity tests run over whatever viso_matcher_variants() reports for the build under test.  Returns
- * VISO_ERR_ARG for a variant this build does not have. */
+ * plain family).  The product build offers two: 3 = match_union_kernel (the default: rows gathered from the XCD's L2,
+ * a wave scores every row it loads against eight y-adjacent queries; vector-ALU bound) and
+ * 5 = match_prune_kernel (exact successive elimination on block sums in front of a cell-granular scorer; as fast, its
+ * cost falls with the share of queries that have a distinctive match).  Further variants (2 = match_batch_kernel<0>,
+ * 4 = match_strip_kernel) exist in -DVISO_DEBUG_VARIANTS builds only.  Every variant gives identical results, and the
+ * parity tests run over whatever viso_matcher_variants() reports for the build under test.  Returns VISO_ERR_ARG for a
+ * variant this build does not have. */
 int viso_ctx_set_matcher(viso_ctx* ctx, int variant);
 /* The variants of this build: fills out[0..cap), returns their number.  Needs no device. */
 int viso_matcher_variants(int* out, int cap);
@@ -230,7 +232,8 @@ int viso_batch_upload_async(viso_batch* b, int f0, int nf, const float* kp,
  * encoding of what MyFeatureExtractor produces (3x3 Sobel of uint8: integers in [-1020, 1020], src/viso.cpp:1004-1024)
  * at half the bytes of the reference's CV_32F rows (:995,1008) — the PCIe-bound streaming mode moves half the data.
  * Same results as the f32 uploads of the same values.  All frames of a batch must come through ONE of the two
- * families (the int16 rows live in the f32 rows' device buffer); needs dlen <= 128. */
+ * families (the int16 rows live in the f32 rows' device buffer): the batch remembers per frame which family filled it,
+ * and viso_batch_run* returns VISO_ERR_ARG when the frames of a run disagree.  Needs dlen <= 128. */
 int viso_batch_upload_i16(viso_batch* b, int f0, int nf, const float* kp,
                           const int16_t* desc16, const int32_t* n);
 int viso_batch_upload_i16_async(viso_batch* b, int f0, int nf, const float* kp,
@@ -287,8 +290,12 @@ int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok,
 int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl);
 /* Per-hypothesis state of the last run's RANSAC stage (diagnostics / tests): tr_h [n_frames][ransac_iter][6],
  * ok_h, cnt_h [n_frames][ransac_iter] (support sizes; frame 0 unused), *n_undecided = hypotheses that needed the
- * wave-per-hypothesis kernel.  Any pointer may be NULL. */
+ * wave-per-hypothesis kernel.  Any pointer may be NULL.  ransac_iter is the one given to viso_batch_set_params;
+ * viso_batch_get_hypotheses2 takes the capacity of the caller's arrays (in hypotheses per frame) and returns
+ * VISO_ERR_ARG instead of writing past them. */
 int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided);
+int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, double* tr_h, int32_t* ok_h, int32_t* cnt_h,
+                               int32_t* n_undecided);
 /* Work counters of the last run, for the algorithmic-bytes model of
  * per (which,t) the number of scored (query,candidate) pairs C
  * and matches emitted M_out.  scored/m_out: [3][n_frames] int64. */

@@ -137,8 +137,9 @@ DEFAULT_MATCHER = 3
 
 
 def matcher_variants():
-    """What this build of libviso_hip.so offers (viso_ctx_set_matcher): (3,) for the product build, (2, 3, 4) for
-    `make DEBUG_VARIANTS=1`.  Asked of the library itself, so a debug build gets its variants tested."""
+    """What this build of libviso_hip.so offers (viso_ctx_set_matcher): (3, 5) for the product build — match_union_kernel
+    (default) and match_prune_kernel — and (2, 3, 4, 5) for `make DEBUG_VARIANTS=1`.  Asked of the library itself, so a
+    debug build gets its variants tested."""
     out = (C.c_int * 8)()
     n = load().viso_matcher_variants(out, 8)
     return tuple(out[i] for i in range(min(n, 8)))
@@ -498,6 +499,7 @@ class Batch:
     def set_params(self, stereo, temporal, param, seed=0, first_frame=0):
         self._chk("viso_batch_set_params", self.L.viso_batch_set_params(
             self.h, C.byref(stereo), C.byref(temporal), C.byref(param), seed, first_frame))
+        self.ransac_iter = int(param.ransac_iter)     # what viso_batch_get_hypotheses copies per frame
 
     def run_matcher(self):
         self._chk("viso_batch_run_matcher", self.L.viso_batch_run_matcher(self.h))
@@ -532,8 +534,16 @@ class Batch:
         self._chk("viso_batch_get_poses", self.L.viso_batch_get_poses(self.h, ptr(tr, C.c_double), ptr(ok, C.c_int32), ptr(n, C.c_int32)))
         return tr, ok, n
 
-    def hypotheses(self, iters):
-        """(tr_h [nf][iters][6], ok_h [nf][iters], cnt_h [nf][iters], n_undecided) of the last run's RANSAC stage."""
+    def hypotheses(self, iters=None):
+        """(tr_h [nf][iters][6], ok_h [nf][iters], cnt_h [nf][iters], n_undecided) of the last run's RANSAC stage.
+        The buffers are sized from the ransac_iter given to set_params (the library copies nf * that many entries);
+        an `iters` that disagrees is refused instead of letting the copy run past a smaller buffer."""
+        have = getattr(self, "ransac_iter", None)
+        if have is None:
+            raise RuntimeError("hypotheses(): set_params has not been called on this batch")
+        if iters is not None and iters != have:
+            raise ValueError(f"hypotheses(iters={iters}): the batch was set up with ransac_iter={have}")
+        iters = have
         tr = np.zeros((self.nf, iters, 6))
         ok = np.zeros((self.nf, iters), np.int32)
         cnt = np.zeros((self.nf, iters), np.int32)

@@ -45,6 +45,7 @@ struct viso_batch {
     bool params_set;
     bool timing;
     bool desc_i16;             // the descriptor buffer holds int16 rows (viso_batch_upload_i16*), not the f32 boundary layout
+    std::vector<signed char> desc_family;   // per frame: 0 = never uploaded, 1 = f32 rows, 2 = int16 rows (the two must not mix in a run)
     // The RANSAC stage of run k (latency bound: a few hundred waves on serial fp64 chains for ~1 ms) runs on a
     // stream of its own (the context's second stream), so that the matcher of run k+1 — which touches none of its
     // buffers — fills the GPU beside it: stream (matcher, triangulation, circle join) --ev_join--> solver_stream (RANSAC) --ev_ransac--> the next
@@ -205,6 +206,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
     b->n_probs = ((n_frames + 7) / 8) * 24;
     b->params_set = false; b->timing = false; b->desc_i16 = false;
+    b->desc_family.assign((size_t)n_frames, 0);
     b->ev_next = 0; b->ev_ms_sum = 0; b->ev_n = 0;
     b->solver_stream = nullptr; b->ev_join = nullptr; b->ev_ransac = nullptr; b->ransac_pending = false;
     b->ev_stamp[0] = b->ev_stamp[1] = b->ev_stamp[2] = nullptr; b->stamps = false;
@@ -277,6 +279,7 @@ extern "C" int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp,
     int r;
     if ((r = enter(b)) < 0) return r;
     b->desc_i16 = false;
+    for (int t = f0; t < f0 + nf; ++t) b->desc_family[(size_t)t] = 1;
     // the batch's kernels run on a non-blocking stream: order the copies behind them, then wait (synchronous call)
     hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
@@ -326,6 +329,7 @@ extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const floa
     int r;
     if ((r = enter(b)) < 0) return r;
     b->desc_i16 = false;
+    for (int t = f0; t < f0 + nf; ++t) b->desc_family[(size_t)t] = 1;
     hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
     HIP_TRY(hipMemcpyAsync(b->kp + (size_t)f0 * 2 * c, kp, sizeof(float2) * (size_t)nf * 2 * c, hipMemcpyHostToDevice, s));
@@ -347,6 +351,7 @@ static int upload_i16_impl(viso_batch* b, int f0, int nf, const float* kp, const
     int r;
     if ((r = enter(b)) < 0) return r;
     b->desc_i16 = true;
+    for (int t = f0; t < f0 + nf; ++t) b->desc_family[(size_t)t] = 2;
     hipStream_t s = b->ctx->stream;
     const size_t c = (size_t)b->cap;
     int16_t* d16 = reinterpret_cast<int16_t*>(b->desc);
@@ -437,6 +442,16 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     if (from_images && (!b->images || b->dlen != VISO_DESC_LEN)) {
         viso_set_error("viso_batch_run_images: no images uploaded (or descriptor length is not 121)");
         return VISO_ERR_ARG;
+    }
+    if (!from_images) {   // f32 rows and int16 rows share one device buffer: a run over frames of both families would
+                          // reinterpret one of them (garbage matches, no error) -- refuse it
+        bool f32 = false, i16 = false;
+        for (signed char f : b->desc_family) { f32 = f32 || f == 1; i16 = i16 || f == 2; }
+        if (f32 && i16) {
+            viso_set_error("viso_batch_run: frames of this batch were uploaded through both viso_batch_upload (f32 rows) and "
+                           "viso_batch_upload_i16 (int16 rows); upload all frames through one family");
+            return VISO_ERR_ARG;
+        }
     }
     int r;
     if ((r = enter(b)) < 0) return r;
@@ -686,6 +701,15 @@ extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int3
 
 // The per-hypothesis state of the last run's RANSAC stage (test / diagnostics): tr_h [n_frames][iters][6], ok_h and
 // cnt_h [n_frames][iters] (frame 0 unused), *n_undecided = hypotheses the lane-per-hypothesis kernel handed on.
+extern "C" int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, double* tr_h, int32_t* ok_h, int32_t* cnt_h,
+                                          int32_t* n_undecided) {
+    if (!b || iters_capacity < (b->iters > 0 ? b->iters : 1)) {
+        viso_set_error("viso_batch_get_hypotheses2: arrays hold %d hypotheses per frame, the batch has %d", iters_capacity, b ? b->iters : 0);
+        return VISO_ERR_ARG;
+    }
+    return viso_batch_get_hypotheses(b, tr_h, ok_h, cnt_h, n_undecided);
+}
+
 extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided) {
     if (!b || !b->tr_h) { viso_set_error("viso_batch_get_hypotheses: no run yet"); return VISO_ERR_ARG; }
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }

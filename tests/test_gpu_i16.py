@@ -66,6 +66,35 @@ def test_i16_rows_give_the_f32_results(viso, oracle):
     pk.close(); pd.close(); b.close(); ctx.close()
 
 
+def test_mixed_families_in_one_run_are_refused(viso):
+    """int16 rows live in the f32 rows' device buffer; a run over frames of both families would reinterpret
+    one of them silently.  The batch remembers the family per frame and viso_batch_run* refuses the mix."""
+    nf = 5
+    seq = synth.make_sequence(92, nf, n_kp=300, width=600, height=200)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    d16 = seq["desc"].astype(np.int16)
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, seq["kp"].shape[2])
+    b.set_params(st, tm, seq["param"], seed=3)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.run()
+    want = b.poses()
+    b.upload_i16(seq["kp"][2:4], d16[2:4], seq["n"][2:4], f0=2)          # frames 2..3 as int16, the rest still f32
+    with pytest.raises(RuntimeError, match="both"):
+        b.run()
+    with pytest.raises(RuntimeError, match="both"):
+        b.run_matcher()
+    b.upload_i16(seq["kp"], d16, seq["n"])                               # all frames through one family again
+    b.run()
+    assert all(np.array_equal(x, y) for x, y in zip(b.poses(), want))
+    # the hypotheses getter sizes its arrays from set_params' ransac_iter and refuses another count
+    tr_h, ok_h, cnt_h, _ = b.hypotheses()
+    assert tr_h.shape == (nf, seq["param"].ransac_iter, 6)
+    with pytest.raises(ValueError):
+        b.hypotheses(seq["param"].ransac_iter - 10)
+    b.close(); ctx.close()
+
+
 def test_i16_extreme_values(viso, oracle):
     """The whole int16 range (beyond what Sobel of uint8 produces): still exact, never the general path."""
     rng = np.random.default_rng(5)
