@@ -25,7 +25,7 @@
 #define ST_THREADS 256
 #define ST_WAVES 4
 #define ST_QPW 64            // queries per wave = per tile
-#define ST_WCAP 448          // window keypoints per chunk (7 per lane)
+#define ST_WCAP 384          // window keypoints per chunk (6 per lane; a uniform tile of 2000-keypoint images sees ~320)
 #define ST_NBY 64            // y buckets
 #define ST_SLOTS 8           // candidates per query and chunk that may reach the scorer
 #define ST_PCAP (ST_QPW * ST_SLOTS)
@@ -40,9 +40,10 @@ struct StWaveLds {
     uint16_t ypos[ST_WCAP];              // their window positions
     int hist[ST_NBY + 1];                // bucket counts, then bucket starts (hist[ST_NBY] = number of entries)
     uint16_t slot[ST_SLOTS][ST_QPW];     // per query: y-order indices of its candidates
-    uint32_t flat[ST_PCAP + ST_PAD];     // query << 16 | window position
-    uint32_t sads[ST_PCAP + ST_PAD];
+    uint32_t flat[ST_PCAP + ST_PAD];     // query << 16 | window position; the scorer leaves SAD << 9 | window position in the
+                                         // pair's own slot (SAD < 2^23, position < ST_WCAP <= 512): no second array
 };
+static_assert(ST_WCAP <= 512, "window positions share a word with the SAD");
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t st_dpp(uint32_t v) {
@@ -232,11 +233,13 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
             const gbytes_t wrows = trows + (size_t)(lo + cb) * (VISO_ROW * 2);
             u32x4 t0[ST_NP], t1[ST_NP], u0[ST_NP], u1[ST_NP];
             int dst[ST_NP];
+            uint32_t wpos[ST_NP];
 #define ST_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
                 const int gi_ = (T) * 8 + g8;                                                              \
                 const uint32_t e_ = L.flat[gi_];                                                           \
                 dst[SLOT] = gi_;                                                                           \
+                wpos[SLOT] = e_ & 0x1ffu;                                                                  \
                 const grow_t tr_ = (grow_t)(wrows + (((e_ & 0xffffu) << 8) | (uint32_t)(sub << 4)));       \
                 const grow_t qr_ = (grow_t)(qrows + (((e_ >> 16) << 8) | (uint32_t)(sub << 4)));           \
                 t0[SLOT] = tr_[0]; t1[SLOT] = tr_[8];                                                      \
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
                 s_ += st_dpp<0xB1>(s_);                                                                    \
                 s_ += st_dpp<0x4E>(s_);                                                                    \
                 s_ += st_dpp<0x141>(s_);                                                                   \
-                if (sub == 0) L.sads[dst[SLOT]] = s_;   /* slots past ntot are scratch */                  \
+                if (sub == 0) L.flat[dst[SLOT]] = (s_ << 9) | wpos[SLOT];   /* slots past ntot are scratch */ \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -281,8 +284,9 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
         __builtin_amdgcn_wave_barrier();
         // ---- reduce: the lane's own SADs into its running order statistics
         for (int s = 0; s < n2g; ++s) {
-            const uint32_t v = L.sads[base + s];
-            const uint32_t w = (L.flat[base + s] & 0xffffu) + (uint32_t)cb;
+            const uint32_t f = L.flat[base + s];
+            const uint32_t v = f >> 9;
+            const uint32_t w = (f & 0x1ffu) + (uint32_t)cb;
             const bool lt = v < d1, eq = v == d1;
             d2 = (v <= d1) ? d1 : min(d2, v);
             bw = lt ? w : bw;
