@@ -38,9 +38,11 @@ __device__ __forceinline__ int h_reflect101(int p, int len) {
 }
 
 // uint8 tile rows ty0-3 .. ty0+th+2, columns tx0-3 .. tx0+tw+2 -> s_img (BORDER_REFLECT_101 outside the image)
+// NW waves share the rows of one tile (NW = 1: a wave loads its own tile)
+template <int NW>
 __device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im, int rows, int cols, int tx0, int ty0,
                                                  int tw, int th, unsigned char* s_img) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = NW == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool inside = tx0 >= 3 && ty0 >= 3 && tx0 + tw + 3 <= cols && ty0 + th + 3 <= rows;
     const int ndw = (tw + 6 + 3) / 4;                             // dwords per LDS row
     if (tx0 >= 3 && ndw <= 16 && tx0 - 3 + 4 * ndw <= cols) {
@@ -48,11 +50,11 @@ __device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im,
         // rows put that at any alignment: the hardware takes unaligned dword loads), 16 lanes per row, four rows per
         // wave instruction, eight instructions in flight
         const int sub = lane >> 4, dw = lane & 15;
-        for (int base = wave * 4 + sub; base < th + 6; base += 8 * 16) {
+        for (int base = wave * 4 + sub; base < th + 6; base += 8 * 4 * NW) {
             uint32_t v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int ly = base + u * 16;
+                const int ly = base + u * 4 * NW;
                 v[u] = 0;
                 if (ly < th + 6 && dw < ndw) {
                     int gy = ty0 - 3 + ly;
@@ -64,7 +66,7 @@ __device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im,
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int ly = base + u * 16;
+                const int ly = base + u * 4 * NW;
                 if (ly < th + 6 && dw < ndw) reinterpret_cast<uint32_t*>(s_img + ly * HW_PITCH)[dw] = v[u];
             }
         }
@@ -76,11 +78,11 @@ __device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im,
     if (!inside) { gx0 = h_reflect101(gx0, cols); gx1 = h_reflect101(gx1, cols); }
     const bool second = lane + 64 < tw + 6;
     const bool first = lane < tw + 6;
-    for (int base = wave; base < th + 6; base += 8 * (HW_THREADS / 64)) {
+    for (int base = wave; base < th + 6; base += 8 * NW) {
         unsigned char v0[8], v1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int ly = base + u * (HW_THREADS / 64);
+            const int ly = base + u * NW;
             v0[u] = 0; v1[u] = 0;
             if (ly < th + 6) {
                 int gy = ty0 - 3 + ly;
@@ -92,7 +94,7 @@ __device__ __forceinline__ void harris_load_tile(const uint8_t* __restrict__ im,
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int ly = base + u * (HW_THREADS / 64);
+            const int ly = base + u * NW;
             if (ly < th + 6) {
                 if (first) s_img[ly * HW_PITCH + lane] = v0[u];
                 if (second) s_img[ly * HW_PITCH + 64 + lane] = v1[u];
@@ -109,8 +111,8 @@ __device__ __forceinline__ float wave_shl1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
-// Wave `band` of the workgroup walks output rows [y0, y1) of the tile (relative to ty0); sink(y, lx - 1, R) is called
-// by the lanes that own an output column (0 <= lx - 1 < tw) for every row, in row order.
+// Wave `band` of the workgroup walks output rows [y0, y1) of the tile (relative to ty0); sink(y, lx - 1, R, valid) is
+// called by EVERY lane for every row, in row order; valid = the lane owns an output column (0 <= lx - 1 < tw).
 template <class Sink>
 __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
                                                  int tw, int y0, int y1, double k, Sink sink) {
@@ -180,7 +182,7 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
         const float m3 = m1 - m2;
         const float tr = a + c;
         const float R = (float)((double)m3 - k * (double)tr * (double)tr);
-        if (lx >= 1 && lx <= tw && gx < cols) sink(y, lx - 1, R);
+        sink(y, lx - 1, R, lx >= 1 && lx <= tw && gx < cols);   // every lane calls (wave-wide operations inside are fine)
     }
 }
 
@@ -195,13 +197,13 @@ __global__ __launch_bounds__(HW_THREADS) void harris_response_kernel(const uint8
     const int tw = min(HR_TW, cols - tx0), th = min(HR_TH, rows - ty0);
     const uint8_t* im = images + (size_t)img * rows * cols;
     float* out = resp + (size_t)img * rows * cols;
-    harris_load_tile(im, rows, cols, tx0, ty0, tw, th, s_img);
+    harris_load_tile<HW_THREADS / 64>(im, rows, cols, tx0, ty0, tw, th, s_img);
     __syncthreads();
     const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rb = (th + 3) / 4;   // wave uniform: scalar loop control
     const int y0 = band * rb, y1 = min(th, y0 + rb);
     if (y0 < y1)
         harris_walk_band(s_img, rows, cols, tx0, ty0, tw, y0, y1, k,
-                         [&](int y, int x, float R) { out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
+                         [&](int y, int x, float R, bool valid) { if (valid) out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
 }
 
 struct BinArgs {
@@ -241,8 +243,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return ((unsigned long long)mh << 32) | ml;
 }
 
-#define HD_MAXPER 32  // corners per bin the fused detector merges (4 x per keys; the reference has 10)
-#define HD_LIST 128   // fallback list of a wave of the fused detector (its quarter of the bin), in the dead pixel tile
+#define HD_MAXPER 32  // corners per bin the fused detector keeps (the reference has 10)
 #define HB_LIST 256   // keys >= the last optimistic pick collected by the one-walk exact path (per wave)
 
 // The `per` largest keys, descending, of the bin pixels idx = first + lane + step * i < P (idx in MEMORY order: x
@@ -387,63 +388,78 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
     if ((threadIdx.x & 63) == 0) a.cnt[(size_t)img * nbins + bin] = n;
 }
 
-// The fused detector: one workgroup per (image, bin).  The bin IS the tile: its responses are computed by the band
-// walk above straight into LDS (stridex * stridey floats), and wave 0 then selects the bin's corners from there.  The
-// response image (4 bytes per pixel written and read back by the two-kernel path) never exists; per image the only
-// HBM traffic is the uint8 pixels in and the corners out.
+// The fused detector: one WAVE per (image, bin), four bins per workgroup, no workgroup barrier.  The bin IS the tile: the
+// wave loads its pixels (+ halo) into its slice of LDS, walks all of its rows (one warm-up of six rows per bin; with
+// the rows split over four waves the warm-up was a third of the work) and selects the corners ON THE WAY: a key that
+// beats the running threshold tau (the `per`-th best key so far, 0 until then) is appended to the wave's candidate list
+// in LDS; when the list could overflow on the next row its `per` best are kept and tau rises.  Every key ever dropped
+// was <= tau at that time <= the final `per`-th best, so the true top `per` are in the list at the end: exact, no second
+// pass, and neither the response image nor the bin's responses ever exist in memory.  Per image the HBM traffic is the
+// uint8 pixels in (+ halo re-reads from L2) and the corners out.
+#define HD_CAND 256   // candidate keys per wave; a row appends at most HW_MAXW
+__device__ __forceinline__ int harris_keep_best(unsigned long long* list, int n, int per, unsigned long long& tau) {
+    // the `per` largest of list[0..n) to list[0..per) (descending), tau = the smallest kept (0 if fewer than `per`)
+    const int lane = threadIdx.x & 63;
+    unsigned long long mine[HD_CAND / 64];
+#pragma unroll
+    for (int u = 0; u < HD_CAND / 64; ++u) mine[u] = (lane + 64 * u < n) ? list[lane + 64 * u] : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    int kept = 0;
+    unsigned long long last = 0;
+    for (int round = 0; round < per; ++round) {
+        unsigned long long loc = mine[0];
+#pragma unroll
+        for (int u = 1; u < HD_CAND / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
+        const unsigned long long best = wave_max_u64(loc);
+        if (best == 0) break;
+#pragma unroll
+        for (int u = 0; u < HD_CAND / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
+        if (lane == 0) list[kept] = best;
+        last = best;
+        ++kept;
+    }
+    __builtin_amdgcn_wave_barrier();
+    tau = kept == per ? last : 0ull;
+    return kept;
+}
+
 __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, const uint8_t* __restrict__ images, double k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char h_smem[];
-    __shared__ unsigned long long s_cand[4 * HD_MAXPER];
-    __shared__ int s_ncand[4];
     const int nbins = a.nbinx * a.nbiny;
-    const int img = blockIdx.x / nbins, bin = blockIdx.x % nbins;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * (HW_THREADS / 64) + wave;
+    if (unit >= (long long)a.n_img * nbins) return;
+    const int img = (int)(unit / nbins), bin = (int)(unit % nbins);
     const int tx0 = (bin / a.nbiny) * a.stridex, ty0 = (bin % a.nbiny) * a.stridey;
     const int tw = a.stridex, th = a.stridey;              // bins never reach past the image: stride * nbin <= size
-    unsigned char* s_img = h_smem;
-    size_t tile_bytes = ((size_t)(th + 6) * HW_PITCH + 15) & ~(size_t)15;
-    if (tile_bytes < 4 * HD_LIST * sizeof(unsigned long long)) tile_bytes = 4 * HD_LIST * sizeof(unsigned long long);
-    float* s_resp = reinterpret_cast<float*>(h_smem + tile_bytes);
-    harris_load_tile(images + (size_t)img * a.rows * a.cols, a.rows, a.cols, tx0, ty0, tw, th, s_img);
-    __syncthreads();
-    const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rb = (th + 3) / 4;   // wave uniform: scalar loop control
-    const int y0 = band * rb, y1 = min(th, y0 + rb);
-    if (y0 < y1)
-        harris_walk_band(s_img, a.rows, a.cols, tx0, ty0, tw, y0, y1, k,
-                         [&](int y, int x, float R) { s_resp[y * tw + x] = fabsf(R); });
-    __syncthreads();
-    // selection: every wave takes the pixels idx = wave * 64 + lane (mod 256) of the bin and finds ITS `per` largest keys
-    // (all four waves busy; one wave walking the whole bin while three wait held the workgroup for twice the walk's time),
-    // then wave 0 picks the bin's `per` largest among the 4 * per survivors -- the true top `per` are among them
     const int per = a.per;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long* cand = s_cand;                     // [4][per] (per <= HD_MAXPER)
-    unsigned long long* list = reinterpret_cast<unsigned long long*>(s_img) + wave * HD_LIST;   // the pixels are dead by now
-    const int nw = harris_top_keys<HD_LIST>(tw, th, tw * th, per, wave * 64, HW_THREADS, [&](int xo, int yo) { return s_resp[yo * tw + xo]; },
-                                            [&](int n, unsigned long long key) { if (lane == 0) cand[wave * per + n] = key; }, list);
-    if (lane == 0) s_ncand[wave] = nw;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long mine[(4 * HD_MAXPER + 63) / 64];
-#pragma unroll
-        for (int u = 0; u < (4 * HD_MAXPER + 63) / 64; ++u) {
-            const int e = lane + 64 * u, w = e / per, i = e % per;
-            mine[u] = (e < 4 * per && i < s_ncand[w]) ? cand[e] : 0ull;
+    const size_t tile_bytes = ((size_t)(th + 6) * HW_PITCH + 15) & ~(size_t)15;
+    unsigned char* s_img = h_smem + (size_t)wave * (tile_bytes + HD_CAND * sizeof(unsigned long long));
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(s_img + tile_bytes);
+    harris_load_tile<1>(images + (size_t)img * a.rows * a.cols, a.rows, a.cols, tx0, ty0, tw, th, s_img);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long tau = 0;
+    int n = 0;
+    harris_walk_band(s_img, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool valid) {
+        // push position of the reference's scan (x outer, y inner, :953-955)
+        const unsigned long long key = valid ? harris_key(fabsf(R), x * th + y) : 0ull;
+        const bool take = key > tau;
+        const unsigned long long m = __ballot(take);
+        if (m) {                                           // uniform
+            const int at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (take) list[at] = key;
+            n += __popcll(m);
+            if (n > HD_CAND - 64) {                        // uniform: the next row might not fit
+                __builtin_amdgcn_wave_barrier();
+                n = harris_keep_best(list, n, per, tau);
+            }
         }
-        const BinEmit emit{a, ((size_t)img * nbins + bin) * a.per, tx0, ty0};
-        int n = 0;
-        for (int round = 0; round < per; ++round) {
-            unsigned long long loc = mine[0];
-#pragma unroll
-            for (int u = 1; u < (4 * HD_MAXPER + 63) / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
-            const unsigned long long best = wave_max_u64(loc);
-            if (best == 0) break;
-#pragma unroll
-            for (int u = 0; u < (4 * HD_MAXPER + 63) / 64; ++u) if (mine[u] == best) mine[u] = 0;
-            emit(n, best);
-            ++n;
-        }
-        if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
-    }
+    });
+    __builtin_amdgcn_wave_barrier();
+    n = harris_keep_best(list, n, per, tau);
+    const BinEmit emit{a, ((size_t)img * nbins + bin) * a.per, tx0, ty0};
+    for (int i = 0; i < n; ++i) emit(i, list[i]);
+    if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
 }
 
 // One workgroup per image: concatenate the bins' corners in bin order.
@@ -484,9 +500,8 @@ int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int 
 size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per) {
     const int sx = cols / nbinx, sy = rows / nbiny;
     if (sx <= 0 || sy <= 0 || sx > HW_MAXW || per > HD_MAXPER) return 0;
-    size_t tile = ((size_t)(sy + 6) * HW_PITCH + 15) & ~(size_t)15;
-    if (tile < 4 * HD_LIST * sizeof(unsigned long long)) tile = 4 * HD_LIST * sizeof(unsigned long long);   // the fallback lists live there
-    const size_t b = tile + sizeof(float) * (size_t)sx * sy;
+    const size_t tile = ((size_t)(sy + 6) * HW_PITCH + 15) & ~(size_t)15;
+    const size_t b = (HW_THREADS / 64) * (tile + HD_CAND * sizeof(unsigned long long));   // per wave: its bin's pixels + candidate keys
     return b <= 64 * 1024 ? b : 0;
 }
 
@@ -505,7 +520,7 @@ int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int ro
     if (!lds) { viso_set_error("harris: bin geometry does not fit the fused detector"); return VISO_ERR_UNSUPPORTED; }
     if (lds > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(harris_detect_kernel, dim3((unsigned)((long long)n_img * nbins)), dim3(HW_THREADS), lds, s, a, images, k);
+    hipLaunchKernelGGL(harris_detect_kernel, dim3((unsigned)(((long long)n_img * nbins + HW_THREADS / 64 - 1) / (HW_THREADS / 64))), dim3(HW_THREADS), lds, s, a, images, k);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(harris_compact_kernel, dim3(n_img), dim3(256), sizeof(int) * (size_t)(nbins + 1), s, a, kp_out,
                        resp_out, n_out, cap, kp_stride);
