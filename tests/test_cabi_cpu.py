@@ -179,3 +179,28 @@ def test_cpp_host_mirror_selftest(tmp_path):
     args = [str(tmp_path / "ok44.png"), str(tmp_path / "ok44.pgm")] + args
     r = subprocess.run([exe, str(tmp_path)] + args, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_png_decoder_survives_hostile_files_under_sanitizers(tmp_path):
+    """The KITTI runner's own PNG decoder (libviso_amd/host/png_read.hpp: table-driven inflate on raw pointers) reads
+    files it does not trust.  tools/png_fuzz.cpp, built with AddressSanitizer + UBSan for the CPU, damages a valid
+    8-bit grayscale PNG 1500 times (bit flips, truncation, rewritten chunk lengths, runs of 0x00 / 0xff and random
+    bytes inside the IDAT payload) and decodes every variant: refused or an image of the header's size, never a
+    report, never a byte written past a caller's buffer."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pngutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "png_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        os.path.join(ROOT, "tools", "png_fuzz.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(3)
+    img = np.clip(np.cumsum(rng.normal(0, 3, (96, 160)), 1) + 128, 0, 255).astype(np.uint8)
+    seed = str(tmp_path / "seed.png")
+    pngutil.write_gray_png(seed, img)
+    r = subprocess.run([exe, seed, "1500"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "png_fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
