@@ -133,6 +133,33 @@ def test_runner_reports_where_the_time_went(tree):
     assert "decode: 3 threads" in out and "GPU stamps: upload" in out and f"{N_FRAMES} frames in" in out
 
 
+def test_decode_threads_and_chunking_do_not_change_the_poses(tree):
+    """The images of a chunk are decoded by worker threads straight into the pinned upload buffer of the chunk's slot while
+    the GPU works on the previous chunk; the halo frame is copied from the other slot.  Any number of threads, any chunk
+    size: the same pose file.  And the sequence still ends at the first frame that cannot be decoded (src/viso.h:94-96)."""
+    import shutil
+    home, _ = tree
+    _run([EXE, "t1", "03", str(FIRST), "--decode-threads", "1", "--chunk", "64"], home)
+    one = open(_pose_file(home, "t1"), "rb").read()
+    for sha, threads, chunk in (("t7c2", "7", "2"), ("t2c1", "2", "1"), ("t16c4", "16", "4")):
+        _run([EXE, sha, "03", str(FIRST), "--decode-threads", threads, "--chunk", chunk], home)
+        assert open(_pose_file(home, sha), "rb").read() == one, sha
+    # a damaged frame in the middle: the run ends there (frames FIRST .. FIRST+5 remain), for every thread count
+    seq_dir = os.path.join(home, "sequences", "03")
+    bad = os.path.join(seq_dir, "image_1", "%06d.png" % (FIRST + 6))
+    keep = bad + ".keep"
+    shutil.copy(bad, keep)
+    try:
+        with open(bad, "r+b") as f:
+            f.seek(60); f.write(b"\xff" * 40)
+        for sha, threads in (("cut1", "1"), ("cut5", "5")):
+            out = _run([EXE, sha, "03", str(FIRST), "--decode-threads", threads, "--chunk", "4"], home)
+            assert "frames 6 " in out, out
+            assert open(_pose_file(home, sha), "rb").read() == b"".join(one.splitlines(keepends=True)[:6]), sha
+    finally:
+        shutil.move(keep, bad)
+
+
 def test_sub_range_with_begin_and_end(tree):
     """begin/end (src/kitti.cpp:86-94) under sharding: frames FIRST+2 .. FIRST+8, W = 1 and 2."""
     home, _ = tree
