@@ -45,9 +45,11 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(SolverArgs a) {
     if (N >= 3) {
         const unsigned long long s0 = a.seed ^ (0xD1B54A32D192ED03ULL * (S.frame + 1)) ^
                                       (0x8CB92BA72F3D8DD7ULL * ((unsigned long long)h + 1));
-        for (int base = 0; m < 3 && base < N; base += 64) {
+        // draw t = f(s0 + (t + 1) gamma): the lane's counter advances by 64 gamma per round (an add, not a 64-bit multiply)
+        unsigned long long ctr = s0 + 0x9E3779B97F4A7C15ULL * ((unsigned long long)lane + 1);
+        for (int base = 0; m < 3 && base < N; base += 64, ctr += 64ULL * 0x9E3779B97F4A7C15ULL) {
             const int t = base + lane;
-            unsigned long long z = s0 + 0x9E3779B97F4A7C15ULL * ((unsigned long long)t + 1);
+            unsigned long long z = ctr;
             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
             z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
             z ^= z >> 31;
