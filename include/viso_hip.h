@@ -98,6 +98,9 @@ int viso_ctx_synchronize(viso_ctx* ctx);
 int viso_ctx_set_matcher(viso_ctx* ctx, int variant);
 /* The variants of this build: fills out[0..cap), returns their number.  Needs no device. */
 int viso_matcher_variants(int* out, int cap);
+/* The variant a new context starts with: the build's default, or $VISO_MATCHER when that names a variant of this build
+ * (an A/B and test aid).  Needs no device. */
+int viso_matcher_default(void);
 /* How the RANSAC stage splits the <= 100 Gauss-Newton iterations of a 3-point hypothesis (src/viso.cpp:1593) between
  * its two kernels: the lane-per-hypothesis kernel runs the first `split`, the wave-per-hypothesis kernel the rest of
  * the few that are still undecided.  0 = the build's default (10); 100 = the lane kernel alone.  Every split gives

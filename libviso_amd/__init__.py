@@ -133,7 +133,6 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-DEFAULT_MATCHER = 3
 
 
 def matcher_variants():
@@ -145,9 +144,11 @@ def matcher_variants():
     return tuple(out[i] for i in range(min(n, 8)))
 
 
-def __getattr__(name):   # MATCHER_VARIANTS: resolved on first use (needs the library, not a device)
+def __getattr__(name):   # MATCHER_VARIANTS / DEFAULT_MATCHER: resolved on first use (need the library, not a device)
     if name == "MATCHER_VARIANTS":
         return matcher_variants()
+    if name == "DEFAULT_MATCHER":   # the build's default, or $VISO_MATCHER (viso_matcher_default)
+        return int(load().viso_matcher_default())
     raise AttributeError(name)
 
 

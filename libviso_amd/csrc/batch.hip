@@ -21,7 +21,7 @@ struct viso_batch {
     viso_ctx* ctx;
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
-    float2* kp; float* desc; int* n; uint16_t* packed; uint2* sums; int* bad_img; int* bad_any; int* zero;
+    float2* kp; float* desc; int* n; uint16_t* packed; uint8_t* packed8; uint2* sums; int* bad_img; int* bad_any; int* zero;
     float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // column-bucket view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
@@ -109,7 +109,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     for (int k = 0; k < VISO_NPIN_SLOTS; ++k) if (b->n_pin_ev[k]) note(hipEventDestroy(b->n_pin_ev[k]));
     if (b->n_pin) note(hipHostFree(b->n_pin));
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
-                    b->kp, b->desc, b->n, b->packed, b->sums, b->zero, b->probs, b->res, b->sorted,
+                    b->kp, b->desc, b->n, b->packed, b->packed8, b->sums, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
@@ -132,6 +132,7 @@ static int build_items(viso_batch* b) {
             v.bstart = b->bstart + i * (VISO_NB + 1); v.xinfo = b->xinfo + i * 8;
             v.rows = b->packed + i * dsi;
             v.sums = b->sums + i * kpi;
+            v.rows8 = b->packed8 + i * kpi * VISO_ROW8;
             v.qord = b->qord + i * (((size_t)cap + 63) & ~(size_t)63);
             v.bad = b->bad_img + i;
         }
@@ -230,7 +231,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
     A(dalloc(&b->kp, nf * 2 * c)); A(dalloc(&b->desc, nf * 2 * c * dlen)); A(dalloc(&b->n, nf * 2));
-    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->sums, nf * 2 * c)); A(dalloc(&b->zero, 8));
+    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->packed8, nf * 2 * c * VISO_ROW8)); A(dalloc(&b->sums, nf * 2 * c)); A(dalloc(&b->zero, 8));
     A(dalloc(&b->probs, (size_t)b->n_probs));
     A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 8)); A(dalloc(&b->views, nf * 2 + 1));
@@ -456,7 +457,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     int r;
     if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
-    const int with_sums = b->ctx->matcher_variant == 5;   // block sums: only match_prune_kernel reads them
+    const int with_sums = pack_extras(b->ctx->matcher_variant);   // block sums / 8-bit planes: what the selected temporal kernel reads
     // the run's counters (scored, ovf_cnt, bad_img, bad_any) are zeroed by the first kernel of the run, not by a memset
     if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap, reinterpret_cast<uint32_t*>(b->scored), (int)(b->zeroed_bytes / 4))) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])

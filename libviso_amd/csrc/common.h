@@ -7,6 +7,10 @@
 #include "../../include/viso_hip.h"
 
 #define VISO_ROW 128          // packed descriptor row: 128 x u16 = 256 B (121 used, rest = bias)
+#define VISO_ROW8 128         // bytes of a row's 8-bit plane (ImageView::rows8)
+#define VISO_ROW8_SLACK (7 * VISO_ROW8)   // 8 * SAD8 - SAD <= this (at most 128 elements count, each off by at most 7)
+#define VISO_PACK_SUMS 1      // pack kernels, `extras`: also write ImageView::sums (matcher variant 5)
+#define VISO_PACK_ROWS8 2     //                         also write ImageView::rows8 (matcher variant 6)
 #define VISO_BIAS 32768       // u16 = int16 value + 32768 (SAD is translation invariant)
 #define VISO_WAVE 64
 #define VISO_QCAP 256         // per-wave candidate queue entries
@@ -56,6 +60,10 @@ struct ImageView {               // one image's keypoints + descriptors on the d
                                  //     biased like the elements (4 x u16).  sum_k |S_q,k - S_t,k| <= SAD(q, t) (triangle
                                  //     inequality per block; clamping is 1-Lipschitz): the lower bound match_prune_kernel
                                  //     prunes candidates with.  Written by the pack kernels together with the rows.
+    uint8_t* rows8;              // [n][128] bucket order: the rows' 8-bit plane, element h(v) = clamp((v + 1024) >> 3, 0, 255) (pad
+                                 //     = h(0)).  8 |h(a) - h(b)| - 7 <= |a - b| for ANY a, b (floor and clamp are monotone and
+                                 //     1-Lipschitz in units of 8), so 8 SAD8 - 7 * 121 <= SAD: the lower bound match_union8_kernel
+                                 //     ranks candidates with.  Written by the pack kernels when matcher variant 6 is selected.
     int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
                                  //     every problem that reads the image then takes the general (double) kernel
 };
@@ -109,10 +117,11 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
-// with_sums != 0: also the rows' block sums (ImageView::sums), which only match_prune_kernel (matcher variant 5) reads
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int with_sums);
+// extras: VISO_PACK_SUMS / VISO_PACK_ROWS8 — what the selected matcher variant reads beside the u16 rows (pack_extras)
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras);
+static inline int pack_extras(int variant) { return variant == 5 ? VISO_PACK_SUMS : variant == 6 ? VISO_PACK_ROWS8 : 0; }
 // the same from int16 descriptors [n_img][cap][dlen] (viso_batch_upload_i16*): never flags anything
-int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int with_sums);
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras);
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt);
@@ -185,10 +194,11 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
                        const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
+int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
-                        int rows, int cols, int with_sums);
+                        int rows, int cols, int extras);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
 size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per);
 int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -30,7 +31,7 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     viso_ctx* c = new viso_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
-    c->matcher_variant = VISO_MATCHER_DEFAULT;
+    c->matcher_variant = viso_matcher_default();
     c->gn_split = 0;   // 0 = the build's default (VISO_GN_SPLIT, solver.hip)
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -71,15 +72,29 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
 
 static viso_ctx* ctx_or_default(viso_ctx* c) { return c ? c : viso_default_ctx(); }
 
+static bool matcher_known(int variant) {
+#ifdef VISO_DEBUG_VARIANTS
+    return variant >= 2 && variant <= 6;
+#else
+    return variant == 3 || variant == 5 || variant == 6;
+#endif
+}
+
+// The variant a new context starts with: the build's default, or $VISO_MATCHER when it names a variant of this build (a
+// test / A-B aid: the whole suite through another kernel without touching the callers).  Needs no device.
+extern "C" int viso_matcher_default(void) {
+    const char* e = getenv("VISO_MATCHER");
+    if (e && *e) {
+        const int v = atoi(e);
+        if (matcher_known(v)) return v;
+    }
+    return VISO_MATCHER_DEFAULT;
+}
+
 extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
     c = ctx_or_default(c);
     if (!c) return VISO_ERR_HIP;
-#ifdef VISO_DEBUG_VARIANTS
-    const bool known = variant >= 2 && variant <= 5;
-#else
-    const bool known = variant == 3 || variant == 5;
-#endif
-    if (!known) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
+    if (!matcher_known(variant)) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
     c->matcher_variant = variant;
     return VISO_OK;
 }
@@ -95,9 +110,9 @@ extern "C" int viso_ctx_set_gn_split(viso_ctx* c, int split) {
 // Variants this build of the library offers (no device needed): fills out[0..cap) and returns how many exist.
 extern "C" int viso_matcher_variants(int* out, int cap) {
 #ifdef VISO_DEBUG_VARIANTS
-    const int v[] = {2, 3, 4, 5};
+    const int v[] = {2, 3, 4, 5, 6};
 #else
-    const int v[] = {3, 5};
+    const int v[] = {3, 5, 6};
 #endif
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; out && i < n && i < cap; ++i) out[i] = v[i];
@@ -188,8 +203,8 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if ((r = ctx_scratch(c, 8, sizeof(int) * n1, (void**)&dpos)) < 0) return r;
     if ((r = ctx_scratch(c, 9, sizeof(int) * 16, (void**)&dmisc)) < 0) return r;
     if ((r = ctx_scratch(c, 10, sizeof(MatchProblem) + 2 * sizeof(ImageView), (void**)&dprob)) < 0) return r;
-    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64) + sums (8n), 16-B aligned pieces
-    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64 + ((8 * n + 15) / 16) * 16; };
+    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64) + sums (8n) + rows8 (128n), 16-B aligned pieces
+    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64 + ((8 * n + 15) / 16) * 16 + VISO_ROW8 * n; };
     if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
     int* dtile;
     if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
@@ -213,6 +228,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         v.xinfo = (float*)(tail + 4 * (VISO_NB + 1));
         v.qord = (uint8_t*)(tail + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16);
         v.sums = (uint2*)((unsigned char*)v.qord + ((n + 63) / 64) * 64);
+        v.rows8 = (uint8_t*)v.sums + ((8 * n + 15) / 16) * 16;
         return v;
     };
     MatchProblem P{};
@@ -234,7 +250,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         const int one[1] = {1};
         HIP_TRY(hipMemcpyAsync(dmisc + 2, one, sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(dmisc + 7, one, sizeof(int), hipMemcpyHostToDevice, s));
-    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, c->matcher_variant == 5)) < 0) return r;
+    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, pack_extras(c->matcher_variant))) < 0) return r;
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];

@@ -86,7 +86,7 @@ extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, 
 // in flight together, BORDER_REFLECT_101 applied to the coordinates), staged in LDS, then lane l produces elements
 // 2l and 2l+1 of every descriptor from LDS.
 __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __restrict__ imgs, int n_img, int cap,
-                                                           const uint8_t* __restrict__ images, int rows, int cols, int with_sums) {
+                                                           const uint8_t* __restrict__ images, int rows, int cols, int extras) {
     __shared__ unsigned char s_win[4][VISO_EXT_KPW][VISO_EXT_WIN * VISO_EXT_WIN + 7];
     typedef const __attribute__((address_space(1))) uint8_t* gbyte_t;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
         if (k >= nk) break;                       // wave uniform
         const unsigned char* win = s_win[wv][k];
         uint32_t packed = 0;
-        int vsum = 0;
+        int vsum = 0, v2[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 2 * lane + h;
@@ -158,22 +158,24 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
             }
             packed |= ((uint32_t)(v + VISO_BIAS) & 0xffffu) << (16 * h);
             vsum += v;
+            v2[h] = v;
         }
         reinterpret_cast<uint32_t*>(I.rows + (size_t)(j0 + k) * VISO_ROW)[lane] = packed;
-        if (with_sums) {   // uniform; ImageView::sums (match_prune_kernel)
+        if (extras & VISO_PACK_SUMS) {   // uniform; ImageView::sums (match_prune_kernel)
             const uint2 bs = pack_block_sums(vsum);
             if (lane == 0) I.sums[j0 + k] = bs;
         }
+        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)(j0 + k), lane, v2[0], v2[1]);   // uniform; match_union8_kernel
     }
 }
 
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
-                        int rows, int cols, int with_sums) {
+                        int rows, int cols, int extras) {
     const int capp = (cap + VISO_EXT_KPW - 1) / VISO_EXT_KPW * VISO_EXT_KPW;
     const long long waves = (long long)n_img * capp / VISO_EXT_KPW;
     if (waves == 0) return VISO_OK;
     hipLaunchKernelGGL(extract_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp,
-                       images, rows, cols, with_sums);
+                       images, rows, cols, extras);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

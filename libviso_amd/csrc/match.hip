@@ -165,7 +165,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 #define VISO_PACK_RPW 8   // rows per wave
 
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
-                                                        int cap, int dlen, int* __restrict__ bad_any, int with_sums) {
+                                                        int cap, int dlen, int* __restrict__ bad_any, int extras) {
     __shared__ __attribute__((aligned(16))) float s_buf[4][VISO_PACK_RPW * VISO_ROW];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) f32x4* gvec_t;
@@ -215,10 +215,11 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
         ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
         // block sums (ImageView::sums; only match_prune_kernel reads them): lanes 16b..16b+15 hold block b; meaningless
         // for flagged images (never read then)
-        if (with_sums) {   // uniform
+        if (extras & VISO_PACK_SUMS) {   // uniform
             const uint2 bs = pack_block_sums((int)ar + (int)br);
             if (lane == 0) I.sums[d] = bs;
         }
+        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, (int)ar, (int)br);   // uniform
     }
     if (__any(isbad) && lane == 0) { atomicOr(I.bad, 1); atomicOr(bad_any, 1); }
 }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
 // CV_32F Sobel windows, half the PCIe bytes).  desc16: [n_img][cap][dlen] int16, tightly packed; one wave = 8
 // consecutive rows = one contiguous 16-B aligned run of 8 * dlen * 2 bytes.  An int16 always fits the rows: no flag.
 __global__ __launch_bounds__(256) void pack_desc_i16_kernel(const ImageView* __restrict__ imgs, int n_img, int cap, int cap_stride,
-                                                            int dlen, const int16_t* __restrict__ desc16, int with_sums) {
+                                                            int dlen, const int16_t* __restrict__ desc16, int extras) {
     __shared__ __attribute__((aligned(16))) uint16_t s_buf[4][VISO_PACK_RPW * VISO_ROW];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* gvec_t;
@@ -268,20 +269,21 @@ __global__ __launch_bounds__(256) void pack_desc_i16_kernel(const ImageView* __r
         const uint32_t ua = (uint32_t)(a + VISO_BIAS) & 0xffffu, ub = (uint32_t)(b + VISO_BIAS) & 0xffffu;
         const int d = __builtin_amdgcn_readlane(dst, k);
         ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
-        if (with_sums) {   // uniform
+        if (extras & VISO_PACK_SUMS) {   // uniform
             const uint2 bs = pack_block_sums(a + b);
             if (lane == 0) I.sums[d] = bs;
         }
+        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, a, b);   // uniform
     }
 }
 
-int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int with_sums) {
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras) {
     if (n_img <= 0) return VISO_OK;
     if (dlen > VISO_ROW) { viso_set_error("int16 descriptors longer than %d are not supported", VISO_ROW); return VISO_ERR_UNSUPPORTED; }
     const int capp = (cap + VISO_PACK_RPW - 1) / VISO_PACK_RPW * VISO_PACK_RPW;
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
-    hipLaunchKernelGGL(pack_desc_i16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp, cap, dlen, desc16, with_sums);
+    hipLaunchKernelGGL(pack_desc_i16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp, cap, dlen, desc16, extras);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -292,7 +294,7 @@ __global__ void flag_all_kernel(int* flags, int n, int* any) {
     if (i == 0) *any = 1;
 }
 
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int with_sums) {
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras) {
     if (n_img <= 0) return VISO_OK;
     if (dlen > VISO_ROW) {  // rows do not fit the packed format: every image takes the general path
         hipLaunchKernelGGL(flag_all_kernel, dim3((n_img + 255) / 256), dim3(256), 0, s, bad_img, n_img, bad_any);
@@ -305,7 +307,7 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
     const int blocks = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any, with_sums);
+    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any, extras);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(VISO_WAVE) void match_overflow_kernel(MatchArgs a) 
 // 2 and 4 exist in -DVISO_DEBUG_VARIANTS builds only (make DEBUG_VARIANTS=1).
 // The stereo problems always take match_batch_kernel<1>.  Same results from all of them (the parity tests run over viso_matcher_variants(): a DEBUG_VARIANTS build gets all three tested).
 const char* matcher_kernel_name(int variant) {
-    return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : variant == 5 ? "match_prune_kernel" : "match_strip_kernel";
+    return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : variant == 5 ? "match_prune_kernel" : variant == 6 ? "match_union8_kernel" : "match_strip_kernel";
 }
 
 // layout 0: problems in any order (both instantiations enumerate all of them);

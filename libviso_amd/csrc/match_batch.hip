@@ -492,6 +492,9 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     if (variant == 5) {
         const int r = launch_match_prune_temporal(s, at, bt);
         if (r < 0) return r;
+    } else if (variant == 6) {
+        const int r = launch_match_union8_temporal(s, at, bt);
+        if (r < 0) return r;
     } else {
         const int r = launch_match_union_temporal(s, at, bt);
         if (r < 0) return r;

@@ -23,6 +23,25 @@ __device__ __forceinline__ uint2 pack_block_sums(int v) {
     return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
 }
 
+// 8-bit plane of a packed row (ImageView::rows8).  h is monotone and |h(a) - h(b)| <= (|a - b| + 7) / 8 for any ints.
+// The clamp comes FIRST and through inline asm: written as clamp((v + 1024) >> 3, 0, 255) on two values that are then
+// packed, hipcc 7.2 selects gfx950's v_ashr_pk_u8_i32 and treats bits 31:16 of its result as zero, while the hardware
+// leaves the destination's upper half as it was (0xffff where v + 1024 was negative: the neighbour's bytes of the plane
+// dword came out as 255; found by tests/test_gpu_union8.py, values below -1024).
+__device__ __forceinline__ uint32_t row8_of(int v) {
+    int x = v + 1024;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"(2047));
+    return (uint32_t)x >> 3;
+}
+
+// lane l holds elements 2l, 2l+1 of row `row` (pad elements as 0): the even lanes write the plane's dwords
+__device__ __forceinline__ void store_row8(uint8_t* rows8, size_t row, int lane, int va, int vb) {
+    const uint32_t h2 = row8_of(va) | (row8_of(vb) << 8);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h2, 0x101, 0xf, 0xf, true);   // row_shl:1: lane + 1's pair
+    if ((lane & 1) == 0)
+        ((__attribute__((address_space(1))) uint32_t*)reinterpret_cast<uint32_t*>(rows8 + row * VISO_ROW8))[lane >> 1] = h2 | (nb << 16);
+}
+
 // cvflann::L1<float> over 2 elements: result = 0; result += |a0-b0|; result += |a1-b1|
 __device__ __forceinline__ float l1_kp(float qx, float qy, float2 t) {
     float r = fabsf(qx - t.x);
