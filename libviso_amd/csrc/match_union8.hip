@@ -476,23 +476,90 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // verdict of the group's query (the same in its eight lanes)
         const bool mine = sub == 0 && gq_orig >= 0;   // lanes 8k of live queries
         const bool AisMin = !has2 || dA < dB;
-        const uint32_t d1 = AisMin ? dA : dB, d2 = AisMin ? dB : dA;
-        bool accept = !none, irregular = false;
+        uint32_t d1 = AisMin ? dA : dB;
+        uint32_t ewin = AisMin ? eA : eB;   // list entry of the winner
+        bool accept = !none, irregular = false, rescue = false;
         if (!none && has2) {
-            irregular = dA == dB;   // exact tie of the two: the overflow kernel applies the largest-key rule (or rejects)
+            const uint32_t d2 = AisMin ? dB : dA;
             const int L3 = (int)((tr.m3 >> 9) << 3) - VISO_ROW8_SLACK;   // <= SAD of every unscored candidate (has3)
             if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
                 const double lim = (double)d2 * mp.ratio;
                 accept = (double)d1 < lim;
-                if (has3) {
-                    const bool ok = accept ? (L3 > (int)d1 && (double)d1 < (double)L3 * mp.ratio) : ((double)L3 >= lim);
-                    irregular = irregular || !ok;
-                }
+                if (has3) rescue = !(accept ? (L3 > (int)d1 && (double)d1 < (double)L3 * mp.ratio) : ((double)L3 >= lim));
             } else if (has3) {
-                irregular = irregular || !(L3 > (int)d1);
+                rescue = !(L3 > (int)d1);
             }
+            // exact tie of the two: the overflow kernel applies the largest-key rule (or finds a smaller third)
+            if (dA == dB) { irregular = true; rescue = false; }
         } else if (!none && mp.second) {
             accept = (double)d1 < 1.7976931348623157e308 * mp.ratio;   // one candidate: best_d2 keeps its initial value
+        }
+        // ---------------- rescue: the two exact SADs and the third key's bound do not settle the query (0.3 % of the bench's
+        // queries; most of them when a query's SADs lie within the bound's slack of each other): the WAVE scores all its
+        // members exactly — 8 lanes per row over the round's list, (min, second min, argmin) as two
+        // packed keys SAD << 9 | position like match_union_kernel — instead of sending it to match_overflow_kernel (a
+        // kernel of its own behind this one: 36 us per step for these queries against ~1 us here)
+        {
+            unsigned long long rm = __ballot(rescue && sub == 0);   // bit 8k: query k
+            uint32_t r_m1 = 0xffffffffu, r_m2 = 0xffffffffu;
+            const int g8 = lane >> 3;
+            const int npass = (nu + 7) >> 3;
+            while (rm) {   // wave uniform
+                const int bit = __builtin_ctzll(rm);
+                rm &= rm - 1;
+                const int k = bit >> 3;
+                const int jq = min(__builtin_amdgcn_readlane(gq_j, bit), q1 - 1);
+                const grow_t rq = (grow_t)(qrows + (size_t)jq * (VISO_ROW * 2) + (sub << 4));
+                const u32x4 x0 = rq[0], x1 = rq[8];
+                const uint32_t msk = 31u - (uint32_t)k;
+                uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
+#define MU_SAD16(R0, R1)                                                                                   \
+                ({                                                                                         \
+                    uint32_t s_ = __builtin_amdgcn_sad_u16((R0).x, x0.x, 0u);                              \
+                    s_ = __builtin_amdgcn_sad_u16((R0).y, x0.y, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R0).z, x0.z, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R0).w, x0.w, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R1).x, x1.x, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R1).y, x1.y, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R1).z, x1.z, s_);                                       \
+                    s_ = __builtin_amdgcn_sad_u16((R1).w, x1.w, s_);                                       \
+                    s_ += mu_dpp<0xB1>(s_);                                          /* lane ^ 1 */        \
+                    s_ += mu_dpp<0x4E>(s_);                                          /* lane ^ 2 */        \
+                    s_ += (uint32_t)__builtin_amdgcn_ds_swizzle((int)s_, 0x101F);    /* lane ^ 4 */        \
+                    s_;                                                                                    \
+                })
+#define MU_UPD2(KEY) do { const uint32_t k_ = (KEY); m2 = mu_med3(m1, m2, k_); m1 = min(m1, k_); } while (0)
+                for (int t = 0; t < npass; ++t) {   // one pass at a time: two in flight cost 8 registers the kernel does not have
+                    const uint32_t e0 = ul[t * 8 + g8];
+                    const grow_t ra = (grow_t)(wrows + (((e0 & 0x00ffffffu) << 1) | (uint32_t)(sub << 4)));
+                    const u32x4 a0 = ra[0], a1 = ra[8];
+                    const uint32_t sa = MU_SAD16(a0, a1);
+                    // member of query k: bit 31 - k of the entry CLEAR; a non-member's key is all ones
+                    MU_UPD2(((sa << 9) | (uint32_t)(t * 8 + g8)) | (uint32_t)__builtin_amdgcn_sbfe((int)e0, msk, 1u));
+                }
+#undef MU_UPD2
+#undef MU_SAD16
+                // every lane of a group holds the group's keys: merge the 8 groups (lane ^ 8, ^ 16, ^ 32)
+#define MU_MRG2(O1, O2) do { const uint32_t o1_ = (O1), o2_ = (O2); m2 = min(max(m1, o1_), min(m2, o2_)); m1 = min(m1, o1_); } while (0)
+                MU_MRG2(mu_dpp<0x128>(m1), mu_dpp<0x128>(m2));
+                MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x401F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x401F));
+                {
+                    const auto h1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
+                    const auto h2 = __builtin_amdgcn_permlane32_swap(m2, m2, false, false);
+                    m1 = h1[0]; m2 = h2[0];
+                    MU_MRG2(h1[1], h2[1]);
+                }
+#undef MU_MRG2
+                if (g8 == k) { r_m1 = m1; r_m2 = m2; }
+            }
+            if (rescue) {   // the group's query, exact: min SAD, second smallest with multiplicity, argmin (keys are distinct)
+                d1 = r_m1 >> 9;
+                ewin = ul[r_m1 & 511u];
+                const bool has_second = r_m2 != 0xffffffffu;
+                irregular = has_second && (r_m2 >> 9) == d1;   // exact tie of the minimum: largest-key rule, overflow kernel
+                accept = true;
+                if (mp.second) accept = (double)d1 < (has_second ? (double)(r_m2 >> 9) : 1.7976931348623157e308) * mp.ratio;
+            }
         }
         // in-radius candidates per query (K cap, and what a query that leaves for the overflow kernel must not count):
         // no query can have more than the list holds, so they are only needed when the list is longer than K or a
@@ -513,12 +580,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         }
         if (mine) {
             if (list_ovf || my_cnt > K || irregular) {
-                // more than K candidates / union too long / a verdict the two exact SADs do not settle: overflow kernel
+                // more than K candidates / union too long / exact tie of the minimum: overflow kernel
                 P.ovf[atomicAdd(P.ovf_cnt, 1)] = make_int2(prob, gq_j);
             } else {
                 int idx = -1;
                 if (accept) {
-                    const int w = (int)(((AisMin ? eA : eB) & 0x00ffffffu) >> 7);   // window position of the winner
+                    const int w = (int)((ewin & 0x00ffffffu) >> 7);   // window position of the winner
                     idx = P.t.sidx[lo + w];
                 }
                 P.res[gq_orig] = make_int2(idx, none ? -1 : (int)d1);

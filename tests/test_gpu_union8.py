@@ -97,11 +97,12 @@ def _oracle_call(oracle, seq, which, t, st, tm):
                              st if which == 0 else tm, return_scored=True)
 
 
-@pytest.mark.parametrize("scale, expect_many_overflows", [(1.0, False), (0.04, True)])
-def test_counters_and_matches_whichever_path_a_query_takes(viso, oracle, scale, expect_many_overflows):
+@pytest.mark.parametrize("scale", [1.0, 0.04])
+def test_counters_and_matches_whichever_path_a_query_takes(viso, oracle, scale):
     """Image-sized frames through the batch pipeline.  scale 1: the bench's data, nearly every query is settled by its two
     exact SADs.  scale 0.04: descriptors squeezed into +-40, every SAD of a query within the slack of the others — the
-    third key never clears the bound and the queries leave for the overflow kernel: same matches, same counters."""
+    third key never clears the bound and the kernel's rescue loop scores all members of (nearly) every query exactly:
+    same matches, same counters; only exact ties of the minimum (and the K cap) still leave for the overflow kernel."""
     if V8 not in libviso_amd.MATCHER_VARIANTS:
         pytest.skip("this build has no variant 6")
     seq = synth.make_sequence(611, 3, n_kp=1500, width=900, height=300, ragged=True, dup_frac=0.03)
@@ -114,10 +115,7 @@ def test_counters_and_matches_whichever_path_a_query_takes(viso, oracle, scale, 
             want, wsc = _oracle_call(oracle, seq, which, t, st, tm)
             assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc, (scale, which, t)
     n_temporal = int(seq["n"][1:].sum())
-    if expect_many_overflows:
-        assert novf > n_temporal // 2, (novf, n_temporal)
-    else:
-        assert novf < n_temporal // 10, (novf, n_temporal)
+    assert novf < n_temporal // 10, (novf, n_temporal)
     b.close(); ctx.close()
 
 
