@@ -218,10 +218,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     const int half = lane >> 5;          // phase 1: lanes 0..31 test queries 0..3 of the round, lanes 32..63 queries 4..7
     unsigned long long scored = 0;
     constexpr int ROUNDS = MU_QPB / (MU_WAVES * MU_G);   // 2 rounds of 8 queries per wave
-    // which of the round's eight queries the lane tracks after the transposing reduction (phase 2): the partners of
-    // the three exchange steps (lane ^ 4, lane ^ 2, lane ^ 1 within the 8-lane group) differ in exactly one of these
-    const bool sel1 = ((lane >> 1) & 1) != 0, sel0 = (lane & 1) != 0;
-    const int myq = ((lane >> 2) & 1) + (sel1 ? 2 : 0) + (sel0 ? 4 : 0);
+    // which of the round's eight queries the lane tracks after the reduction of phase 2: query bit 1 = lane bit 2 (the first
+    // exchange step, lane ^ 4, keeps the pair (0,1 | 4,5) or (2,3 | 6,7)), query bit 2 = lane bit 1 (lane ^ 2 keeps the
+    // low or the high four), query bit 0 = lane bit 0 (which HALF of the packed pair the lane extracts at the end)
+    const bool sel1 = ((lane >> 1) & 1) != 0;
+    const int myq = (lane & 1) + 2 * ((lane >> 2) & 1) + (sel1 ? 4 : 0);
+    const uint32_t hoff = (uint32_t)(lane & 1) << 4;   // bit offset of the lane's half in a packed pair of totals
     const int msh = 31 - myq;   // membership bit of query myq in a list entry (bit 7 - k of the mask byte)
 
     // query data one round ahead: lane l carries local index / keypoint / original index of query (l & 3) + 4 * half
@@ -358,39 +360,43 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 const grow_t row_ = (grow_t)(wrows8 + ((ent_ & 0x00ffffffu) | (uint32_t)(sub << 4)));      \
                 r0[SLOT] = row_[0];                                                                        \
             } while (0)
-#define MU_SAD(K, SLOT)                                                                                    \
+            // SAD8 of queries 2J (low half) and 2J + 1 (high half, v_sad_hi_u8: (sad << 16) + accumulator) against the lane's
+            // 16 bytes of the row, in ONE register: a lane's share is <= 16 * 255 and a row's total <= 128 * 255 < 2^15, so
+            // the halves never carry into each other on the way through the reduction
+#define MU_SAD2(J, SLOT)                                                                                   \
             ({                                                                                             \
-                const u32x4 qa_ = *reinterpret_cast<const u32x4*>(&s_qrow[wave][K][sub * 4]);           \
+                const u32x4 qa_ = *reinterpret_cast<const u32x4*>(&s_qrow[wave][2 * (J)][sub * 4]);     \
+                const u32x4 qb_ = *reinterpret_cast<const u32x4*>(&s_qrow[wave][2 * (J) + 1][sub * 4]); \
                 uint32_t s_ = __builtin_amdgcn_sad_u8(r0[SLOT].x, qa_.x, 0u);                              \
                 s_ = __builtin_amdgcn_sad_u8(r0[SLOT].y, qa_.y, s_);                                       \
                 s_ = __builtin_amdgcn_sad_u8(r0[SLOT].z, qa_.z, s_);                                       \
                 s_ = __builtin_amdgcn_sad_u8(r0[SLOT].w, qa_.w, s_);                                       \
+                s_ = __builtin_amdgcn_sad_hi_u8(r0[SLOT].x, qb_.x, s_);                                    \
+                s_ = __builtin_amdgcn_sad_hi_u8(r0[SLOT].y, qb_.y, s_);                                    \
+                s_ = __builtin_amdgcn_sad_hi_u8(r0[SLOT].z, qb_.z, s_);                                    \
+                s_ = __builtin_amdgcn_sad_hi_u8(r0[SLOT].w, qb_.w, s_);                                    \
                 s_;                                                                                        \
             })
-#define MU_X1(A, B) ({ uint32_t k_ = sel0 ? (B) : (A); const uint32_t g_ = sel0 ? (A) : (B); k_ += mu_dpp<0xB1>(g_); k_; })   /* lane ^ 1 */
 #define MU_X2(A, B) ({ uint32_t k_ = sel1 ? (B) : (A); const uint32_t g_ = sel1 ? (A) : (B); k_ += mu_dpp<0x4E>(g_); k_; })   /* lane ^ 2 */
-            // first exchange step, lane ^ 4, on all four pairs at once: two bank-masked v_add_u32_dpp per pair (see
-            // match_union.hip); one asm block behind an s_nop 1 (DPP reads inside inline asm are invisible to the
-            // compiler's hazard recognizer)
-#define MU_X4x4(S0, S1, S2, S3, S4, S5, S6, S7)                                                            \
+            // first exchange step, lane ^ 4, on both pairs of registers at once: a lane's bit 2 is its DPP BANK, so "keep A
+            // and add the partner's A" / "keep B and add the partner's B" are two bank-masked v_add_u32_dpp (banks 0, 2 take
+            // A + A[lane + 4], banks 1, 3 take B + B[lane - 4]) instead of two selects and an add.  One asm block behind an
+            // s_nop 1: the compiler's hazard recognizer does not see DPP reads inside inline asm (a VGPR written by the
+            // previous two VALU instructions must not be a DPP source); inside the block every source is older than that
+#define MU_X4x2(S0, S1, S2, S3)                                                                            \
             asm("s_nop 1\n\t"                                                                              \
                 "v_add_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
                 "v_add_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
-                "v_add_u32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
-                "v_add_u32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                         \
-                "v_add_u32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
-                "v_add_u32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
-                "v_add_u32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
-                "v_add_u32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa"                              \
-                : "+v"(S0), "+v"(S2), "+v"(S4), "+v"(S6) : "v"(S1), "v"(S3), "v"(S5), "v"(S7))
+                "v_add_u32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
+                "v_add_u32_dpp %1, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa"                              \
+                : "+v"(S0), "+v"(S2) : "v"(S1), "v"(S3))
 #define MU_REDUCE(SLOT)                                                                                   \
             do {                                                                                           \
-                uint32_t s0_ = MU_SAD(0, SLOT), s1_ = MU_SAD(1, SLOT), s2_ = MU_SAD(2, SLOT), s3_ = MU_SAD(3, SLOT); \
-                uint32_t s4_ = MU_SAD(4, SLOT), s5_ = MU_SAD(5, SLOT), s6_ = MU_SAD(6, SLOT), s7_ = MU_SAD(7, SLOT); \
-                MU_X4x4(s0_, s1_, s2_, s3_, s4_, s5_, s6_, s7_);   /* s0_ s2_ s4_ s6_: queries (0|1) (2|3) (4|5) (6|7) by bit 2 */ \
-                const uint32_t c0_ = MU_X2(s0_, s2_), c1_ = MU_X2(s4_, s6_);                               \
-                const uint32_t m_ = MU_X1(c0_, c1_);                                                       \
-                mu_update(tr, (m_ << 9) | un[SLOT]);                                                       \
+                uint32_t p0_ = MU_SAD2(0, SLOT), p1_ = MU_SAD2(1, SLOT), p2_ = MU_SAD2(2, SLOT), p3_ = MU_SAD2(3, SLOT); \
+                MU_X4x2(p0_, p1_, p2_, p3_);   /* p0_: queries (0,1) or (2,3) by lane bit 2; p2_: (4,5) or (6,7) */ \
+                uint32_t c_ = MU_X2(p0_, p2_);                                                             \
+                c_ += mu_dpp<0xB1>(c_);        /* lane ^ 1: both lanes hold the pair's two totals */       \
+                mu_update(tr, (__builtin_amdgcn_ubfe(c_, hoff, 16u) << 9) | un[SLOT]);                     \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -412,10 +418,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     if (t + p < npass) MU_REDUCE(p);
             }
 #undef MU_REDUCE
-#undef MU_X4x4
+#undef MU_X4x2
 #undef MU_X2
-#undef MU_X1
-#undef MU_SAD
+#undef MU_SAD2
 #undef MU_ISSUE
         }
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
@@ -436,9 +441,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             o.m1 = h1[1]; o.m2 = h2[1]; o.m3 = h3[1];
             mu_merge(tr, o);
         }
-        {   // lane group g takes query g: its keys sit in the group's lane with myq == g (lane bits (2, 1, 0) = query bits (0, 1, 2))
+        {   // lane group g takes query g: its keys sit in the group's lane with myq == g (lane bits (0, 2, 1) = query bits (0, 1, 2))
             const int k = lane >> 3;
-            const int src = (lane & 0x38) | ((k & 1) << 2) | (k & 2) | (k >> 2);
+            const int src = (lane & 0x38) | (k & 1) | ((k & 2) << 1) | ((k & 4) >> 1);
             tr.m1 = (uint32_t)__shfl((int)tr.m1, src);
             tr.m2 = (uint32_t)__shfl((int)tr.m2, src);
             tr.m3 = (uint32_t)__shfl((int)tr.m3, src);
