@@ -131,7 +131,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
                        const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant,
                        const int2* ovf_q, const int* ovf_cnt, int general_possible = 1);
 const char* matcher_kernel_name(int variant);
-#define VISO_MATCHER_DEFAULT 3
+#define VISO_MATCHER_DEFAULT 6
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);

@@ -903,11 +903,14 @@ __global__ __launch_bounds__(VISO_WAVE) void match_overflow_kernel(MatchArgs a) 
 }
 
 // Which kernel takes the temporal problems of the u16 path (viso_ctx_set_matcher, per context):
-//   3 = match_union_kernel  (rows gathered from L2, one load scored against four queries, match_union.hip)   <- default
+//   6 = match_union8_kernel (match_union8.hip: the union pass on the rows' 8-bit planes, the two best scored exactly)  <- default
+//   3 = match_union_kernel  (match_union.hip: rows gathered from L2, every row scored against eight queries on the u16 rows)
+//   5 = match_prune_kernel  (match_prune.hip: exact successive elimination on block sums, cell-granular scorer)
 //   4 = match_strip_kernel  (window rows resident in LDS, tools/experiments/match_strip.hip: 0.60 ms against 0.44 ms)
 //   2 = match_batch_kernel<0> (rows gathered from L2, one pair per 8-lane group, match_batch.hip: 0.63 ms)
 // 2 and 4 exist in -DVISO_DEBUG_VARIANTS builds only (make DEBUG_VARIANTS=1).
-// The stereo problems always take match_batch_kernel<1>.  Same results from all of them (the parity tests run over viso_matcher_variants(): a DEBUG_VARIANTS build gets all three tested).
+// The stereo problems always take match_stereo_kernel / match_batch_kernel<1>.  Same results from all of them (the parity
+// tests run over viso_matcher_variants()).
 const char* matcher_kernel_name(int variant) {
     return variant == 2 ? "match_batch_kernel<0>" : variant == 3 ? "match_union_kernel" : variant == 5 ? "match_prune_kernel" : variant == 6 ? "match_union8_kernel" : "match_strip_kernel";
 }
