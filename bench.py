@@ -11,7 +11,7 @@ final sort).  The same JSON line also carries
                uploads (feature-in and image-in): the PCIe-inclusive rate
   roofline     the dominant kernel against the ceilings that can bound it, each
                a fraction <= 1: HBM (PMC bytes), L2 (PMC requests), VALU issue
-               (PMC instructions), v_sad_u16 issue (scored pairs); kernel time
+               (PMC instructions), v_sad_u8 / v_sad_u16 issue (scored pairs); kernel time
                from a single-stream pass measured live with HIP events
   cpu_baseline the CPU oracle on the host cores: per stage, matcher-only and
                end to end on one thread, and frames-parallel on all cores
@@ -416,13 +416,20 @@ def main():
     default_workload = (args.frames, args.kp, args.width, args.height, args.clustered) == (512, 2000, 1241, 376, 0.0)
     pmc = load_pmc(kname, default_workload)
     ceilings = {}
-    # (iv) the arithmetic this path exists for: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores 128
-    # elements = one (query, candidate) pair; v_sad_u16 is a half-rate opcode (one per 4 cycles per SIMD)
-    sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_SAD
+    # (iv) the arithmetic this path exists for.  u16 kernels: one v_sad_u16 wave-instruction (64 lanes x 2 elements) scores
+    # 128 elements = one (query, candidate) pair.  match_union8_kernel ranks every pair on the rows' 8-bit planes: one
+    # v_sad_u8 / v_sad_hi_u8 wave-instruction (64 lanes x 4 elements) scores TWO pairs, and only the two best candidates
+    # of a query are scored again on the u16 rows.  All of them are half-rate opcodes (one per 4 cycles per SIMD)
+    u8_kernel = kname == "match_union8_kernel"
+    sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_SAD * (2 if u8_kernel else 1)
     valu_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_FULL
     ceilings["sad_valu"] = {"achieved": pairs / t_k, "peak": sad_peak, "unit": "scored pairs/s",
                             "frac": pairs / t_k / sad_peak,
-                            "what": "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each; a half-rate opcode: 4 cycles per wave-instruction per SIMD (tools/valu_rate.hip measures 4.56), 1024 SIMDs at 2.4 GHz"}
+                            "what": ("useful v_sad_u8 issue: scored pairs (device counter) x HALF a wave-instruction each (a pair is 128 byte "
+                                     "elements, an instruction does 256); the two exact v_sad_u16 scorings per query are not counted as useful"
+                                     if u8_kernel else
+                                     "useful v_sad_u16 issue: scored pairs (device counter) x 1 wave-instruction each")
+                                    + "; a half-rate opcode: 4 cycles per wave-instruction per SIMD (tools/valu_rate.hip measures 4.56), 1024 SIMDs at 2.4 GHz"}
     valu_busy = None
     if pmc["hbm_bytes"] is not None:
         a = pmc["hbm_bytes"] / t_k / 1e9
@@ -435,7 +442,7 @@ def main():
             ceilings["valu_issue"] = {"achieved": a, "peak": valu_peak, "unit": "VALU wave-instructions/s", "frac": a / valu_peak,
                                       "what": "SQ_INSTS_VALU / kernel time against the NOMINAL issue rate (every opcode at the full rate: "
                                               "one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz). ~90 % of the kernel's "
-                                              "instructions are half-rate opcodes (v_sad_u16, DPP adds, selects, v_med3/v_min): see valu_busy"}
+                                              "instructions are half-rate opcodes (v_sad_u8 / v_sad_u16, DPP adds, selects, v_med3/v_min): see valu_busy"}
             if "SQ_ACTIVE_INST_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
                 cyc = sq["GRBM_GUI_ACTIVE"] / 8.0            # rocprofv3 sums the 8 XCDs: shader cycles of one launch
                 valu_busy = {"rocprof_VALUBusy": sq["SQ_ACTIVE_INST_VALU"] / 256.0 / cyc,
@@ -502,6 +509,7 @@ def main():
         "scored_pairs_per_launch": pairs,
         "overflow_queries_per_step": n_overflow,
         "overflow_note": "queries of one step (all three calls) handed to match_overflow_kernel: K cap, exact SAD tie, LDS list overflow",
+        "rows8_note": ("the pack kernels also write the rows' 8-bit planes (128 B per keypoint) for this kernel: inside the timed step" if u8_kernel else None),
         "effective_bandwidth": {"algorithmic_bytes_per_launch": balg_temporal, "GB/s": balg_temporal / t_k / 1e9,
                                 "note": "SURVEY 8(d) B_alg (every scored pair counted as a fresh 484-B f32 row) / kernel time: an "
                                         "effective figure served by L2/LDS, not comparable with the HBM peak"},

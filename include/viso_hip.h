@@ -88,13 +88,14 @@ int viso_ctx_destroy(viso_ctx* ctx);
 void* viso_ctx_stream(viso_ctx* ctx);
 int viso_ctx_synchronize(viso_ctx* ctx);
 /* Which kernel takes the temporal match_desc calls of this context (ctx == NULL: the default context of the
- * plain family).  The product build offers two: 3 = match_union_kernel (the default: rows gathered from the XCD's L2,
- * a wave scores every row it loads against eight y-adjacent queries; vector-ALU bound) and
- * 5 = match_prune_kernel (exact successive elimination on block sums in front of a cell-granular scorer; as fast, its
- * cost falls with the share of queries that have a distinctive match).  Further variants (2 = match_batch_kernel<0>,
- * 4 = match_strip_kernel) exist in -DVISO_DEBUG_VARIANTS builds only.  Every variant gives identical results, and the
- * parity tests run over whatever viso_matcher_variants() reports for the build under test.  Returns VISO_ERR_ARG for a
- * variant this build does not have. */
+ * plain family).  The product build offers three: 6 = match_union8_kernel (the default: a wave ranks every row of a
+ * round's union list against eight y-adjacent queries on the rows' 8-bit planes, scores the two best candidates of a
+ * query exactly, and lets a rigorous lower bound of the rest decide whether that settles match_desc),
+ * 3 = match_union_kernel (the same round structure on the u16 rows: every pair scored exactly; the default until
+ * round 4) and 5 = match_prune_kernel (exact successive elimination on block sums in front of a cell-granular scorer).
+ * Further variants (2 = match_batch_kernel<0>, 4 = match_strip_kernel) exist in -DVISO_DEBUG_VARIANTS builds only.
+ * Every variant gives identical results, and the parity tests run over whatever viso_matcher_variants() reports for
+ * the build under test.  Returns VISO_ERR_ARG for a variant this build does not have. */
 int viso_ctx_set_matcher(viso_ctx* ctx, int variant);
 /* The variants of this build: fills out[0..cap), returns their number.  Needs no device. */
 int viso_matcher_variants(int* out, int cap);

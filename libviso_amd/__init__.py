@@ -136,9 +136,9 @@ def _i32(a):
 
 
 def matcher_variants():
-    """What this build of libviso_hip.so offers (viso_ctx_set_matcher): (3, 5) for the product build — match_union_kernel
-    (default) and match_prune_kernel — and (2, 3, 4, 5) for `make DEBUG_VARIANTS=1`.  Asked of the library itself, so a
-    debug build gets its variants tested."""
+    """What this build of libviso_hip.so offers (viso_ctx_set_matcher): (3, 5, 6) for the product build —
+    match_union_kernel, match_prune_kernel and match_union8_kernel (6, the default) — and (2, 3, 4, 5, 6) for
+    `make DEBUG_VARIANTS=1`.  Asked of the library itself, so a debug build gets its variants tested."""
     out = (C.c_int * 8)()
     n = load().viso_matcher_variants(out, 8)
     return tuple(out[i] for i in range(min(n, 8)))
