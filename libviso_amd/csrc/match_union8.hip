@@ -33,6 +33,8 @@
 #ifndef MU_NP
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
 #endif
+#define MU_S8ROWS 176      // list positions whose SAD8 (in units of 128: one byte) is kept per query for the rescue (with this much
+                           // LDS 7 workgroups per CU still fit; the bench's lists hold 94 rows on average)
 #define MU_KPCAP 512       // window keypoints staged in LDS
 #define MU_NBY 64          // y buckets of the staged window
 
@@ -102,6 +104,7 @@ __device__ __forceinline__ constexpr int mu_qlane(int k) { return (k & 3) + 32 *
 __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union8_kernel(BatchMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][32];   // the round's query rows, 8-bit planes
+    __shared__ uint8_t s_s8[MU_WAVES][MU_G][MU_S8ROWS];   // SAD8 >> 7 of (query, list position) of the round: what the rescue selects from
     __shared__ float2 s_ykp[MU_KPCAP];       // staged window keypoints in y-bucket order
     __shared__ uint16_t s_ypos[MU_KPCAP];    // their window positions
     __shared__ int s_ys[MU_NBY + 1];         // bucket counts, then bucket starts
@@ -162,6 +165,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         if (ty1 > ty0) yscale = (float)MU_NBY / (ty1 - ty0);
         if (!(yscale > 0.f) || !(yscale < 3.0e38f)) yscale = 0.f;
     }
+    // wave-uniform floats belong in scalar registers (the vector ALU takes one as an operand): four VGPRs less
+    ty0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ty0)));
+    yscale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(yscale)));
     static_assert(MU_KPCAP <= 2 * MU_THREADS, "two window entries per thread");
     float2 e_kp[2];
     int e_b[2], e_r[2];
@@ -178,6 +184,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     float2 kp0 = make_float2(0.f, 0.f);
     const bool has0 = n2 > 0;
     if (has0) kp0 = P.t.skp[P.t.rank[0]];
+    kp0.x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(kp0.x)));
+    kp0.y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(kp0.y)));
     __syncthreads();
     if (wave == 0) {
         const int h = s_ys[lane];
@@ -213,6 +221,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     const gbytes_t wrows8 = (gbytes_t)reinterpret_cast<const char*>(P.t.rows8) + (size_t)lo * VISO_ROW8;
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
     const gbytes_t qrows = (gbytes_t)reinterpret_cast<const char*>(P.q.rows);
+    const gbytes_t qrows8 = (gbytes_t)reinterpret_cast<const char*>(P.q.rows8);
     uint32_t* ul = s_ul[wave];
     const int sub = lane & 7;
     const int half = lane >> 5;          // phase 1: lanes 0..31 test queries 0..3 of the round, lanes 32..63 queries 4..7
@@ -243,6 +252,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     } while (0)
     MU_PREFETCH(0);
 
+#pragma unroll   // both rounds inline: left rolled (the compiler's choice once the body grew) the loop spills 22 registers
     for (int r = 0; r < ROUNDS; ++r) {
         // ---------------- round setup.  Lane l holds query (l & 3) + 4 * half: the four queries its half tests in phase 1
         // are the four lanes of its quad (DPP quad broadcasts, no scalar traffic)
@@ -277,7 +287,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         for (int k = 0; k < MU_G / 2; ++k) {
             const int je = __builtin_amdgcn_readlane(pli, mu_qlane(2 * k)), jo = __builtin_amdgcn_readlane(pli, mu_qlane(2 * k + 1));
             const int jk = q0 + (half ? jo : je);
-            qw[k] = ((const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(P.q.rows8))[(size_t)min(jk, q1 - 1) * (VISO_ROW8 / 4) + (lane & 31)];
+            qw[k] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + ((uint32_t)min(jk, q1 - 1) * (uint32_t)VISO_ROW8 + (uint32_t)((lane & 31) << 2)));   // scalar base + 32-bit offset
         }
         if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
         // ---------------- phase 1: one scan over the y buckets the round's diamonds touch, 32 targets per step: both
@@ -353,6 +363,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             g8 >>= 3;
             u32x4 r0[MU_NP];
             uint32_t un[MU_NP];   // the pass's list position for the tracker key, all ones where the lane's query is not a member
+            // LDS byte address of the lane's SAD8 slot of pass 0 (query myq, list position g8)
+            const uint32_t s8w = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)&s_s8[wave][myq][g8];
+            uint32_t s8a = s8w;
 #define MU_ISSUE(SLOT, T)                                                                                  \
             do {                                                                                           \
                 const uint32_t ent_ = ul[(T) * 8 + g8];                                                    \
@@ -390,13 +403,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 "v_add_u32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                         \
                 "v_add_u32_dpp %1, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa"                              \
                 : "+v"(S0), "+v"(S2) : "v"(S1), "v"(S3))
-#define MU_REDUCE(SLOT)                                                                                   \
+#define MU_REDUCE(SLOT, T)                                                                                \
             do {                                                                                           \
                 uint32_t p0_ = MU_SAD2(0, SLOT), p1_ = MU_SAD2(1, SLOT), p2_ = MU_SAD2(2, SLOT), p3_ = MU_SAD2(3, SLOT); \
                 MU_X4x2(p0_, p1_, p2_, p3_);   /* p0_: queries (0,1) or (2,3) by lane bit 2; p2_: (4,5) or (6,7) */ \
                 uint32_t c_ = MU_X2(p0_, p2_);                                                             \
                 c_ += mu_dpp<0xB1>(c_);        /* lane ^ 1: both lanes hold the pair's two totals */       \
-                mu_update(tr, (__builtin_amdgcn_ubfe(c_, hoff, 16u) << 9) | un[SLOT]);                     \
+                const uint32_t m_ = __builtin_amdgcn_ubfe(c_, hoff, 16u);                                  \
+                /* members and non-members alike; lists longer than the store pile up in its last row (the rescue then leaves   */ \
+                /* them to the overflow kernel).  As asm: a C store into LDS between the pipeline's LDS reads made the       */ \
+                /* register allocator spill 26 registers                                                                      */ \
+                asm volatile("ds_write_b8 %0, %1" : : "v"(s8a), "v"(m_ >> 7));   /* SAD8 < 2^15 */          \
+                s8a = min(s8a + 8u, s8w + (MU_S8ROWS / 8 - 1) * 8u);   /* a running address: an index min(T, ..) of the loop counter made the compiler spill 24 registers */ \
+                mu_update(tr, (m_ << 9) | un[SLOT]);                                                       \
             } while (0)
             if (npass > 0) {
 #pragma unroll
@@ -406,7 +425,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             for (; t + MU_NP < npass; t += MU_NP) {   // steady state: no branch between reduce and refill
 #pragma unroll
                 for (int p = 0; p < MU_NP; ++p) {
-                    MU_REDUCE(p);
+                    MU_REDUCE(p, t + p);
                     __builtin_amdgcn_sched_barrier(0);   // keep the refill of this slot HERE (see match_union.hip)
                     MU_ISSUE(p, t + p + MU_NP);
                     __builtin_amdgcn_sched_barrier(0);
@@ -415,7 +434,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             if (npass > 0) {   // the last passes (no pass of padding is scored)
 #pragma unroll
                 for (int p = 0; p < MU_NP; ++p)
-                    if (t + p < npass) MU_REDUCE(p);
+                    if (t + p < npass) MU_REDUCE(p, t + p);
             }
 #undef MU_REDUCE
 #undef MU_X4x2
@@ -457,7 +476,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         if (__any(!none)) {   // wave uniform
             const grow_t ra = (grow_t)(wrows + (((eA & 0x00ffffffu) << 1) | (uint32_t)(sub << 4)));
             const grow_t rb = (grow_t)(wrows + (((eB & 0x00ffffffu) << 1) | (uint32_t)(sub << 4)));
-            const grow_t rq = (grow_t)(qrows + (size_t)min(gq_j, q1 - 1) * (VISO_ROW * 2) + (sub << 4));
+            const grow_t rq = (grow_t)(qrows + ((uint32_t)min(gq_j, q1 - 1) * (uint32_t)(VISO_ROW * 2) + (uint32_t)(sub << 4)));   // scalar base + 32-bit offset
             const u32x4 a0 = ra[0], a1 = ra[8], b0 = rb[0], b1 = rb[8], x0 = rq[0], x1 = rq[8];
 #define MU_SAD16(R0, R1)                                                                                   \
             ({                                                                                             \
@@ -478,14 +497,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             dB = MU_SAD16(b0, b1);
 #undef MU_SAD16
         }
-        // verdict of the group's query (the same in its eight lanes)
+        // verdict of the group's query (the same in its eight lanes); the two exact candidates as keys SAD << 9 | list position
         const bool mine = sub == 0 && gq_orig >= 0;   // lanes 8k of live queries
-        const bool AisMin = !has2 || dA < dB;
-        uint32_t d1 = AisMin ? dA : dB;
-        uint32_t ewin = AisMin ? eA : eB;   // list entry of the winner
+        uint32_t kA = none ? 0xffffffffu : ((dA << 9) | (tr.m1 & 511u)), kB = has2 ? ((dB << 9) | (tr.m2 & 511u)) : 0xffffffffu;
         bool accept = !none, irregular = false, rescue = false;
         if (!none && has2) {
-            const uint32_t d2 = AisMin ? dB : dA;
+            const uint32_t d1 = min(dA, dB), d2 = max(dA, dB);
             const int L3 = (int)((tr.m3 >> 9) << 3) - VISO_ROW8_SLACK;   // <= SAD of every unscored candidate (has3)
             if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
                 const double lim = (double)d2 * mp.ratio;
@@ -497,75 +514,119 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
             // exact tie of the two: the overflow kernel applies the largest-key rule (or finds a smaller third)
             if (dA == dB) { irregular = true; rescue = false; }
         } else if (!none && mp.second) {
-            accept = (double)d1 < 1.7976931348623157e308 * mp.ratio;   // one candidate: best_d2 keeps its initial value
+            accept = (double)dA < 1.7976931348623157e308 * mp.ratio;   // one candidate: best_d2 keeps its initial value
         }
         // ---------------- rescue: the two exact SADs and the third key's bound do not settle the query (0.3 % of the bench's
-        // queries; most of them when a query's SADs lie within the bound's slack of each other): the WAVE scores all its
-        // members exactly — 8 lanes per row over the round's list, (min, second min, argmin) as two
-        // packed keys SAD << 9 | position like match_union_kernel — instead of sending it to match_overflow_kernel (a
-        // kernel of its own behind this one: 36 us per step for these queries against ~1 us here)
+        // queries; many more where SADs lie within the bound's slack of each other: low-contrast descriptors, repeated
+        // texture).  Phase 2 left every cell's SAD8 (in units of 128) in LDS: the WAVE picks the query's members whose bound
+        // L fails the very test the third key failed (the two it has already scored excepted), scores them exactly — their
+        // list positions compacted into LDS, four lanes per row, the query's u16 row read from LDS, (min, second min,
+        // argmin) as two packed keys SAD << 9 | position — and takes the verdict again over those and the first two.  What
+        // the new verdict needs of the unscored ones follows from the test they passed (the minimum can only have fallen,
+        // and with it both thresholds), unless a REJECT turned into an accept: then the selection runs once more with the
+        // accept's test (scored cells are marked).  Rounds whose list is longer than the SAD8 store (dense keypoints) leave
+        // such queries to match_overflow_kernel, as every query of this kind would otherwise: 36 us of that kernel per step
+        // for the bench's few, against ~1 us here
         {
+            asm volatile("" ::: "memory");   // phase 2 wrote s_s8 through asm: nothing below may be moved above it
             unsigned long long rm = __ballot(rescue && sub == 0);   // bit 8k: query k
-            uint32_t r_m1 = 0xffffffffu, r_m2 = 0xffffffffu;
             const int g8 = lane >> 3;
-            const int npass = (nu + 7) >> 3;
+            uint16_t* ml = reinterpret_cast<uint16_t*>(&s_qrow[wave][0][0]);   // survivors' list positions (the planes' staging area is free by now)
+            uint32_t* qst = &s_qrow[wave][4][0];                                // the query's u16 row: 64 dwords
+            static_assert(MU_S8ROWS <= 256, "the survivor list holds every position that may survive");
+            if (nu > MU_S8ROWS) {   // wave uniform: not every cell's SAD8 was kept (dense data): overflow kernel
+                rm = 0;
+                if (rescue) { irregular = true; rescue = false; }
+            }
+#define MU_UPD2(KEY) do { const uint32_t k_ = (KEY); m2 = mu_med3(m1, m2, k_); m1 = min(m1, k_); } while (0)
             while (rm) {   // wave uniform
                 const int bit = __builtin_ctzll(rm);
                 rm &= rm - 1;
                 const int k = bit >> 3;
                 const int jq = min(__builtin_amdgcn_readlane(gq_j, bit), q1 - 1);
-                const grow_t rq = (grow_t)(qrows + (size_t)jq * (VISO_ROW * 2) + (sub << 4));
-                const u32x4 x0 = rq[0], x1 = rq[8];
+                const uint32_t ka = (uint32_t)__builtin_amdgcn_readlane((int)kA, bit), kb = (uint32_t)__builtin_amdgcn_readlane((int)kB, bit);
+                const uint32_t pa = ka & 511u, pb = kb & 511u;
+                const int d1k = (int)(min(ka, kb) >> 9);
+                const double limk = (double)(max(ka, kb) >> 9) * mp.ratio;
+                const bool acck = !mp.second || (double)d1k < limk;   // the verdict of the two smallest exact SADs so far, as above
                 const uint32_t msk = 31u - (uint32_t)k;
+                __builtin_amdgcn_wave_barrier();
+                qst[lane] = *(const __attribute__((address_space(1))) uint32_t*)(qrows + ((uint32_t)jq * (uint32_t)(VISO_ROW * 2) + (uint32_t)(lane << 2)));
+                int nm = 0;
+                for (int b = 0; b < nu; b += VISO_WAVE) {   // nu <= MU_S8ROWS: three steps at most
+                    const uint32_t i = (uint32_t)(b + lane);
+                    bool sel = false;
+                    if (i < (uint32_t)nu) {
+                        const uint32_t e = ul[i];
+                        const uint32_t q8 = s_s8[wave][k][i];   // floor(SAD8 / 128), or 255: scored exactly already
+                        const int Lt = (int)(q8 << 10) - VISO_ROW8_SLACK;   // <= 8 SAD8 - slack <= SAD
+                        // can the candidate be ignored?  accept: it is not the minimum, does not tie it and passes :715 as the
+                        // second best; reject: it is above the limit the minimum must stay below
+                        const bool clear = q8 == 255u || (!mp.second ? Lt > d1k : (acck ? (Lt > d1k && (double)d1k < (double)Lt * mp.ratio) : ((double)Lt >= limk)));
+                        sel = ((e >> msk) & 1u) == 0 && !clear && i != pa && i != pb;
+                        if (sel) s_s8[wave][k][i] = 255;   // scored below: never again
+                    }
+                    const unsigned long long bal = __ballot(sel);
+                    if (sel) ml[nm + mbcnt(bal)] = (uint16_t)i;
+                    nm += __popcll(bal);
+                }
+                // FOUR lanes per survivor, sixteen survivors per step (a rare path: short code and few registers matter more
+                // than coalescing): a lane walks its quarter of the row in four 16-byte pieces against the query's row in LDS
+                __builtin_amdgcn_wave_barrier();
                 uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
-#define MU_SAD16(R0, R1)                                                                                   \
-                ({                                                                                         \
-                    uint32_t s_ = __builtin_amdgcn_sad_u16((R0).x, x0.x, 0u);                              \
-                    s_ = __builtin_amdgcn_sad_u16((R0).y, x0.y, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R0).z, x0.z, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R0).w, x0.w, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R1).x, x1.x, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R1).y, x1.y, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R1).z, x1.z, s_);                                       \
-                    s_ = __builtin_amdgcn_sad_u16((R1).w, x1.w, s_);                                       \
-                    s_ += mu_dpp<0xB1>(s_);                                          /* lane ^ 1 */        \
-                    s_ += mu_dpp<0x4E>(s_);                                          /* lane ^ 2 */        \
-                    s_ += (uint32_t)__builtin_amdgcn_ds_swizzle((int)s_, 0x101F);    /* lane ^ 4 */        \
-                    s_;                                                                                    \
-                })
-#define MU_UPD2(KEY) do { const uint32_t k_ = (KEY); m2 = mu_med3(m1, m2, k_); m1 = min(m1, k_); } while (0)
-                for (int t = 0; t < npass; ++t) {   // one pass at a time: two in flight cost 8 registers the kernel does not have
-                    const uint32_t e0 = ul[t * 8 + g8];
-                    const grow_t ra = (grow_t)(wrows + (((e0 & 0x00ffffffu) << 1) | (uint32_t)(sub << 4)));
-                    const u32x4 a0 = ra[0], a1 = ra[8];
-                    const uint32_t sa = MU_SAD16(a0, a1);
-                    // member of query k: bit 31 - k of the entry CLEAR; a non-member's key is all ones
-                    MU_UPD2(((sa << 9) | (uint32_t)(t * 8 + g8)) | (uint32_t)__builtin_amdgcn_sbfe((int)e0, msk, 1u));
-                }
-#undef MU_UPD2
-#undef MU_SAD16
-                // every lane of a group holds the group's keys: merge the 8 groups (lane ^ 8, ^ 16, ^ 32)
+                if (nm > 0) {
+                    for (int sb = 0; sb < nm; sb += 16) {
+                        const int sv = sb + (lane >> 2);
+                        const uint32_t pos = ml[min(sv, nm - 1)];
+                        const grow_t ra = (grow_t)(wrows + (((ul[pos] & 0x00ffffffu) << 1) | (uint32_t)((lane & 3) << 6)));
+                        uint32_t sa = 0;
+#pragma unroll 1   // (two pieces in flight already spill)
+                        for (int c = 0; c < 4; ++c) {
+                            const u32x4 r_ = ra[c];
+                            const u32x4 x_ = *reinterpret_cast<const u32x4*>(&qst[(lane & 3) * 16 + 4 * c]);
+                            sa = __builtin_amdgcn_sad_u16(r_.x, x_.x, sa);
+                            sa = __builtin_amdgcn_sad_u16(r_.y, x_.y, sa);
+                            sa = __builtin_amdgcn_sad_u16(r_.z, x_.z, sa);
+                            sa = __builtin_amdgcn_sad_u16(r_.w, x_.w, sa);
+                        }
+                        sa += mu_dpp<0xB1>(sa);   // lane ^ 1
+                        sa += mu_dpp<0x4E>(sa);   // lane ^ 2
+                        // one key per survivor (the quad's first lane), none past the list's end
+                        MU_UPD2((sv < nm && (lane & 3) == 0) ? ((sa << 9) | pos) : 0xffffffffu);
+                    }
+                    // (min, second min) over the quads' first lanes (the only ones with keys; lane 8k reads the result): keys are distinct
 #define MU_MRG2(O1, O2) do { const uint32_t o1_ = (O1), o2_ = (O2); m2 = min(max(m1, o1_), min(m2, o2_)); m1 = min(m1, o1_); } while (0)
-                MU_MRG2(mu_dpp<0x128>(m1), mu_dpp<0x128>(m2));
-                MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x401F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x401F));
-                {
-                    const auto h1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
-                    const auto h2 = __builtin_amdgcn_permlane32_swap(m2, m2, false, false);
-                    m1 = h1[0]; m2 = h2[0];
-                    MU_MRG2(h1[1], h2[1]);
-                }
+                    MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x101F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x101F));   // lane ^ 4
+                    MU_MRG2(mu_dpp<0x128>(m1), mu_dpp<0x128>(m2));                                                       // lane ^ 8
+                    MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x401F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x401F));   // lane ^ 16
+                    {
+                        const auto h1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
+                        const auto h2 = __builtin_amdgcn_permlane32_swap(m2, m2, false, false);
+                        m1 = h1[0]; m2 = h2[0];
+                        MU_MRG2(h1[1], h2[1]);
+                    }
 #undef MU_MRG2
-                if (g8 == k) { r_m1 = m1; r_m2 = m2; }
+                }
+                // the group's query: the survivors' keys and the two it had (keys are distinct), the verdict again
+                bool again = false;
+                if (g8 == k) {
+                    MU_UPD2(kA);
+                    MU_UPD2(kB);
+                    kA = m1; kB = m2;
+                    accept = !mp.second || (double)(m1 >> 9) < (double)(m2 >> 9) * mp.ratio;
+                    // a reject that became an accept: the unscored candidates were only shown to be above the reject's limit —
+                    // once more, with the accept's test (what is scored is marked: the second time decides)
+                    again = accept && !acck;
+                }
+                if (__any(again)) rm |= 1ull << bit;   // wave uniform
             }
-            if (rescue) {   // the group's query, exact: min SAD, second smallest with multiplicity, argmin (keys are distinct)
-                d1 = r_m1 >> 9;
-                ewin = ul[r_m1 & 511u];
-                const bool has_second = r_m2 != 0xffffffffu;
-                irregular = has_second && (r_m2 >> 9) == d1;   // exact tie of the minimum: largest-key rule, overflow kernel
-                accept = true;
-                if (mp.second) accept = (double)d1 < (has_second ? (double)(r_m2 >> 9) : 1.7976931348623157e308) * mp.ratio;
-            }
+#undef MU_UPD2
+            // exact tie of the minimum (largest-key rule): overflow kernel
+            if (rescue && (kA >> 9) == (kB >> 9)) irregular = true;
         }
+        const uint32_t kwin = min(kA, kB);
+        const uint32_t d1 = kwin >> 9;
+        const uint32_t ewin = ul[none ? 0u : (kwin & 511u)];   // list entry of the winner
         // in-radius candidates per query (K cap, and what a query that leaves for the overflow kernel must not count):
         // no query can have more than the list holds, so they are only needed when the list is longer than K or a
         // query leaves — bit counts over the list then; the lanes of group k keep query k's
