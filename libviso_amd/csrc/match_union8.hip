@@ -33,6 +33,9 @@
 #ifndef MU_NP
 #define MU_NP 2            // passes in flight (3 measured slower even without spills)
 #endif
+#ifndef MU_RNP
+#define MU_RNP 2           // rescue: passes of eight survivors in flight
+#endif
 #define MU_S8ROWS 176      // list positions whose SAD8 (in units of 128: one byte) is kept per query for the rescue (with this much
                            // LDS 7 workgroups per CU still fit; the bench's lists hold 94 rows on average)
 #define MU_KPCAP 512       // window keypoints staged in LDS
@@ -520,7 +523,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // queries; many more where SADs lie within the bound's slack of each other: low-contrast descriptors, repeated
         // texture).  Phase 2 left every cell's SAD8 (in units of 128) in LDS: the WAVE picks the query's members whose bound
         // L fails the very test the third key failed (the two it has already scored excepted), scores them exactly — their
-        // list positions compacted into LDS, four lanes per row, the query's u16 row read from LDS, (min, second min,
+        // list positions compacted into LDS, eight lanes per row and two passes in flight, the query's u16 row read from LDS, (min, second min,
         // argmin) as two packed keys SAD << 9 | position — and takes the verdict again over those and the first two.  What
         // the new verdict needs of the unscored ones follows from the test they passed (the minimum can only have fallen,
         // and with it both thresholds), unless a REJECT turned into an accept: then the selection runs once more with the
@@ -550,8 +553,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 const double limk = (double)(max(ka, kb) >> 9) * mp.ratio;
                 const bool acck = !mp.second || (double)d1k < limk;   // the verdict of the two smallest exact SADs so far, as above
                 const uint32_t msk = 31u - (uint32_t)k;
+                // the query's u16 row: requested now, stored to LDS behind the selection (its latency under the selection's)
+                const uint32_t qv = *(const __attribute__((address_space(1))) uint32_t*)(qrows + ((uint32_t)jq * (uint32_t)(VISO_ROW * 2) + (uint32_t)(lane << 2)));
                 __builtin_amdgcn_wave_barrier();
-                qst[lane] = *(const __attribute__((address_space(1))) uint32_t*)(qrows + ((uint32_t)jq * (uint32_t)(VISO_ROW * 2) + (uint32_t)(lane << 2)));
                 int nm = 0;
                 for (int b = 0; b < nu; b += VISO_WAVE) {   // nu <= MU_S8ROWS: three steps at most
                     const uint32_t i = (uint32_t)(b + lane);
@@ -570,33 +574,47 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     if (sel) ml[nm + mbcnt(bal)] = (uint16_t)i;
                     nm += __popcll(bal);
                 }
-                // FOUR lanes per survivor, sixteen survivors per step (a rare path: short code and few registers matter more
-                // than coalescing): a lane walks its quarter of the row in four 16-byte pieces against the query's row in LDS
+                // EIGHT lanes per survivor, eight survivors per pass, MU_RNP passes in flight; a lane takes its two 16-byte
+                // pieces of the row against the query's row in LDS (re-read per pass: kept in registers it costs the 8 the
+                // kernel does not have)
+                __builtin_amdgcn_wave_barrier();
+                qst[lane] = qv;
+                if (nm > 0 && lane < 8 * MU_RNP) ml[nm + lane] = ml[nm - 1];   // padding: scored, key masked out below
                 __builtin_amdgcn_wave_barrier();
                 uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
                 if (nm > 0) {
-                    for (int sb = 0; sb < nm; sb += 16) {
-                        const int sv = sb + (lane >> 2);
-                        const uint32_t pos = ml[min(sv, nm - 1)];
-                        const grow_t ra = (grow_t)(wrows + (((ul[pos] & 0x00ffffffu) << 1) | (uint32_t)((lane & 3) << 6)));
-                        uint32_t sa = 0;
-#pragma unroll 1   // (two pieces in flight already spill)
-                        for (int c = 0; c < 4; ++c) {
-                            const u32x4 r_ = ra[c];
-                            const u32x4 x_ = *reinterpret_cast<const u32x4*>(&qst[(lane & 3) * 16 + 4 * c]);
-                            sa = __builtin_amdgcn_sad_u16(r_.x, x_.x, sa);
-                            sa = __builtin_amdgcn_sad_u16(r_.y, x_.y, sa);
-                            sa = __builtin_amdgcn_sad_u16(r_.z, x_.z, sa);
-                            sa = __builtin_amdgcn_sad_u16(r_.w, x_.w, sa);
+                    for (int t = 0; t * 8 < nm; t += MU_RNP) {
+                        uint32_t pos[MU_RNP];
+                        u32x4 a0[MU_RNP], a1[MU_RNP];
+#pragma unroll
+                        for (int p = 0; p < MU_RNP; ++p) {
+                            pos[p] = ml[(t + p) * 8 + g8];
+                            const grow_t ra = (grow_t)(wrows + (((ul[pos[p]] & 0x00ffffffu) << 1) | (uint32_t)(sub << 4)));
+                            a0[p] = ra[0]; a1[p] = ra[8];
                         }
-                        sa += mu_dpp<0xB1>(sa);   // lane ^ 1
-                        sa += mu_dpp<0x4E>(sa);   // lane ^ 2
-                        // one key per survivor (the quad's first lane), none past the list's end
-                        MU_UPD2((sv < nm && (lane & 3) == 0) ? ((sa << 9) | pos) : 0xffffffffu);
+#pragma unroll
+                        for (int p = 0; p < MU_RNP; ++p) {
+                            int o_ = sub * 4;
+                            asm volatile("" : "+v"(o_));   // not loop invariant: the query row is re-read
+                            const u32x4 x0_ = *reinterpret_cast<const u32x4*>(&qst[o_]);
+                            uint32_t sa = __builtin_amdgcn_sad_u16(a0[p].x, x0_.x, 0u);
+                            sa = __builtin_amdgcn_sad_u16(a0[p].y, x0_.y, sa);
+                            sa = __builtin_amdgcn_sad_u16(a0[p].z, x0_.z, sa);
+                            sa = __builtin_amdgcn_sad_u16(a0[p].w, x0_.w, sa);
+                            const u32x4 x1_ = *reinterpret_cast<const u32x4*>(&qst[o_ + 32]);
+                            sa = __builtin_amdgcn_sad_u16(a1[p].x, x1_.x, sa);
+                            sa = __builtin_amdgcn_sad_u16(a1[p].y, x1_.y, sa);
+                            sa = __builtin_amdgcn_sad_u16(a1[p].z, x1_.z, sa);
+                            sa = __builtin_amdgcn_sad_u16(a1[p].w, x1_.w, sa);
+                            sa += mu_dpp<0xB1>(sa);                                          // lane ^ 1
+                            sa += mu_dpp<0x4E>(sa);                                          // lane ^ 2
+                            sa += (uint32_t)__builtin_amdgcn_ds_swizzle((int)sa, 0x101F);    // lane ^ 4
+                            // one key per survivor (the group's first lane), none past the list's end
+                            MU_UPD2(((t + p) * 8 + g8 < nm && sub == 0) ? ((sa << 9) | pos[p]) : 0xffffffffu);
+                        }
                     }
-                    // (min, second min) over the quads' first lanes (the only ones with keys; lane 8k reads the result): keys are distinct
+                    // (min, second min) over the groups' first lanes (the only ones with keys; lane 8k reads the result): keys are distinct
 #define MU_MRG2(O1, O2) do { const uint32_t o1_ = (O1), o2_ = (O2); m2 = min(max(m1, o1_), min(m2, o2_)); m1 = min(m1, o1_); } while (0)
-                    MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x101F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x101F));   // lane ^ 4
                     MU_MRG2(mu_dpp<0x128>(m1), mu_dpp<0x128>(m2));                                                       // lane ^ 8
                     MU_MRG2((uint32_t)__builtin_amdgcn_ds_swizzle((int)m1, 0x401F), (uint32_t)__builtin_amdgcn_ds_swizzle((int)m2, 0x401F));   // lane ^ 16
                     {
