@@ -108,6 +108,13 @@ int viso_matcher_default(void);
  * bit-identical hypotheses (tests/test_gpu_solver_edges.py); this is a tuning / test knob.  ctx == NULL: the default
  * context of the plain family. */
 int viso_ctx_set_gn_split(viso_ctx* ctx, int split);
+/* match_union8_kernel (matcher variant 6) ranks candidates on 8-bit planes h(v) = clamp((v + (128 << s)) >> s, 0, 255) of the
+ * descriptor rows.  shift = -1 (default): s is chosen per run from the descriptor magnitudes the previous run of the batch
+ * packed (the smallest s that clamps at most one element pair in 256; 3 before any statistics exist and in the one-call
+ * plain family); 0..3: fixed.  Every s gives the same results — the bound behind the ranking holds for any s and any
+ * descriptors — it only decides how often the kernel has to score more than two candidates of a query exactly.
+ * $VISO_ROW8_SHIFT sets the same for every new context (test / A-B aid). */
+int viso_ctx_set_row8_shift(viso_ctx* ctx, int shift);
 /* Name of that kernel as it appears in rocprofv3 summaries. */
 const char* viso_ctx_matcher_kernel_name(viso_ctx* ctx);
 const char* viso_last_error(void);
@@ -313,6 +320,8 @@ int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags);
  * / candidate lists beyond the tile kernels' LDS slots): a few for sparse features, a sizeable share where keypoints
  * cluster densely.  Same results either way; this is the data-dependent cost to watch. */
 int viso_batch_get_overflow_count(viso_batch* b, int32_t* n);
+/* Diagnostics: the shift of the 8-bit planes the batch's last run used (viso_ctx_set_row8_shift). */
+int viso_batch_get_row8_shift(viso_batch* b, int* shift);
 /* Duration of the kernel that takes the temporal calls (viso_ctx_matcher_kernel_name), measured with hipEvents
  * on the context's stream: average in ms over the runs since the last viso_batch_kernel_ms call. */
 int viso_batch_kernel_timing(viso_batch* b, int enable);

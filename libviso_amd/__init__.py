@@ -64,6 +64,9 @@ def load():
     L.viso_ctx_set_matcher.argtypes = [C.c_void_p, C.c_int]
     L.viso_matcher_variants.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.viso_ctx_set_gn_split.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "viso_ctx_set_row8_shift"):   # (absent from older builds of the library: VISO_HIP_SO A/B runs)
+        L.viso_ctx_set_row8_shift.argtypes = [C.c_void_p, C.c_int]
+        L.viso_batch_get_row8_shift.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.viso_batch_get_hypotheses.argtypes = [C.c_void_p, f64p, i32p, i32p, i32p]
     L.viso_host_alloc.restype = C.c_void_p
     L.viso_host_alloc.argtypes = [C.c_size_t]
@@ -157,6 +160,13 @@ def set_matcher_variant(v, ctx=None):
     r = load().viso_ctx_set_matcher(ctx.h if ctx is not None else None, int(v))
     if r != 1:
         _err("viso_ctx_set_matcher", r)
+
+
+def set_row8_shift(shift, ctx=None):
+    """viso_ctx_set_row8_shift: the shift of match_union8_kernel's 8-bit planes, -1 = chosen from the data (default), 0..3 = fixed."""
+    r = load().viso_ctx_set_row8_shift(ctx.h if ctx is not None else None, int(shift))
+    if r != 1:
+        _err("viso_ctx_set_row8_shift", r)
 
 
 def set_gn_split(split, ctx=None):
@@ -568,6 +578,11 @@ class Batch:
         n = C.c_int32(0)
         self._chk("viso_batch_get_overflow_count", self.L.viso_batch_get_overflow_count(self.h, C.byref(n)))
         return n.value
+
+    def row8_shift(self):
+        s = C.c_int(-1)
+        self._chk("viso_batch_get_row8_shift", self.L.viso_batch_get_row8_shift(self.h, C.byref(s)))
+        return s.value
 
     def kernel_timing(self, enable):
         self._chk("viso_batch_kernel_timing", self.L.viso_batch_kernel_timing(self.h, int(enable)))

@@ -21,7 +21,9 @@ struct viso_batch {
     viso_ctx* ctx;
     int nf, cap, dlen, iters;
     int n_probs;               // padded problem count (multiple of 24)
-    float2* kp; float* desc; int* n; uint16_t* packed; uint8_t* packed8; uint2* sums; int* bad_img; int* bad_any; int* zero;
+    float2* kp; float* desc; int* n; uint16_t* packed; uint8_t* packed8; uint2* sums;
+    // the 8-bit planes' shift (VISO_R8_*, csrc/common.h): device counters, their pinned landing place, the event behind the copy
+    int* r8cnt = nullptr; int* r8pin = nullptr; hipEvent_t r8ev = nullptr; bool r8pending = false; int r8shift = VISO_R8_DEFAULT; int r8last = VISO_R8_DEFAULT; unsigned r8runs = 0; int* bad_img; int* bad_any; int* zero;
     float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // column-bucket view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
@@ -108,8 +110,10 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     for (auto& e : b->events) { note(hipEventDestroy(e.first)); note(hipEventDestroy(e.second)); }
     for (int k = 0; k < VISO_NPIN_SLOTS; ++k) if (b->n_pin_ev[k]) note(hipEventDestroy(b->n_pin_ev[k]));
     if (b->n_pin) note(hipHostFree(b->n_pin));
+    if (b->r8pin) note(hipHostFree(b->r8pin));
+    if (b->r8ev) note(hipEventDestroy(b->r8ev));
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
-                    b->kp, b->desc, b->n, b->packed, b->packed8, b->sums, b->zero, b->probs, b->res, b->sorted,
+                    b->kp, b->desc, b->n, b->packed, b->packed8, b->r8cnt, b->sums, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
@@ -231,7 +235,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
     A(dalloc(&b->kp, nf * 2 * c)); A(dalloc(&b->desc, nf * 2 * c * dlen)); A(dalloc(&b->n, nf * 2));
-    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->packed8, nf * 2 * c * VISO_ROW8)); A(dalloc(&b->sums, nf * 2 * c)); A(dalloc(&b->zero, 8));
+    A(dalloc(&b->packed, nf * 2 * c * VISO_ROW)); A(dalloc(&b->packed8, nf * 2 * c * VISO_ROW8)); A(dalloc(&b->r8cnt, 4)); A(dalloc(&b->sums, nf * 2 * c)); A(dalloc(&b->zero, 8));
     A(dalloc(&b->probs, (size_t)b->n_probs));
     A(dalloc(&b->skp, nf * 2 * c)); A(dalloc(&b->sidx, nf * 2 * c)); A(dalloc(&b->rank, nf * 2 * c));
     A(dalloc(&b->bstart, nf * 2 * (VISO_NB + 1))); A(dalloc(&b->xinfo, nf * 2 * 8)); A(dalloc(&b->views, nf * 2 + 1));
@@ -251,6 +255,11 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
     A(dalloc(&b->tr, nf * 6)); A(dalloc(&b->ok, nf)); A(dalloc(&b->n_inl, nf)); A(dalloc(&b->inl, nf * c));
+    if (r >= 0 && (hipHostMalloc((void**)&b->r8pin, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess ||
+                   hipEventCreateWithFlags(&b->r8ev, hipEventDisableTiming) != hipSuccess)) {
+        viso_set_error("viso_batch_create: pinned buffer / event for the planes' statistics failed");
+        r = VISO_ERR_HIP;
+    }
     if (r >= 0 && hipHostMalloc((void**)&b->n_pin, sizeof(int) * VISO_NPIN_SLOTS * 2 * nf, hipHostMallocDefault) != hipSuccess) {
         b->n_pin = nullptr;
         viso_set_error("viso_batch_create: hipHostMalloc of the n staging ring failed");
@@ -394,6 +403,13 @@ extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, con
     return VISO_OK;
 }
 
+// Diagnostics: the shift of the 8-bit planes the last run used (matcher variant 6; see VISO_R8_* in csrc/common.h).
+extern "C" int viso_batch_get_row8_shift(viso_batch* b, int* shift) {
+    if (!b || !shift) { viso_set_error("viso_batch_get_row8_shift: bad argument"); return VISO_ERR_ARG; }
+    *shift = b->r8last;
+    return VISO_OK;
+}
+
 extern "C" int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, void** n) {
     if (!b) return VISO_ERR_ARG;
     if (kp) *kp = b->kp;
@@ -457,15 +473,36 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
     int r;
     if ((r = enter(b)) < 0) return r;
     hipStream_t s = b->ctx->stream;
-    const int with_sums = pack_extras(b->ctx->matcher_variant);   // block sums / 8-bit planes: what the selected temporal kernel reads
+    const int with_sums = pack_extras(b->ctx->matcher_variant, b->dlen);   // block sums / 8-bit planes: what the selected temporal kernel reads
     // the run's counters (scored, ovf_cnt, bad_img, bad_any) are zeroed by the first kernel of the run, not by a memset
-    if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap, reinterpret_cast<uint32_t*>(b->scored), (int)(b->zeroed_bytes / 4))) < 0) return r;
+    // the shift of this run's 8-bit planes (variant 6): forced, or the smallest that clamps at most one element pair in 256
+    // of the sample the last counting run took (frames of a sequence look alike; a resident batch sees its own data
+    // again).  Counting runs: the first, then every VISO_R8_EVERY-th; their counts come back asynchronously (no wait: a
+    // copy that has not landed yet is looked at by a later run).  Any shift gives the same results: this is speed only
+    int* r8cnt = nullptr;
+    if (with_sums & VISO_PACK_ROWS8) {
+        if (b->r8pending && hipEventQuery(b->r8ev) == hipSuccess) {
+            b->r8pending = false;
+            const unsigned long long rows = (unsigned)b->r8pin[VISO_R8_ROWS], lim = rows * 64ull / 256ull;
+            if (rows) b->r8shift = (unsigned)b->r8pin[VISO_R8_C128] <= lim ? 0 : (unsigned)b->r8pin[VISO_R8_C128 + 1] <= lim ? 1 : (unsigned)b->r8pin[VISO_R8_C128 + 2] <= lim ? 2 : 3;
+        }
+        if (!b->r8pending && b->ctx->row8_force < 0 && b->r8runs % VISO_R8_EVERY == 0) r8cnt = b->r8cnt;
+        ++b->r8runs;
+        b->r8last = b->ctx->row8_force >= 0 ? b->ctx->row8_force : b->r8shift;
+    }
+    const int r8s = b->r8last;
+    if ((r = launch_sort_kp(s, b->views, b->nf * 2, b->cap, reinterpret_cast<uint32_t*>(b->scored), (int)(b->zeroed_bytes / 4), r8cnt)) < 0) return r;
     if (from_images) {   // Sobel windows straight into packed rows (never bad: integers in [-1020,1020])
-        if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols, with_sums)) < 0) return r;
+        if ((r = launch_extract_pack(s, b->views, b->nf * 2, b->cap, b->images, b->img_rows, b->img_cols, with_sums, r8s, r8cnt)) < 0) return r;
     } else {
-        if (b->desc_i16) r = launch_pack_i16(s, b->views, b->nf * 2, b->cap, b->dlen, reinterpret_cast<const int16_t*>(b->desc), with_sums);
-        else r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any, with_sums);
+        if (b->desc_i16) r = launch_pack_i16(s, b->views, b->nf * 2, b->cap, b->dlen, reinterpret_cast<const int16_t*>(b->desc), with_sums, r8s, r8cnt);
+        else r = launch_pack(s, b->views, b->nf * 2, b->cap, b->dlen, b->bad_img, b->bad_any, with_sums, r8s, r8cnt);
         if (r < 0) return r;
+    }
+    if (r8cnt) {   // the sample's counts on their way to the host
+        HIP_TRY(hipMemcpyAsync(b->r8pin, b->r8cnt, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(b->r8ev, s));
+        b->r8pending = true;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {
@@ -482,7 +519,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
             b->ev_next = (b->ev_next + 1) % VISO_EVENT_POOL;
         }
     }
-    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, b->ovf_q, b->ovf_cnt, from_images ? 0 : 1)) < 0) return r;
+    if ((r = launch_match_timed(s, b->probs, b->n_probs, b->cap, b->dlen, b->mp, b->bad_any, e0, e1, 1, b->ctx->matcher_variant, b->ovf_q, b->ovf_cnt, r8s, from_images ? 0 : 1)) < 0) return r;
     if ((r = launch_sort(s, b->probs, b->n_probs, b->cap)) < 0) return r;
     if (b->stamps) HIP_TRY(hipEventRecord(b->ev_stamp[2], s));   // re-recorded behind the solver by run_rest
     return VISO_OK;

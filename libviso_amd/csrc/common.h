@@ -8,7 +8,16 @@
 
 #define VISO_ROW 128          // packed descriptor row: 128 x u16 = 256 B (121 used, rest = bias)
 #define VISO_ROW8 128         // bytes of a row's 8-bit plane (ImageView::rows8)
-#define VISO_ROW8_SLACK (7 * VISO_ROW8)   // 8 * SAD8 - SAD <= this (at most 128 elements count, each off by at most 7)
+// The planes' element is h_s(v) = clamp((v + (128 << s)) >> s, 0, 255) with a shift s in 0..3 chosen per RUN from the data:
+// every 16th run of a batch (and its first) the pack kernels count, over a sample of rows, how many element pairs reach
+// 128 / 256 / 512 (VISO_R8_*), the counts come back through a pinned buffer behind an event, and the host gives the runs
+// after that the smallest s that clamps at most 1 pair in 256 — as a kernel argument.  (SAD8 << s) - VISO_ROW8_SLACK(s) <=
+// SAD for ANY descriptors and any s: a wrong s costs time (more candidates scored exactly), never a result.
+#define VISO_ROW8_SLACK(S) (((1 << (S)) - 1) * VISO_ROW8)   // at most 128 elements count, each off by at most 2^s - 1
+#define VISO_R8_C128 0        // int cnt[4] per batch (8-byte aligned): [0..2] sampled element pairs (lanes of the pack kernels) whose
+#define VISO_R8_ROWS 3        //   larger magnitude reaches 128 / 256 / 512, [3] sampled rows
+#define VISO_R8_DEFAULT 3     // shift before any statistics exist (covers the whole range of a 3x3 Sobel of uint8)
+#define VISO_R8_EVERY 16      // runs between two looks at the data
 #define VISO_PACK_SUMS 1      // pack kernels, `extras`: also write ImageView::sums (matcher variant 5)
 #define VISO_PACK_ROWS8 2     //                         also write ImageView::rows8 (matcher variant 6)
 #define VISO_BIAS 32768       // u16 = int16 value + 32768 (SAD is translation invariant)
@@ -60,10 +69,11 @@ struct ImageView {               // one image's keypoints + descriptors on the d
                                  //     biased like the elements (4 x u16).  sum_k |S_q,k - S_t,k| <= SAD(q, t) (triangle
                                  //     inequality per block; clamping is 1-Lipschitz): the lower bound match_prune_kernel
                                  //     prunes candidates with.  Written by the pack kernels together with the rows.
-    uint8_t* rows8;              // [n][128] bucket order: the rows' 8-bit plane, element h(v) = clamp((v + 1024) >> 3, 0, 255) (pad
-                                 //     = h(0)).  8 |h(a) - h(b)| - 7 <= |a - b| for ANY a, b (floor and clamp are monotone and
-                                 //     1-Lipschitz in units of 8), so 8 SAD8 - 7 * 121 <= SAD: the lower bound match_union8_kernel
-                                 //     ranks candidates with.  Written by the pack kernels when matcher variant 6 is selected.
+    uint8_t* rows8;              // [n][128] bucket order: the rows' 8-bit plane, element h_s(v) = clamp((v + (128 << s)) >> s, 0, 255)
+                                 //     (pad = h_s(0)), s = the run's shift (a kernel argument, see VISO_R8_*).  2^s |h(a) - h(b)| - (2^s - 1) <= |a - b|
+                                 //     for ANY a, b (floor and clamp are monotone and 1-Lipschitz in units of 2^s), so
+                                 //     (SAD8 << s) - VISO_ROW8_SLACK(s) <= SAD: the lower bound match_union8_kernel ranks candidates
+                                 //     with.  Written by the pack kernels when matcher variant 6 is selected.
     int* bad;                    // [1] != 0: this image's descriptors do not fit the u16 rows (pack_desc_kernel);
                                  //     every problem that reads the image then takes the general (double) kernel
 };
@@ -95,6 +105,7 @@ struct viso_ctx {
     hipStream_t stream;
     bool own_stream;
     int matcher_variant;         // viso_ctx_set_matcher
+    int row8_force;              // viso_ctx_set_row8_shift: -1 = chosen from the data (default), 0..3 = fixed
     int gn_split;                // viso_ctx_set_gn_split
     // second stream of the context: the RANSAC stage of its batches runs here, beside the next run's
     // matcher on `stream` (viso_ctx_synchronize waits for both).  One per CONTEXT, not per batch: the runtime maps
@@ -113,23 +124,28 @@ viso_ctx* viso_default_ctx();
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
 // zero_words / n_zero: optional 32-bit words the kernel zeroes on the way (a run's counters: one memset less in front of it)
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words = nullptr, int n_zero = 0);
+// r8zero: the batch's four VISO_R8_* counters, zeroed too when the run is one that counts (or null)
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words = nullptr, int n_zero = 0,
+                   int* r8zero = nullptr);
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
 // extras: VISO_PACK_SUMS / VISO_PACK_ROWS8 — what the selected matcher variant reads beside the u16 rows (pack_extras)
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras);
-static inline int pack_extras(int variant) { return variant == 5 ? VISO_PACK_SUMS : variant == 6 ? VISO_PACK_ROWS8 : 0; }
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras, int r8s, int* r8cnt);
+// match_union8_kernel keeps a cell's SAD8 >> 7 in a byte whose value 255 marks "scored exactly": 127 elements x 255 = 32385
+// stays below that, 128 x 255 does not.  Descriptors of 128 elements (the reference's have 121) take match_union_kernel
+static inline int matcher_effective(int variant, int dlen) { return (variant == 6 && dlen > 127) ? 3 : variant; }
+static inline int pack_extras(int variant, int dlen) { variant = matcher_effective(variant, dlen); return variant == 5 ? VISO_PACK_SUMS : variant == 6 ? VISO_PACK_ROWS8 : 0; }
 // the same from int16 descriptors [n_img][cap][dlen] (viso_batch_upload_i16*): never flags anything
-int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras);
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras, int r8s, int* r8cnt);
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt);
+                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt, int r8s);
 // general_possible = 0: the rows cannot be flagged (descriptors extracted on the device from uint8 images), the
 // kernels of the general (double) path are not even launched
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                        const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant,
-                       const int2* ovf_q, const int* ovf_cnt, int general_possible = 1);
+                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible = 1);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 6
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
@@ -188,17 +204,18 @@ struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_
     int vblocks;                 // match_batch_kernel: (problem, tile) slots the grid walks (the stereo instantiation gets a small grid)
     int* bad;                    // [0] "some image of this run is flagged": lets the (normally idle) general kernels leave at once
                                  // [1] tiles match_stereo_kernel left to match_batch_kernel<1> (0: that kernel leaves at once)
+    int r8s, _pad8;              // the shift of the 8-bit planes this run (match_union8_kernel)
     MatchParamsDev mp[2];
 };
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant);
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
-                        int rows, int cols, int extras);
+                        int rows, int cols, int extras, int r8s, int* r8cnt);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
 size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per);
 int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,

@@ -32,6 +32,11 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     memset(c, 0, sizeof(*c));
     c->device = device;
     c->matcher_variant = viso_matcher_default();
+    c->row8_force = -1;
+    if (const char* e = getenv("VISO_ROW8_SHIFT")) {   // test / A-B aid: a fixed shift of the 8-bit planes for every new context
+        const int v = atoi(e);
+        if (*e && v >= 0 && v <= 3) c->row8_force = v;
+    }
     c->gn_split = 0;   // 0 = the build's default (VISO_GN_SPLIT, solver.hip)
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -96,6 +101,14 @@ extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
     if (!c) return VISO_ERR_HIP;
     if (!matcher_known(variant)) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
     c->matcher_variant = variant;
+    return VISO_OK;
+}
+
+extern "C" int viso_ctx_set_row8_shift(viso_ctx* c, int shift) {
+    c = ctx_or_default(c);
+    if (!c) return VISO_ERR_HIP;
+    if (shift < -1 || shift > 3) { viso_set_error("viso_ctx_set_row8_shift: -1 (from the data) or 0..3"); return VISO_ERR_ARG; }
+    c->row8_force = shift;
     return VISO_OK;
 }
 
@@ -216,6 +229,8 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     }
     // dmisc: [0]=n1 [1]=n2 [2]=bad (both images share one flag) [3]=m_cnt [4..5]=scored (u64) [6]=ovf_cnt [7]=bad_any
     int hm[10] = {n1, n2, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = tiles match_stereo_kernel declines (follows bad_any)
+    // the planes' shift (matcher variant 6): one call, no previous run to learn it from: the default, or the forced one
+    const int r8s = c->row8_force >= 0 ? c->row8_force : VISO_R8_DEFAULT;
     HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, s));
     auto view = [&](unsigned char* base, size_t n, const float2* kp, const float* f, const int* np, uint16_t* rows) {
         ImageView v{};
@@ -250,11 +265,11 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         const int one[1] = {1};
         HIP_TRY(hipMemcpyAsync(dmisc + 2, one, sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(dmisc + 7, one, sizeof(int), hipMemcpyHostToDevice, s));
-    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, pack_extras(c->matcher_variant))) < 0) return r;
+    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, pack_extras(c->matcher_variant, dlen), r8s, nullptr)) < 0) return r;
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     mpd[1] = mpd[0];
-    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant, dovf, dmisc + 6)) < 0) return r;
+    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant, dovf, dmisc + 6, r8s)) < 0) return r;
     if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
     int m = 0;
     HIP_TRY(hipMemcpyAsync(&m, dmisc + 3, sizeof(int), hipMemcpyDeviceToHost, s));

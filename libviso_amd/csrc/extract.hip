@@ -86,7 +86,7 @@ extern "C" int viso_extract_descriptors(const uint8_t* img, int rows, int cols, 
 // in flight together, BORDER_REFLECT_101 applied to the coordinates), staged in LDS, then lane l produces elements
 // 2l and 2l+1 of every descriptor from LDS.
 __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __restrict__ imgs, int n_img, int cap,
-                                                           const uint8_t* __restrict__ images, int rows, int cols, int extras) {
+                                                           const uint8_t* __restrict__ images, int rows, int cols, int extras, int r8s, int* __restrict__ r8cnt, unsigned r8m) {
     __shared__ unsigned char s_win[4][VISO_EXT_KPW][VISO_EXT_WIN * VISO_EXT_WIN + 7];
     typedef const __attribute__((address_space(1))) uint8_t* gbyte_t;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
             if (t < VISO_EXT_WIN * VISO_EXT_WIN) s_win[wv][k][t] = w[k][u];
         }
     __builtin_amdgcn_wave_barrier();
+    const bool r8on = r8cnt && ((unsigned)wave & r8m) == 0;   // uniform: ~256 waves of the launch
+    R8Count r8c = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < VISO_EXT_KPW; ++k) {
         if (k >= nk) break;                       // wave uniform
@@ -165,17 +167,18 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
             const uint2 bs = pack_block_sums(vsum);
             if (lane == 0) I.sums[j0 + k] = bs;
         }
-        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)(j0 + k), lane, v2[0], v2[1]);   // uniform; match_union8_kernel
+        if (extras & VISO_PACK_ROWS8) { store_row8(I.rows8, (size_t)(j0 + k), lane, v2[0], v2[1], r8s); if (r8on) r8_count(r8c, v2[0], v2[1]); }   // uniform; match_union8_kernel
     }
+    if (r8on) r8_flush(r8c, r8cnt, lane);
 }
 
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
-                        int rows, int cols, int extras) {
+                        int rows, int cols, int extras, int r8s, int* r8cnt) {
     const int capp = (cap + VISO_EXT_KPW - 1) / VISO_EXT_KPW * VISO_EXT_KPW;
     const long long waves = (long long)n_img * capp / VISO_EXT_KPW;
     if (waves == 0) return VISO_OK;
     hipLaunchKernelGGL(extract_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp,
-                       images, rows, cols, extras);
+                       images, rows, cols, extras, r8s, (extras & VISO_PACK_ROWS8) ? r8cnt : nullptr, r8_mask(waves));
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -44,13 +44,14 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 #define VISO_IMG_THREADS 512
 
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
-                                                                   uint32_t* zero_words, int n_zero) {
+                                                                   uint32_t* zero_words, int n_zero, int* r8zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* ykey = reinterpret_cast<uint32_t*>(smem);   // [n rounded up to 64] sortable y of the entry at each position
     __shared__ int s_cnt[VISO_NB + 1];                    // bucket counts -> starts -> running offsets
     __shared__ float s_red[5][VISO_IMG_THREADS / 64];
     __shared__ float s_x[2];
     if ((int)blockIdx.x >= n_img) return;
+    if (r8zero && blockIdx.x == 0 && threadIdx.x < 4) r8zero[threadIdx.x] = 0;   // a run whose pack kernels count magnitudes (VISO_R8_*)
     if (zero_words) {   // this workgroup's slice of the run's counters (first kernel of a run: everything that counts comes later)
         const int per = (n_zero + n_img - 1) / n_img;
         for (int i = threadIdx.x; i < per; i += VISO_IMG_THREADS) {
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     }
 }
 
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero) {
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero) {
     if (n_img <= 0) return VISO_OK;
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
@@ -152,7 +153,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
     const size_t lds = (size_t)n64 * sizeof(uint32_t) + 16;
     if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_kp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64, zero_words, n_zero);
+    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64, zero_words, n_zero, r8zero);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -165,7 +166,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
 #define VISO_PACK_RPW 8   // rows per wave
 
 __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restrict__ imgs, int n_img,
-                                                        int cap, int dlen, int* __restrict__ bad_any, int extras) {
+                                                        int cap, int dlen, int* __restrict__ bad_any, int extras, int r8s, int* __restrict__ r8cnt, unsigned r8m) {
     __shared__ __attribute__((aligned(16))) float s_buf[4][VISO_PACK_RPW * VISO_ROW];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) f32x4* gvec_t;
@@ -219,16 +220,22 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
             const uint2 bs = pack_block_sums((int)ar + (int)br);
             if (lane == 0) I.sums[d] = bs;
         }
-        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, (int)ar, (int)br);   // uniform
+        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, (int)ar, (int)br, r8s);   // uniform
     }
     if (__any(isbad) && lane == 0) { atomicOr(I.bad, 1); atomicOr(bad_any, 1); }
+    if (r8cnt && ((unsigned)wave & r8m) == 0) {   // uniform, ~256 waves of the launch: the rows once more (they are still in LDS), counted
+        R8Count r8c = {0, 0, 0, 0};
+        for (int k = 0; k < nrows; ++k)
+            r8_count(r8c, c < dlen ? (int)rintf(buf[k * dlen + c]) : 0, c + 1 < dlen ? (int)rintf(buf[k * dlen + c + 1]) : 0);
+        r8_flush(r8c, r8cnt, lane);
+    }
 }
 
 // The same rows from int16 descriptors (viso_batch_upload_i16*: the lossless encoding of the reference's N x 121
 // CV_32F Sobel windows, half the PCIe bytes).  desc16: [n_img][cap][dlen] int16, tightly packed; one wave = 8
 // consecutive rows = one contiguous 16-B aligned run of 8 * dlen * 2 bytes.  An int16 always fits the rows: no flag.
 __global__ __launch_bounds__(256) void pack_desc_i16_kernel(const ImageView* __restrict__ imgs, int n_img, int cap, int cap_stride,
-                                                            int dlen, const int16_t* __restrict__ desc16, int extras) {
+                                                            int dlen, const int16_t* __restrict__ desc16, int extras, int r8s, int* __restrict__ r8cnt, unsigned r8m) {
     __shared__ __attribute__((aligned(16))) uint16_t s_buf[4][VISO_PACK_RPW * VISO_ROW];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* gvec_t;
@@ -273,17 +280,23 @@ __global__ __launch_bounds__(256) void pack_desc_i16_kernel(const ImageView* __r
             const uint2 bs = pack_block_sums(a + b);
             if (lane == 0) I.sums[d] = bs;
         }
-        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, a, b);   // uniform
+        if (extras & VISO_PACK_ROWS8) store_row8(I.rows8, (size_t)d, lane, a, b, r8s);   // uniform
+    }
+    if (r8cnt && ((unsigned)wave & r8m) == 0) {   // uniform, ~256 waves of the launch: the rows once more (still in LDS), counted
+        R8Count r8c = {0, 0, 0, 0};
+        for (int k = 0; k < nrows; ++k)
+            r8_count(r8c, c < dlen ? (int)(int16_t)buf[k * dlen + c] : 0, c + 1 < dlen ? (int)(int16_t)buf[k * dlen + c + 1] : 0);
+        r8_flush(r8c, r8cnt, lane);
     }
 }
 
-int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras) {
+int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, const int16_t* desc16, int extras, int r8s, int* r8cnt) {
     if (n_img <= 0) return VISO_OK;
     if (dlen > VISO_ROW) { viso_set_error("int16 descriptors longer than %d are not supported", VISO_ROW); return VISO_ERR_UNSUPPORTED; }
     const int capp = (cap + VISO_PACK_RPW - 1) / VISO_PACK_RPW * VISO_PACK_RPW;
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
-    hipLaunchKernelGGL(pack_desc_i16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp, cap, dlen, desc16, extras);
+    hipLaunchKernelGGL(pack_desc_i16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, imgs_dev, n_img, capp, cap, dlen, desc16, extras, r8s, (extras & VISO_PACK_ROWS8) ? r8cnt : nullptr, r8_mask(waves));
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -294,7 +307,7 @@ __global__ void flag_all_kernel(int* flags, int n, int* any) {
     if (i == 0) *any = 1;
 }
 
-int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras) {
+int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, int dlen, int* bad_img, int* bad_any, int extras, int r8s, int* r8cnt) {
     if (n_img <= 0) return VISO_OK;
     if (dlen > VISO_ROW) {  // rows do not fit the packed format: every image takes the general path
         hipLaunchKernelGGL(flag_all_kernel, dim3((n_img + 255) / 256), dim3(256), 0, s, bad_img, n_img, bad_any);
@@ -307,7 +320,7 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
     const int blocks = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any, extras);
+    hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any, extras, r8s, (extras & VISO_PACK_ROWS8) ? r8cnt : nullptr, r8_mask(waves));
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -921,8 +934,9 @@ const char* matcher_kernel_name(int variant) {
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], int* bad,
                        hipEvent_t e0, hipEvent_t e1, int layout, int variant,
-                       const int2* ovf_q, const int* ovf_cnt, int general_possible) {
+                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
+    variant = matcher_effective(variant, dlen);
     MatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
@@ -939,7 +953,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     a.vblocks = (int)blocks;
     if (e0) HIP_TRY(hipEventRecord(e0, s));
     {
-        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, variant);
+        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, variant, r8s);
         if (r < 0) return r;
     }
     // general (non-u16) path: normally idle (no image is flagged and every block leaves at once), so
@@ -961,8 +975,8 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
 }
 
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
-                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt) {
-    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant, ovf_q, ovf_cnt);
+                 const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt, int r8s) {
+    return launch_match_timed(s, probs_dev, n_probs, cap_max, dlen, mp, bad, nullptr, nullptr, 0, variant, ovf_q, ovf_cnt, r8s);
 }
 
 

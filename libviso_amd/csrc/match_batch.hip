@@ -458,13 +458,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant) {
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s) {
     BatchMatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
     a.bpp = (cap_max + MB_QPB - 1) / MB_QPB;
     a.gs = 1; a.gf = 0; a.gc = 1; a.vblocks = 0;
     a.bad = bad;
+    a.r8s = r8s; a._pad8 = 0;
     a.mp[0] = mp[0];
     a.mp[1] = mp[1];
     const int groups = (n_probs + 7) / 8;

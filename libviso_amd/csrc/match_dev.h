@@ -23,23 +23,50 @@ __device__ __forceinline__ uint2 pack_block_sums(int v) {
     return make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
 }
 
-// 8-bit plane of a packed row (ImageView::rows8).  h is monotone and |h(a) - h(b)| <= (|a - b| + 7) / 8 for any ints.
+// 8-bit plane of a packed row (ImageView::rows8) at shift s: h_s is monotone and |h(a) - h(b)| <= (|a - b| + 2^s - 1) >> s.
 // The clamp comes FIRST and through inline asm: written as clamp((v + 1024) >> 3, 0, 255) on two values that are then
 // packed, hipcc 7.2 selects gfx950's v_ashr_pk_u8_i32 and treats bits 31:16 of its result as zero, while the hardware
 // leaves the destination's upper half as it was (0xffff where v + 1024 was negative: the neighbour's bytes of the plane
 // dword came out as 255; found by tests/test_gpu_union8.py, values below -1024).
-__device__ __forceinline__ uint32_t row8_of(int v) {
-    int x = v + 1024;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"(2047));
-    return (uint32_t)x >> 3;
+__device__ __forceinline__ uint32_t row8_of(int v, int s) {
+    int x = v + (128 << s);
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"((256 << s) - 1));
+    return (uint32_t)x >> s;
 }
 
 // lane l holds elements 2l, 2l+1 of row `row` (pad elements as 0): the even lanes write the plane's dwords
-__device__ __forceinline__ void store_row8(uint8_t* rows8, size_t row, int lane, int va, int vb) {
-    const uint32_t h2 = row8_of(va) | (row8_of(vb) << 8);
+__device__ __forceinline__ void store_row8(uint8_t* rows8, size_t row, int lane, int va, int vb, int s) {
+    const uint32_t h2 = row8_of(va, s) | (row8_of(vb, s) << 8);
     const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h2, 0x101, 0xf, 0xf, true);   // row_shl:1: lane + 1's pair
     if ((lane & 1) == 0)
         ((__attribute__((address_space(1))) uint32_t*)reinterpret_cast<uint32_t*>(rows8 + row * VISO_ROW8))[lane >> 1] = h2 | (nb << 16);
+}
+
+// Magnitude statistics of the rows a pack wave converts (what the NEXT run's shift is chosen from): call once per row with
+// the lane's two elements, then r8_flush once per wave.  Counts are element PAIRS (lanes) whose larger magnitude reaches
+// 128 / 256 / 512; all wave uniform (ballots).  Only about VISO_R8_WAVES waves of a launch take part (r8_mask: a power of two
+// minus one, from the launcher), and a wave sends its four counts as TWO 64-bit atomics: the counters share a cache
+// line, and with every wave adding to it the pack kernels were ten times slower, with one wave in 64 still 6 % (the line's
+// memory channel is on every wave's path); a few thousand rows are more than a 1-in-256 threshold needs
+#define VISO_R8_WAVES 256
+static inline unsigned r8_mask(long long waves) {   // host: sample waves whose index & mask == 0
+    unsigned m = 1;
+    while ((long long)m * VISO_R8_WAVES * 2 <= waves) m <<= 1;
+    return m - 1;
+}
+struct R8Count { int c128, c256, c512, rows; };
+__device__ __forceinline__ void r8_count(R8Count& c, int va, int vb) {
+    const int m = max(abs(va), abs(vb));
+    c.c128 += __popcll(__ballot(m >= 128));
+    c.c256 += __popcll(__ballot(m >= 256));
+    c.c512 += __popcll(__ballot(m >= 512));
+    c.rows += 1;
+}
+__device__ __forceinline__ void r8_flush(const R8Count& c, int* row8, int lane) {
+    if (lane == 0 && c.rows) {   // four consecutive ints, 8-byte aligned
+        atomicAdd(reinterpret_cast<unsigned long long*>(row8 + VISO_R8_C128), (unsigned long long)(unsigned)c.c128 | ((unsigned long long)(unsigned)c.c256 << 32));
+        atomicAdd(reinterpret_cast<unsigned long long*>(row8 + VISO_R8_C128 + 2), (unsigned long long)(unsigned)c.c512 | ((unsigned long long)(unsigned)c.rows << 32));
+    }
 }
 
 // cvflann::L1<float> over 2 elements: result = 0; result += |a0-b0|; result += |a1-b1|

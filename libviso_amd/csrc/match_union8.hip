@@ -2,9 +2,11 @@
 // union list is ranked on the rows' 8-BIT PLANES and only the two best candidates of a query are scored exactly.
 //
 // Why that is still match_desc (src/viso.cpp:669-726), bit for bit.  A query's outputs are the smallest SAD d1, its
-// candidate, and ONE bit of the second smallest d2: d1 < d2 * ratio (:715).  With h(v) = clamp((v + 1024) >> 3, 0, 255)
-// (ImageView::rows8; floor and clamp are monotone and 1-Lipschitz in units of 8) every element obeys
-// 8 |h(a) - h(b)| - 7 <= |a - b|, so L(t) = 8 SAD8(t) - 896 <= SAD(t) for ANY descriptors of up to 128 elements.  The kernel keeps, per query,
+// candidate, and ONE bit of the second smallest d2: d1 < d2 * ratio (:715).  With h(v) = clamp((v + (128 << s)) >> s, 0, 255),
+// s = the run's shift (ImageView::rows8; floor and clamp are monotone and 1-Lipschitz in units of 2^s), every element obeys
+// 2^s |h(a) - h(b)| - (2^s - 1) <= |a - b|, so L(t) = (SAD8(t) << s) - 128 (2^s - 1) <= SAD(t) for ANY descriptors of up to
+// 128 elements and ANY s in 0..3 (s = 3 covers the whole range of a 3x3 Sobel of uint8 with a slack of 896; the host picks s
+// per run from the magnitudes the pack kernels sampled, common.h VISO_R8_*: speed only, never a result).  The kernel keeps, per query,
 // the THREE smallest SAD8 keys of the union pass; scores the first two exactly (u16 rows, v_sad_u16): e1, e2, d1' = min,
 // d2' = max; and lets L3 = L(third key) — a lower bound of EVERY unscored candidate's SAD, because L is monotone in the
 // key — decide whether the unscored ones can matter:
@@ -23,6 +25,7 @@
 // Tile, round composition and scan are match_union.hip's (see there).
 #include "common.h"
 #include "match_dev.h"
+#include <stddef.h>
 
 #define MU_THREADS 256
 #define MU_WAVES 4
@@ -98,6 +101,16 @@ __device__ __forceinline__ int mu_ybucket(float y, float y0, float scale) {
     int b;
     asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(b) : "v"(f));
     return min(max(b, 0), MU_NBY - 1);
+}
+
+// The shift of this run's planes (BatchMatchArgs::r8s), read from the kernel-argument segment WHERE it is used, through a
+// laundered pointer: as a value the compiler preloads at the kernel's entry it is one more scalar register live across
+// the whole kernel, and this kernel already spills scalar registers into vector lanes (19 of them; 26 with that one,
+// their reloads inside the loops: 0.530 -> 0.542 ms)
+__device__ __forceinline__ int mu_r8s() {
+    const int* kp = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp[offsetof(BatchMatchArgs, r8s) / sizeof(int)];
 }
 
 // the lane that carries query k of a round (lanes 0..31: queries 0..3, lanes 32..63: queries 4..7, repeated every four
@@ -445,6 +458,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
 #undef MU_SAD2
 #undef MU_ISSUE
         }
+        const int r8s = mu_r8s();   // asked for here: the merges and the exact scoring's loads cover the scalar load's latency
         // ---------------- phase 3: merge the 8 lane groups (lanes with equal position in the group track the same
         // query): lane ^ 8 by a rotation within the row of 16 (DPP), lane ^ 16 by ds_swizzle, lane ^ 32 by
         // v_permlane32_swap; every lane then holds the round's three best keys of query myq(lane)
@@ -506,7 +520,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         bool accept = !none, irregular = false, rescue = false;
         if (!none && has2) {
             const uint32_t d1 = min(dA, dB), d2 = max(dA, dB);
-            const int L3 = (int)((tr.m3 >> 9) << 3) - VISO_ROW8_SLACK;   // <= SAD of every unscored candidate (has3)
+            const int L3 = (int)((tr.m3 >> 9) << r8s) - VISO_ROW8_SLACK(r8s);   // <= SAD of every unscored candidate (has3)
             if (mp.second) {   // src/viso.cpp:713-716 — ratio test in double (Q3)
                 const double lim = (double)d2 * mp.ratio;
                 accept = (double)d1 < lim;
@@ -553,6 +567,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 const double limk = (double)(max(ka, kb) >> 9) * mp.ratio;
                 const bool acck = !mp.second || (double)d1k < limk;   // the verdict of the two smallest exact SADs so far, as above
                 const uint32_t msk = 31u - (uint32_t)k;
+                const int r8q = mu_r8s();
                 // the query's u16 row: requested now, stored to LDS behind the selection (its latency under the selection's)
                 const uint32_t qv = *(const __attribute__((address_space(1))) uint32_t*)(qrows + ((uint32_t)jq * (uint32_t)(VISO_ROW * 2) + (uint32_t)(lane << 2)));
                 __builtin_amdgcn_wave_barrier();
@@ -563,7 +578,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     if (i < (uint32_t)nu) {
                         const uint32_t e = ul[i];
                         const uint32_t q8 = s_s8[wave][k][i];   // floor(SAD8 / 128), or 255: scored exactly already
-                        const int Lt = (int)(q8 << 10) - VISO_ROW8_SLACK;   // <= 8 SAD8 - slack <= SAD
+                        const int Lt = (int)(q8 << (7 + r8q)) - VISO_ROW8_SLACK(r8q);   // <= (SAD8 << s) - slack <= SAD
                         // can the candidate be ignored?  accept: it is not the minimum, does not tie it and passes :715 as the
                         // second best; reject: it is above the limit the minimum must stay below
                         const bool clear = q8 == 255u || (!mp.second ? Lt > d1k : (acck ? (Lt > d1k && (double)d1k < (double)Lt * mp.ratio) : ((double)Lt >= limk)));

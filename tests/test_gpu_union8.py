@@ -53,12 +53,16 @@ def _graded_case(rng, n1, n2, vrange, second, ratio):
     return kp1, kp2, d1.astype(np.float32), d2.astype(np.float32), mp
 
 
+@pytest.mark.parametrize("shift", [3, 2, 1, 0])
 @pytest.mark.parametrize("vrange", [1020, 40, 6000])
-def test_graded_sads_around_the_bounds_slack(viso, oracle, vrange):
+def test_graded_sads_around_the_bounds_slack(viso, oracle, vrange, shift):
+    """Every shift of the planes must give the oracle's matches on every data range: a shift too small for the data clamps
+    (the bound only gets looser), a shift too large leaves a slack wider than the SADs."""
     if V8 not in libviso_amd.MATCHER_VARIANTS:
         pytest.skip("this build has no variant 6")
     rng = np.random.default_rng(8800 + vrange)
     libviso_amd.set_matcher_variant(V8)
+    libviso_amd.set_row8_shift(shift)
     try:
         n_acc = 0
         for it in range(40):
@@ -72,6 +76,7 @@ def test_graded_sads_around_the_bounds_slack(viso, oracle, vrange):
         assert n_acc > 100
     finally:
         libviso_amd.set_matcher_variant(libviso_amd.DEFAULT_MATCHER)
+        libviso_amd.set_row8_shift(-1)
 
 
 def _batch(seq, variant, tm=None):
@@ -151,3 +156,32 @@ def test_same_results_as_the_u16_kernel_int16_rows_and_images(viso):
         b.close(); ctx.close()
     assert all(np.array_equal(a, c) for a, c in zip(out[3][0], out[V8][0])) and np.array_equal(out[3][1], out[V8][1])
     assert sum(len(m) for m in out[V8][0]) > 1000
+
+
+@pytest.mark.parametrize("scale, want_shift", [(1.0, 3), (0.5, 2), (0.25, 1), (0.1, 0)])
+def test_the_planes_shift_follows_the_data(viso, oracle, scale, want_shift):
+    """The first run of a batch uses the default shift (3: the whole range of a Sobel of uint8), the pack kernels count
+    magnitudes on the way, and the next run takes the smallest shift that clamps at most one element pair in 256: both runs
+    give the oracle's matches and counters."""
+    if V8 not in libviso_amd.MATCHER_VARIANTS:
+        pytest.skip("this build has no variant 6")
+    seq = synth.make_sequence(615, 3, n_kp=1200, width=800, height=300)
+    seq["desc"] = np.rint(seq["desc"] * scale).astype(np.float32)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    libviso_amd.set_matcher_variant(V8, ctx)
+    libviso_amd.set_row8_shift(-1, ctx)
+    b = libviso_amd.Batch(ctx, 3, 1200)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.set_params(st, tm, seq["param"], seed=5)
+    shifts = []
+    for run in range(2):
+        b.run_matcher()
+        shifts.append(b.row8_shift())
+        sc, _ = b.counters()
+        for t in range(3):
+            for which in range(3 if t else 1):
+                want, wsc = _oracle_call(oracle, seq, which, t, st, tm)
+                assert np.array_equal(b.matches(which, t), want) and sc[which, t] == wsc, (scale, run, which, t)
+    assert shifts == [3, want_shift], shifts
+    b.close(); ctx.close()

@@ -16,8 +16,8 @@ from libviso_amd.abi import MatchParams
 SLACK = 7 * 128
 
 
-def plane(v):
-    return np.clip((v.astype(np.int64) + 1024) >> 3, 0, 255)
+def plane(v, s=3):
+    return np.clip((v.astype(np.int64) + (128 << s)) >> s, 0, 255)
 
 
 def test_plane_bound_holds_for_any_int16_rows():
@@ -29,13 +29,16 @@ def test_plane_bound_holds_for_any_int16_rows():
         a[200:230] = rng.choice([-32768, 32767, -1025, -1024, 1023, 1024], (30, 121))
         a, b = np.clip(a, -32768, 32767), np.clip(b, -32768, 32767)
         sad = np.abs(a - b).sum(1)
-        sad8 = np.abs(plane(a) - plane(b)).sum(1)
-        assert np.all(8 * sad8 - SLACK <= sad)
-        assert np.all(((sad8 >> 7) << 10) - SLACK <= sad)               # the byte the rescue reads: floor(SAD8 / 128)
-    # per element: 8 |h(a) - h(b)| - 7 <= |a - b| over the whole int16 range of one operand
+        for s in range(4):                                              # every shift the kernel may run with
+            sad8 = np.abs(plane(a, s) - plane(b, s)).sum(1)
+            slack = ((1 << s) - 1) * 128
+            assert np.all((sad8 << s) - slack <= sad)
+            assert np.all(((sad8 >> 7) << (7 + s)) - slack <= sad)      # the byte the rescue reads: floor(SAD8 / 128)
+    # per element: 2^s |h(a) - h(b)| - (2^s - 1) <= |a - b| over the whole int16 range of one operand
     a = np.arange(-32768, 32768)
-    for bv in (-32768, -1500, -1024, -7, 0, 5, 1016, 1023, 1024, 32767):
-        assert np.all(8 * np.abs(plane(a) - plane(np.full_like(a, bv))) - 7 <= np.abs(a - bv))
+    for s in range(4):
+        for bv in (-32768, -1500, -1024, -129, -128, -7, 0, 5, 127, 128, 1016, 1023, 1024, 32767):
+            assert np.all((np.abs(plane(a, s) - plane(np.full_like(a, bv), s)) << s) - ((1 << s) - 1) <= np.abs(a - bv))
 
 
 def _emulate(kp1, kp2, d1, d2, mp):
