@@ -238,6 +238,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     const gbytes_t wrows = (gbytes_t)reinterpret_cast<const char*>(P.t.rows) + (size_t)lo * (VISO_ROW * 2);
     const gbytes_t qrows = (gbytes_t)reinterpret_cast<const char*>(P.q.rows);
     const gbytes_t qrows8 = (gbytes_t)reinterpret_cast<const char*>(P.q.rows8);
+    const gbytes_t qord_b = (gbytes_t)reinterpret_cast<const char*>(P.q.qord), qskp_b = (gbytes_t)reinterpret_cast<const char*>(P.q.skp),
+                   qsidx_b = (gbytes_t)reinterpret_cast<const char*>(P.q.sidx);
     uint32_t* ul = s_ul[wave];
     const int sub = lane & 7;
     const int half = lane >> 5;          // phase 1: lanes 0..31 test queries 0..3 of the round, lanes 32..63 queries 4..7
@@ -258,13 +260,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     float2 pq;
     int po;
 #define MU_PREFETCH(R)                                                                                    \
-    do {                                                                                                  \
+    do {   /* scalar bases + 32-bit offsets: no 64-bit address arithmetic per lane */                    \
         const int base_ = wave * (MU_QPB / MU_WAVES) + (R) * MU_G;                                        \
-        pli = (int)P.q.qord[q0 + base_ + qslot];                                                          \
+        pli = (int)*(const __attribute__((address_space(1))) uint8_t*)(qord_b + (uint32_t)(q0 + base_ + qslot)); \
         const int j_ = q0 + pli;                                                                          \
         const int jc_ = min(j_, q1 - 1);                                                                  \
-        pq = P.q.skp[jc_];                                                                                \
-        po = j_ < q1 ? P.q.sidx[jc_] : -1;                                                                \
+        {                                                                                                 \
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));                                     \
+            const f32x2_ k_ = *(const __attribute__((address_space(1))) f32x2_*)(qskp_b + (uint32_t)jc_ * 8u); \
+            pq = make_float2(k_.x, k_.y);                                                                 \
+        }                                                                                                 \
+        po = *(const __attribute__((address_space(1))) int*)(qsidx_b + (uint32_t)jc_ * 4u);             \
+        po = j_ < q1 ? po : -1;                                                                           \
     } while (0)
     MU_PREFETCH(0);
 
@@ -296,14 +303,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // y extent of the four queries of the lane's half (the two halves' scan ranges are joined as scalars below)
         const float ymn = mu_fmin(mu_fmin(qy[0], qy[1]), mu_fmin(qy[2], qy[3]));
         const float ymx = mu_fmax(mu_fmax(qy[0], qy[1]), mu_fmax(qy[2], qy[3]));
-        // the eight query rows' 8-bit planes (32 dwords each): one word per lane and PAIR of rows from global memory
-        // (lanes 0..31 query 2j, lanes 32..63 query 2j + 1; the loads land during the scan), then LDS
+        // the eight query rows' 8-bit planes (32 dwords each): one word per lane and PAIR of rows from global memory (lanes
+        // 0..31 query k, lanes 32..63 query k + 4: the row of quad lane k of the lane's own half, so its byte offset is ONE
+        // quad broadcast of the lane's own; the loads land during the scan), then LDS
         uint32_t qw[MU_G / 2];
-#pragma unroll
-        for (int k = 0; k < MU_G / 2; ++k) {
-            const int je = __builtin_amdgcn_readlane(pli, mu_qlane(2 * k)), jo = __builtin_amdgcn_readlane(pli, mu_qlane(2 * k + 1));
-            const int jk = q0 + (half ? jo : je);
-            qw[k] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + ((uint32_t)min(jk, q1 - 1) * (uint32_t)VISO_ROW8 + (uint32_t)((lane & 31) << 2)));   // scalar base + 32-bit offset
+        {
+            const uint32_t own = (uint32_t)min(q0 + pli, q1 - 1) * (uint32_t)VISO_ROW8;   // the row of the lane's own query
+            const uint32_t l4 = (uint32_t)((lane & 31) << 2);
+            qw[0] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + (mu_bcast<0x00>(own) + l4));   // scalar base + 32-bit offset
+            qw[1] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + (mu_bcast<0x55>(own) + l4));
+            qw[2] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + (mu_bcast<0xAA>(own) + l4));
+            qw[3] = *(const __attribute__((address_space(1))) uint32_t*)(qrows8 + (mu_bcast<0xFF>(own) + l4));
         }
         if (r + 1 < ROUNDS) MU_PREFETCH(r + 1);
         // ---------------- phase 1: one scan over the y buckets the round's diamonds touch, 32 targets per step: both
@@ -363,7 +373,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         // padding behind the list: copies of the last entry with nobody's membership (scored, never counted)
         if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] | 0xff000000u;
         __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < MU_G / 2; ++k) s_qrow[wave][2 * k + half][lane & 31] = qw[k];
+        for (int k = 0; k < MU_G / 2; ++k) s_qrow[wave][k + 4 * half][lane & 31] = qw[k];
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2: rolling pipeline over the union list on the 8-BIT PLANES: load a row's plane once (one
         // dwordx4 per lane, 8 lanes per row), 4 x v_sad_u8 against each of the eight query planes (staged per wave in LDS),
@@ -429,8 +439,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                 /* members and non-members alike; lists longer than the store pile up in its last row (the rescue then leaves   */ \
                 /* them to the overflow kernel).  As asm: a C store into LDS between the pipeline's LDS reads made the       */ \
                 /* register allocator spill 26 registers                                                                      */ \
-                asm volatile("ds_write_b8 %0, %1" : : "v"(s8a), "v"(m_ >> 7));   /* SAD8 < 2^15 */          \
-                s8a = min(s8a + 8u, s8w + (MU_S8ROWS / 8 - 1) * 8u);   /* a running address: an index min(T, ..) of the loop counter made the compiler spill 24 registers */ \
+                asm volatile("ds_write_b8 %0, %1 offset:%2" : : "v"(s8a), "v"(m_ >> 7), "n"((SLOT) * 8));   /* SAD8 < 2^15 */ \
                 mu_update(tr, (m_ << 9) | un[SLOT]);                                                       \
             } while (0)
             if (npass > 0) {
@@ -446,6 +455,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
                     MU_ISSUE(p, t + p + MU_NP);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // the SAD8 slot of the next MU_NP passes: a running address (an index min(pass, ..) of the loop counter made the
+                // compiler spill 24 registers), advanced once per iteration; lists longer than the store pile up in its last rows
+                s8a = min(s8a + 8u * MU_NP, s8w + (MU_S8ROWS / 8 - MU_NP) * 8u);
             }
             if (npass > 0) {   // the last passes (no pass of padding is scored)
 #pragma unroll
