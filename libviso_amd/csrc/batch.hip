@@ -35,7 +35,7 @@ struct viso_batch {
     double *x_c, *Xp_c;          // the solver's inputs: gathered + triangulated by the circle join
     JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
-    double* tr_h; int *ok_h, *cnt_h, *hq;   // hq: list of undecided hypotheses (launch_ransac)
+    double* tr_h; int *ok_h, *cnt_h, *hq; char* rot;   // hq: list of undecided hypotheses (launch_ransac)
     int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_sample_kernel)
     // the *_async uploads stage the caller's (pageable, possibly temporary) n array through a small pinned ring:
     // slot k is reusable once the copy that read it has passed (n_pin_ev[k])
@@ -90,9 +90,10 @@ static void free_solver_bufs(viso_batch* b) {
     if (b->tr_h) hipFree(b->tr_h);
     if (b->ok_h) hipFree(b->ok_h);
     if (b->cnt_h) hipFree(b->cnt_h);
+    if (b->rot) hipFree(b->rot);
     if (b->hq) hipFree(b->hq);
     if (b->samp_h) hipFree(b->samp_h);
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr;
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr; b->rot = nullptr;
 }
 
 // Frees everything it can; the first HIP error met is recorded (viso_last_error) and returned.  Like
@@ -115,7 +116,7 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->packed8, b->r8cnt, b->sums, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->tile_flag, b->qord, b->ovf_q};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->rot, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -198,6 +199,7 @@ static int build_solver_items(viso_batch* b) {
         s.m_ptr = b->mc + t; s.ld = cap; s.samples = nullptr; s.samp_h = b->samp_h + (size_t)t * iters * 3;
         s.frame = b->first_frame + (unsigned long long)t;
         s.tr_h = b->tr_h + (size_t)t * iters * 6; s.ok_h = b->ok_h + (size_t)t * iters; s.cnt_h = b->cnt_h + (size_t)t * iters;
+        s.rot = b->rot + (size_t)t * viso_rot_bytes(iters);
         s.tr = b->tr + (size_t)t * 6; s.ok = b->ok + t; s.n_inl = b->n_inl + t; s.inl = b->inl + (size_t)t * cap;
     }
     HIP_TRY(hipMemcpy(b->sitems, S.data(), sizeof(SolverItem) * S.size(), hipMemcpyHostToDevice));
@@ -230,7 +232,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     for (int k = 0; k < VISO_NPIN_SLOTS; ++k) { b->n_pin_ev[k] = nullptr; b->n_pin_used[k] = false; }
     b->images = nullptr; b->img_rows = b->img_cols = 0;
     b->h_resp = nullptr; b->h_tmp_kp = nullptr; b->h_tmp_resp = nullptr; b->h_cnt = nullptr; b->h_slots = 0;
-    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr;
+    b->tr_h = nullptr; b->ok_h = b->cnt_h = b->hq = nullptr; b->samp_h = nullptr; b->rot = nullptr;
     const size_t nf = (size_t)n_frames, c = (size_t)cap;
     int r = VISO_OK;
     auto A = [&](int rr) { if (r >= 0 && rr < 0) r = rr; };
@@ -440,7 +442,8 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
         int r;
         if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0 ||
-            (r = dalloc(&b->hq, k + 1)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0) return r;
+            (r = dalloc(&b->hq, k + 1)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0 ||
+            (r = dalloc(&b->rot, (size_t)b->nf * viso_rot_bytes(b->iters))) < 0) return r;
     }
     int r = build_solver_items(b);
     if (r < 0) return r;
@@ -664,7 +667,7 @@ static int run_rest(viso_batch* b) {
     }
     // vector<double> tr(6,0), :1312: ransac_refit_kernel writes the zeros itself where no solve succeeds
     if (b->nf > 1) {
-        if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq, b->ctx->gn_split)) < 0) return r;   // :1313
+        if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq, b->ctx->gn_split, b->cap)) < 0) return r;   // :1313
     }
     if (ss != s) {
         HIP_TRY(hipEventRecord(b->ev_ransac, ss));

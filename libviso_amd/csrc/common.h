@@ -166,6 +166,7 @@ struct SolverItem {            // one ransac_minimize_reproj problem (one frame)
     double* tr_h;              // iters x 6   hypothesis transforms
     int* ok_h;                 // iters
     int* cnt_h;                // iters
+    char* rot;                 // viso_rot_bytes(iters): the hypotheses' rotations for the counting kernel (ransac_rot_kernel)
     double* tr;                // 6  in/out (best_tr)
     int* ok;                   // 1
     int* n_inl;                // 1
@@ -194,7 +195,8 @@ struct TriItem {
 // split: iterations the lane-per-hypothesis kernel runs before it hands undecided hypotheses to the wave-per-hypothesis
 // kernel (viso_ctx::gn_split; 100 = the lane kernel does everything)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split);
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points);
+size_t viso_rot_bytes(int iters);   // bytes of SolverItem::rot
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items, const SolverParamsDev& sp);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,
                                const SolverParamsDev& sp, int cap);

@@ -274,132 +274,258 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
 }
 
 // ---- stage 2: support set sizes (get_inliers per hypothesis, src/viso.cpp:1561-1562) -------------------------
-// Workgroup = one frame x INL_H hypotheses.  Lanes 0..INL_H-1 build the rotations (make_rot once per hypothesis, not
-// once per lane of a wave per hypothesis) into LDS; then every thread keeps one point of the frame in registers and
-// walks the hypotheses, reading R as LDS broadcasts: ballot + popcount per wave, one LDS atomic per (wave, hypothesis).
+// The one RANSAC kernel with real arithmetic in it (25 600 hypotheses x ~1 350 points per 512 frame pairs), on a GPU
+// whose vector ALUs the matcher keeps busy.  Two kernels:
 //
-// This is the one RANSAC kernel that is bound by arithmetic, not latency (25 600 hypotheses x ~1 200 points per 512
-// frame pairs: 43 M fp64 wave-instructions = 80 us of the whole GPU's fp64 issue), and the GPU it shares is saturated by
-// the matcher's vector work.  The verdict "err2 < inlier_threshold^2" is therefore taken in three tiers, the same
-// verdicts bit for bit:
-//   1. fp32 (full-rate FMAs, ~50 instructions) with a rigorous bound of its own error (below): decides every point
-//      whose err2 is further from the threshold than that bound (~0.5 % of the threshold for KITTI-like numbers);
+// ransac_rot_kernel: thread per hypothesis: make_rot once, the rotation stored as fp64 (tiers 2 / 3) and as fp32, the
+// fp32 copies of hypotheses 2p and 2p + 1 INTERLEAVED ({r_j of 2p, r_j of 2p + 1}: what a packed instruction takes as
+// one 64-bit operand) with the pair's share of the tier-1 bound behind them; zeroes the hypothesis' count.  A failed
+// hypothesis gets the identity: the counting loop has no case for it, its count is dropped at the end.
+//
+// inlier_count_kernel: one-wave workgroup per (frame, 64 points), a point per lane in registers, the wave walks ALL the
+// frame's hypotheses two at a time.  The pair's 28 floats are wave uniform: read with SCALAR loads (constant address
+// space: nothing writes them while this kernel runs) and used as scalar operands of the packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) — no vector register, no LDS traffic, no barrier and no per-workgroup
+// prologue goes into the rotations (round 3's workgroup per (frame, 10 hypotheses) built them on ten lanes while 246
+// waited, and re-derived every point's constants for each group of ten).  ballot + popcount per wave (the verdicts
+// stay lane masks: the logic on them is scalar), counts packed per pair in a lane of one register, one global atomic
+// per (wave, hypothesis) at the end; what tier 1 leaves undecided is queued as a bit per lane, pair and half and
+// decided behind the loop, every lane with something queued taking one entry per turn.
+//
+// What that bought, measured (tools/alone_pmc.sh, tools/alone_ab.sh, tools/e2e_ab.sh): 41.0 M -> 19.7 M vector
+// instructions per 512 pairs — and the SAME 78-80 us alone, +0.6 % end to end.  Instruction counts mislead on this
+// chip: a plain v_fma_f32 / v_add_f32 / v_mul_f32 on vector registers issues every ~2.6 cycles per SIMD, a packed one
+// every ~4.7 (two FMAs: 2.3 each — no faster than two plain ones), one with a scalar operand 4.2, a compare 4.4,
+// v_rcp_f32 8 (tools/valu_rate.hip).  Round 3's loop was already made of the cheap kind (~170 issue cycles per 64
+// points and hypothesis); this one is ~130, on 25 % fewer (wave, hypothesis) steps (64-point instead of 256-point
+// granularity), and the tail of fp64 decisions (0.22 % of the tests, 19 % of the instructions) costs it 30 of the
+// 80 us alone.  Kept because it is what the end-to-end step sees: less vector-ALU time under the matcher.
+//
+// The verdict "err2 < inlier_threshold^2" is taken in three tiers, the same verdicts bit for bit:
+//   1. fp32 with a rigorous bound of its own error (below): decides every point whose err2 is further from the
+//      threshold than that bound (~0.5 % of the threshold for KITTI-like numbers);
 //   2. fp64 with one refined reciprocal of Z and its error band (is_inlier_pt);
 //   3. the reference's expression with its three divisions.
 // Tier-1 error bound, u = 2^-24.  Inputs rounded to float: relative error u each.  |R_ij| <= 1, so every camera
 // coordinate (three nested FMAs over products of rounded inputs) is off by at most D = 8u (|X|+|Y|+|Z| + T), T = the
-// largest |t_i| of the workgroup's hypotheses; and |Xc|, |Yc|, |Xc - base| <= N = |X|+|Y|+|Z| + T + base + D.  With
+// larger max|t_i| of the PAIR's two hypotheses (a wild hypothesis loosens the bound of its pair only; round 3 took the
+// largest of ten); and |Xc|, |Yc|, |Xc - base| <= N = |X|+|Y|+|Z| + T + base + D.  With
 // z = 1 / |Zc| and D z <= 1/64, g = f / Zc (v_rcp_f32: 1 ulp) has relative error <= 1.1 D z + 4u, so a projection
 // g * n + c is off by at most |g| (D + 1.2 N (1.1 D z + 4u)) + u (|c| + |p|) = |g| (c1 + c2 z) + u (|c| + |p|) with
 // c1 = D + 4.8 u N, c2 = 1.32 D N, and a residual e = o - p by that + u (|o| + |e|).  Summed over the four residuals
 // (|p_k| <= |o_k| + |e_k|): every residual is off by at most de = |g| (c1 + c2 z) + u (Cm + 2 sum|e|), Cm = |cu| + |cv| +
 // 2 sum|o|, and err2 = sum e^2 by at most de (2 sum|e| + 4 de) + 4u err2.  Added to it: what the rounding of the
 // REFERENCE's own fp64 evaluation can move its err2 (tier 2's band, generously: 2e-12 Cm^2 + 8e-12 err2).  The bound is
-// itself evaluated in float: inflated by 1/16 and an absolute 1e-30; anything not finite is "undecided".  D, N, c1, c2,
-// Cm are per point, outside the hypothesis loop: ~45 float instructions per (point, hypothesis).
-#define INL_H 10
-struct InlF32 {   // what tier 1 keeps per hypothesis in LDS (floats) next to the fp64 rotation
-    float r[12];  // R row-major, then t
-    float tmax;   // max |t_i|, rounded up
-    float pad[3];
-};
-__global__ __launch_bounds__(256) void inlier_count_kernel(SolverArgs a, int groups) {
-    __shared__ double s_R[INL_H][12];
-    __shared__ __attribute__((aligned(16))) InlF32 s_F[INL_H];
-    __shared__ int s_ok[INL_H];
-    __shared__ int s_cnt[INL_H];
-    __shared__ float s_tm;
+// itself evaluated in float: inflated by 1/16 and an absolute 1e-30; anything not finite is "undecided".  D and N are
+// sums of a per-point and a per-pair part (two packed adds per point and pair give D, K D, N, 1.32 K D; c1 and c2 one
+// FMA and one multiply more), Cm is per point.  The residuals are computed as e = fma(-n, g, o - c) (o - c rounded
+// once per point): one rounding less than o - (g n + c), which is what the bound charges.
+//
+// What has no packed form stays per hypothesis: v_rcp_f32, the three adds of sum|e| and the two FMAs of the bound that
+// take |1/Zc| and |g| (absolute values are source modifiers of the unpacked encodings only), the compares: ~57 vector
+// instructions per point and PAIR, against ~46 per point and hypothesis in round 3.
+typedef float inl_f2 __attribute__((ext_vector_type(2)));
+#define INL_FMA(A, B, C) __builtin_elementwise_fma((A), (B), (C))
+#define INL_K 2.2578125f   // 1.0625 (the bound's inflation) x 2.125 (the loop works with 2 de, inflated once more)
+
+// layout of a frame's rotation store (SolverItem::rot, viso_rot_bytes(iters) bytes): np = ceil(iters / 2) pair blocks of
+// INL_PAIR_F floats (12 x float2 rotation / translation, then the pair's four bound constants), then iters x 12 doubles
+#define INL_PAIR_F 28
+__host__ __device__ inline size_t rot_off_d(int iters) { return (size_t)((iters + 1) / 2) * (INL_PAIR_F * 4); }
+size_t viso_rot_bytes(int iters) { return (rot_off_d(iters) + (size_t)iters * 96 + 127) & ~(size_t)127; }
+
+__global__ __launch_bounds__(256) void ransac_rot_kernel(SolverArgs a) {
+    const int np2 = ((a.iters + 1) / 2) * 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n_items * np2) return;
+    const int item = (int)(idx / np2), t = (int)(idx % np2);
+    const SolverItem S = a.items[item];
+    float* F = reinterpret_cast<float*>(S.rot) + (size_t)(t >> 1) * INL_PAIR_F + (t & 1);
+    const bool ok = t < a.iters && S.ok_h[t] != 0;
+    if (t < a.iters) S.cnt_h[t] = 0;
+    float tm = 0.f;
+    if (!ok) {   // a failed hypothesis (or the padding of an odd count): the identity — counted like any other, dropped at the end
+#pragma unroll
+        for (int j = 0; j < 12; ++j) F[2 * j] = (j == 0 || j == 4 || j == 8) ? 1.f : 0.f;
+    } else {
+        double tr[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * t + j];
+        RotDev R;
+        make_rot(tr, R);
+        double* o = reinterpret_cast<double*>(S.rot + rot_off_d(a.iters)) + (size_t)t * 12;
+        o[0] = R.r00; o[1] = R.r01; o[2] = R.r02; o[3] = R.r10; o[4] = R.r11; o[5] = R.r12;
+        o[6] = R.r20; o[7] = R.r21; o[8] = R.r22; o[9] = R.tx; o[10] = R.ty; o[11] = R.tz;
+        const double v[12] = {R.r00, R.r01, R.r02, R.r10, R.r11, R.r12, R.r20, R.r21, R.r22, R.tx, R.ty, R.tz};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const float f = (float)v[j];
+            F[2 * j] = f;
+            if (j >= 9) tm = fmaxf(tm, fabsf(f));
+        }
+    }
+    // the pair's share of the tier-1 bound (inlier_count_kernel): T = the larger max|t_i| of the two (threads t, t ^ 1:
+    // the same wave, the pair count per frame is even), rounded up; NaN / inf stay what they are (nothing is decided then)
+    const float U = 5.9604645e-8f;
+    const float T = fmaxf(tm, __shfl_xor(tm, 1)) * (1.f + 4.f * U);
+    if (!(t & 1)) {
+        float* P = F + 24;
+        const float dT = 8.f * U * T * (1.f + 4.f * U);
+        P[0] = dT;                                   // D  = dP + dT
+        P[1] = dT * INL_K * (1.f + 4.f * U);         // DK = K D
+        P[2] = T * (1.f + 4.f * U);                  // N  = nP + T
+        P[3] = dT * (1.32f * INL_K) * (1.f + 4.f * U);   // 1.32 K D
+    }
+}
+
+__device__ __forceinline__ float inl_abs_add_abs(float a, float b) { float d; asm("v_add_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float inl_add_abs(float acc, float a, float b) {   // acc + |a| + |b|
+    float d;
+    asm("v_add_f32_e64 %0, %1, |%2|\n\tv_add_f32_e64 %0, %0, |%3|" : "=&v"(d) : "v"(acc), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float inl_fma_abs0(float a, float b, float c) { float d; asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float inl_fma_abs1(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+__global__ __launch_bounds__(64) void inlier_count_kernel(SolverArgs a, int chunks) {
+    // ONE wave per workgroup: nothing is shared between waves, and a finished wave's slot is refilled at once — with four
+    // waves per workgroup the waves of a CU started, reached their fp64 tail and ended together, and the latencies at both
+    // ends (the chain of dependent loads at the start, the trip to the fp64 rotations at the end) were paid by idle SIMDs
+    typedef unsigned long long u64;
+    const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const SolverItem S = a.items[item];
+    const int lane = threadIdx.x;
+    const int i = chunk * 64 + lane;
+    // the point's loads do not wait for the point count (rows up to ld exist; what lies past the count is never counted)
+    const int ii = max(min(i, S.ld - 1), 0);
+    const int m = *S.m_ptr;
     const float U = 5.9604645e-8f;                       // 2^-24
-    const float ff = (float)a.sp.f, cuf = (float)a.sp.cu, cvf = (float)a.sp.cv, basef = (float)a.sp.base;
+    const float ff = (float)a.sp.f, basef = (float)a.sp.base;
     const float thr2f = (float)(a.sp.inlier_threshold * a.sp.inlier_threshold);
     const float thr_lo = thr2f * (1.f - 4.f * U), thr_hi = thr2f * (1.f + 4.f * U);   // float brackets of the double threshold
-    const float cabs = fabsf(cuf) + fabsf(cvf);
-    for (int unit = blockIdx.x; unit < a.n_items * groups; unit += gridDim.x) {
-    const int item = unit / groups, h0 = (unit % groups) * INL_H;
-    const SolverItem S = a.items[item];
-    const int m = *S.m_ptr;
-    const int nh = min(INL_H, a.iters - h0);
-    const int lane = threadIdx.x & 63;
-    if ((int)threadIdx.x < nh) {
-        const int h = h0 + threadIdx.x;
-        const int ok = S.ok_h[h];
-        s_ok[threadIdx.x] = ok;
-        s_cnt[threadIdx.x] = 0;
-        if (ok) {
-            double tr[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) tr[j] = S.tr_h[6 * h + j];
-            RotDev R;
-            make_rot(tr, R);
-            double* o = s_R[threadIdx.x];
-            o[0] = R.r00; o[1] = R.r01; o[2] = R.r02; o[3] = R.r10; o[4] = R.r11; o[5] = R.r12;
-            o[6] = R.r20; o[7] = R.r21; o[8] = R.r22; o[9] = R.tx; o[10] = R.ty; o[11] = R.tz;
-            InlF32& F = s_F[threadIdx.x];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) F.r[j] = (float)o[j];
-            F.tmax = fmaxf(fmaxf(fabsf(F.r[9]), fabsf(F.r[10])), fabsf(F.r[11])) * (1.f + 4.f * U);
-        } else {
-            s_F[threadIdx.x].tmax = 0.f;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {   // T: the largest |t_i| of this workgroup's hypotheses
-        float t = 0.f;
-        for (int k = 0; k < nh; ++k) t = fmaxf(t, s_F[k].tmax);
-        s_tm = t;
-    }
-    __syncthreads();
-    const float tmax_wg = s_tm;
-    for (int base = 0; base < m; base += 256) {
-        const int i = base + threadIdx.x;
-        const bool have = i < m;
-        const int ii = have ? i : 0;
-        const double X0 = S.X[0 * S.ld + ii], X1 = S.X[1 * S.ld + ii], X2 = S.X[2 * S.ld + ii];
-        const double o0 = S.obs[0 * S.ld + ii], o1 = S.obs[1 * S.ld + ii], o2 = S.obs[2 * S.ld + ii], o3 = S.obs[3 * S.ld + ii];
-        // tier-1 operands: the point in float, and the per-point constants of its error bound
-        const float x0 = (float)X0, x1 = (float)X1, x2 = (float)X2;
-        const float q0 = (float)o0, q1 = (float)o1, q2 = (float)o2, q3 = (float)o3;
-        const float pabs = (fabsf(x0) + fabsf(x1) + fabsf(x2)) * (1.f + 8.f * U) + tmax_wg;
-        const float D = fmaf(8.f * U, pabs, 1e-30f);
-        const float N = (pabs + basef + D) * (1.f + 8.f * U);
-        const float c1 = fmaf(4.8f * U, N, D) * 1.0625f, c2 = 1.32f * D * N * 1.0625f;
-        const float zlim = 0.015625f / D;                                   // D z <= 1/64
+    const float cabs = fabsf((float)a.sp.cu) + fabsf((float)a.sp.cv);
+    const int iters = a.iters, npair = (iters + 1) >> 1;
+    // the point: tier-1 operands and the per-point constants of its error bound
+    const double X0d = S.X[0 * S.ld + ii], X1d = S.X[1 * S.ld + ii], X2d = S.X[2 * S.ld + ii];
+    const double o0d = S.obs[0 * S.ld + ii], o1d = S.obs[1 * S.ld + ii], o2d = S.obs[2 * S.ld + ii], o3d = S.obs[3 * S.ld + ii];
+    const float x0 = (float)X0d, x1 = (float)X1d, x2 = (float)X2d;
+    if (i - lane >= m) return;   // wave uniform: none of the wave's points exists
+    const bool have = i < m;
+    const float qc0 = (float)(o0d - a.sp.cu), qc1 = (float)(o1d - a.sp.cv), qc2 = (float)(o2d - a.sp.cu), qc3 = (float)(o3d - a.sp.cv);
+    // D = dP + dT, N = nP + T, the point's share here, the pair's (the larger max|t_i| of its two hypotheses) from the
+    // rotation store; PD = {dP, K dP}, PN = {nP, 1.32 K dP}: two packed adds give D, K D, N and 1.32 K D
+    inl_f2 PD, PN;
+    float k1j, kmag;
+    {
+        const float q0 = (float)o0d, q1 = (float)o1d, q2 = (float)o2d, q3 = (float)o3d;
+        const float pP = (fabsf(x0) + fabsf(x1) + fabsf(x2)) * (1.f + 8.f * U);
+        const float dP = fmaf(8.f * U, pP, 1e-30f);
+        PD.x = dP; PD.y = dP * INL_K * (1.f + 4.f * U);
+        PN.x = fmaf(pP + basef, 1.f + 32.f * U, 1e-30f);   // N >= |X|+|Y|+|Z| + T + base + D: D <= 2^-20 (|X|+|Y|+|Z| + T)
+        PN.y = dP * (1.32f * INL_K) * (1.f + 4.f * U);
         const float Cm = (cabs + 2.f * (fabsf(q0) + fabsf(q1) + fabsf(q2) + fabsf(q3))) * (1.f + 8.f * U);
-        const float k1 = U * Cm * 1.0625f, kmag = fmaf(2e-12f * Cm, Cm, 1e-30f);
-        for (int k = 0; k < nh; ++k) {
-            if (!s_ok[k]) continue;   // uniform
-            const InlF32& F = s_F[k];
-            const float xc = fmaf(F.r[0], x0, fmaf(F.r[1], x1, fmaf(F.r[2], x2, F.r[9])));
-            const float yc = fmaf(F.r[3], x0, fmaf(F.r[4], x1, fmaf(F.r[5], x2, F.r[10])));
-            const float zc = fmaf(F.r[6], x0, fmaf(F.r[7], x1, fmaf(F.r[8], x2, F.r[11])));
-            const float rz = __builtin_amdgcn_rcpf(zc);
-            const float g = ff * rz;
-            const float p0 = fmaf(xc, g, cuf), p1 = fmaf(yc, g, cvf), p2 = fmaf(xc - basef, g, cuf);
-            const float e0 = q0 - p0, e1 = q1 - p1, e2 = q2 - p2, e3 = q3 - p1;
-            const float s2 = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, e3 * e3)));
-            const float z = fabsf(rz);
-            const float esum2 = 2.f * (fabsf(e0) + fabsf(e1) + fabsf(e2) + fabsf(e3));
-            const float de = fmaf(fabsf(g), fmaf(c2, z, c1), fmaf(2.125f * U, esum2 * 0.5f, k1));   // 2u sum|e|, inflated
-            const float ds = fmaf(fmaf(de, fmaf(4.f, de, esum2), 5.f * U * s2), 1.0625f, kmag);
-            const bool ok1 = z <= zlim;
-            const bool sure_in = ok1 && s2 + ds < thr_lo;
-            const bool sure_out = ok1 && s2 - ds > thr_hi;
-            bool in = sure_in;
-            if (!(sure_in || sure_out)) {   // tiers 2 and 3 (also everything that is not finite)
-                RotDev R;                   // only the entries predict_point reads
-                const double* r = s_R[k];
-                R.r00 = r[0]; R.r01 = r[1]; R.r02 = r[2]; R.r10 = r[3]; R.r11 = r[4]; R.r12 = r[5];
-                R.r20 = r[6]; R.r21 = r[7]; R.r22 = r[8]; R.tx = r[9]; R.ty = r[10]; R.tz = r[11];
-                in = is_inlier_pt(R, a.sp, X0, X1, X2, o0, o1, o2, o3, nullptr);
-            }
-            const int c = __popcll(__ballot(in && have));
-            if (lane == 0 && c) atomicAdd(&s_cnt[k], c);
+        const float k1 = U * Cm * 1.0625f;
+        kmag = fmaf(2e-12f * Cm, Cm, 1e-30f);
+        // the loop works with de2 = 2.125 de (2 de, inflated): err2 is off by de (2 sum|e| + 4 de) = 2 de (sum|e| + 2 de)
+        k1j = k1 * 2.125f;
+    }
+    const inl_f2 X0 = {x0, x0}, X1 = {x1, x1}, X2 = {x2, x2};
+    const inl_f2 QC0 = {qc0, qc0}, QC1 = {qc1, qc1}, QC2 = {qc2, qc2}, QC3 = {qc3, qc3};
+    const inl_f2 K1 = {k1j, k1j}, KM = {kmag, kmag};
+    const inl_f2 FF = {ff, ff}, BASE = {basef, basef};
+    const inl_f2 ESC = {2.125f * U * 2.125f, 2.125f * U * 2.125f}, S2C = {5.3125f * U, 5.3125f * U};
+    const u64 act = __ballot(true), mhave = __ballot(have);
+    typedef const __attribute__((address_space(4))) inl_f2* crot_t;
+    const crot_t Fall = (crot_t)(const void*)S.rot;
+    const double* rotd = reinterpret_cast<const double*>(S.rot + rot_off_d(iters));
+    for (int kb = 0; kb < npair; kb += 64) {   // blocks of 64 pairs: lane p of vcnt holds the counts of pair kb + p, 16 bits each
+    int vcnt = 0;
+    u64 qa = 0, qb = 0;   // per lane: pairs of the block whose first / second hypothesis tier 1 left undecided for the lane's point
+    const int ke = min(npair, kb + 64);
+    // did the two hypotheses of pair kb + lane converge?  Asked for here, used when the lane flushes the pair's counts: a
+    // failed hypothesis (and the padding of an odd count) has the identity in the rotation store, is counted like any
+    // other and dropped at the end — the loop has no case for it (the scalar unit issues one instruction per cycle for the
+    // whole CU, as the four SIMDs do together: every scalar instruction of the loop counts like a vector one)
+    const bool ok0 = kb + lane < ke && S.ok_h[2 * (kb + lane)] != 0;
+    const bool ok1 = kb + lane < ke && 2 * (kb + lane) + 1 < iters && S.ok_h[2 * (kb + lane) + 1] != 0;
+    for (int kp = kb; kp < ke; ++kp) {
+        const crot_t F = Fall + (size_t)kp * (INL_PAIR_F / 2);
+        const inl_f2 r0 = F[0], r1 = F[1], r2 = F[2], r3 = F[3], r4 = F[4], r5 = F[5], r6 = F[6], r7 = F[7], r8 = F[8],
+                     tx = F[9], ty = F[10], tz = F[11];
+        // the bound's constants for this point and pair: c1 = D + 4.8 u N, c2 = 1.32 D N, times K
+        const inl_f2 VD = PD + F[12], VN = PN + F[13];              // {D, K D}, {N, 1.32 K D}
+        const float c1j = fmaf(4.8f * U * INL_K * (1.f + 4.f * U), VN.x, VD.y), c2j = VN.y * VN.x;
+        const inl_f2 xc = INL_FMA(r0, X0, INL_FMA(r1, X1, INL_FMA(r2, X2, tx)));
+        const inl_f2 yc = INL_FMA(r3, X0, INL_FMA(r4, X1, INL_FMA(r5, X2, ty)));
+        const inl_f2 zc = INL_FMA(r6, X0, INL_FMA(r7, X1, INL_FMA(r8, X2, tz)));
+        inl_f2 rz;
+        rz.x = __builtin_amdgcn_rcpf(zc.x);
+        rz.y = __builtin_amdgcn_rcpf(zc.y);
+        const inl_f2 g = rz * FF;
+        const inl_f2 xb = xc - BASE;
+        const inl_f2 e0 = INL_FMA(-xc, g, QC0), e1 = INL_FMA(-yc, g, QC1), e2 = INL_FMA(-xb, g, QC2), e3 = INL_FMA(-yc, g, QC3);
+        const inl_f2 s2 = INL_FMA(e0, e0, INL_FMA(e1, e1, INL_FMA(e2, e2, e3 * e3)));
+        // sum|e| and the two FMAs on |1/Zc| and |g|: absolute values are source modifiers of the unpacked encodings (as C
+        // the compiler builds them from twelve v_and_b32 and packed adds)
+        inl_f2 es, de2;   // sum|e|; 2.125 de
+        es.x = inl_add_abs(inl_abs_add_abs(e0.x, e1.x), e2.x, e3.x);
+        es.y = inl_add_abs(inl_abs_add_abs(e0.y, e1.y), e2.y, e3.y);
+        const inl_f2 tail = INL_FMA(ESC, es, K1);     // 2u sum|e| + u Cm, inflated
+        de2.x = inl_fma_abs0(g.x, inl_fma_abs1(c2j, rz.x, c1j), tail.x);
+        de2.y = inl_fma_abs0(g.y, inl_fma_abs1(c2j, rz.y, c1j), tail.y);
+        const inl_f2 ds = INL_FMA(de2, de2 + es, INL_FMA(S2C, s2, KM));
+        const inl_f2 hi = s2 + ds, lo = s2 - ds;
+        // the verdicts as lane masks (the compares' own results; the logic on them is scalar): "in" = bound holds and
+        // err2 + ds below the threshold; undecided = neither that nor (bound holds and err2 - ds above).  Anything not
+        // finite fails every compare: undecided
+        const inl_f2 DD = {VD.x, VD.x};
+        const inl_f2 dz = rz * DD;                                   // D z <= 1/64
+        const u64 oka = __ballot(fabsf(dz.x) <= 0.015625f), okb = __ballot(fabsf(dz.y) <= 0.015625f);
+        const u64 lta = __ballot(hi.x < thr_lo), ltb = __ballot(hi.y < thr_lo);
+        const u64 gta = __ballot(lo.x > thr_hi), gtb = __ballot(lo.y > thr_hi);
+        const u64 ina = oka & lta, inb = okb & ltb;
+        const u64 una = act & ~(oka & (lta | gta)), unb = act & ~(okb & (ltb | gtb));
+        if (una | unb) {   // wave uniform, ~0.2 % of the points: queued for tiers 2 and 3 behind the block (a bit per pair and half)
+            const u64 bit = 1ull << (kp - kb);
+            if ((una >> lane) & 1) qa |= bit;
+            if ((unb >> lane) & 1) qb |= bit;
         }
+        const int add = __popcll(ina & mhave) + (__popcll(inb & mhave) << 16);
+        vcnt += lane == (kp & 63) ? add : 0;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < nh) S.cnt_h[h0 + threadIdx.x] = s_cnt[threadIdx.x];   // 0 for failed hypotheses
-    __syncthreads();   // s_R / s_ok / s_cnt are rewritten by the next unit
+    // one point per lane: <= 64 per field
+    if (ok0 && (vcnt & 0xffff)) atomicAdd(&S.cnt_h[2 * (kb + lane)], vcnt & 0xffff);
+    if (ok1 && ((unsigned)vcnt >> 16)) atomicAdd(&S.cnt_h[2 * (kb + lane) + 1], (int)((unsigned)vcnt >> 16));
+    // tiers 2 and 3 for what tier 1 left undecided (also everything that is not finite), all of the block's at once:
+    // every lane with something queued takes its first entry per turn — one trip to the fp64 rotations per turn instead
+    // of one per pair with an undecided point (taken on the spot, with one or two lanes active, those trips were 40 % of
+    // the kernel's time).  An inlier adds itself to its hypothesis' count
+    while (qa | qb) {   // per lane
+        int h;
+        if (qa) { h = 2 * (kb + __builtin_ctzll(qa)); qa &= qa - 1; }
+        else { h = 2 * (kb + __builtin_ctzll(qb)) + 1; qb &= qb - 1; }
+        if (h >= iters || S.ok_h[h] == 0) continue;   // a failed hypothesis: not counted
+        RotDev R;               // only the entries predict_point reads
+        const double* r = rotd + (size_t)h * 12;
+        R.r00 = r[0]; R.r01 = r[1]; R.r02 = r[2]; R.r10 = r[3]; R.r11 = r[4]; R.r12 = r[5];
+        R.r20 = r[6]; R.r21 = r[7]; R.r22 = r[8]; R.tx = r[9]; R.ty = r[10]; R.tz = r[11];
+        if (is_inlier_pt(R, a.sp, X0d, X1d, X2d, o0d, o1d, o2d, o3d, nullptr) && have) atomicAdd(&S.cnt_h[h], 1);
     }
+    }
+}
+
+// ransac_rot_kernel + inlier_count_kernel over n_items frames of at most max_points points
+static int launch_inlier_count(hipStream_t s, const SolverArgs& a, int max_points) {
+    const long long nt = (long long)a.n_items * (((a.iters + 1) / 2) * 2);
+    if (nt <= 0) return VISO_OK;
+    hipLaunchKernelGGL(ransac_rot_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    const int chunks = (max_points + 63) / 64;
+    if (chunks <= 0) return VISO_OK;
+    if ((long long)a.n_items * chunks > 0x7fffffffLL) { viso_set_error("ransac: too many points in one launch"); return VISO_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(a.n_items * chunks)), dim3(64), 0, s, a, chunks);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
 }
 
 // ---- workgroup helpers ------------------------------------------------------
@@ -597,7 +723,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
 
 
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split) {
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points) {
     if (n_items <= 0) return VISO_OK;
     SolverArgs a;
     a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
@@ -620,9 +746,8 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
         if (cb > (nh + 3) / 4) cb = (nh + 3) / 4;
         hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        const int groups = (iters + INL_H - 1) / INL_H;
-        hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(n_items * groups)), dim3(256), 0, s, a, groups);
-        HIP_TRY(hipGetLastError());
+        const int ri = launch_inlier_count(s, a, max_points);
+        if (ri < 0) return ri;
     }
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(n_items), dim3(REFIT_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
@@ -769,13 +894,12 @@ extern "C" int viso_support_sizes(const double* X, const double* obs, int m, con
     HIP_TRY(hipMemcpyAsync(dmisc, hm.data(), sizeof(int) * hm.size(), hipMemcpyHostToDevice, c->stream));
     SolverItem it{};
     it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + n_h;
+    if ((r = ctx_scratch(c, 9, viso_rot_bytes(n_h), (void**)&it.rot)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
     SolverArgs a{};
     a.items = ditem; a.n_items = 1; a.iters = n_h;
     fill_solver_params(&a.sp, p);
-    const int groups = (n_h + INL_H - 1) / INL_H;
-    hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)groups), dim3(256), 0, c->stream, a, groups);
-    HIP_TRY(hipGetLastError());
+    if ((r = launch_inlier_count(c->stream, a, m)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(cnt, dmisc + 4 + n_h, sizeof(int) * n_h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VISO_OK;
@@ -822,11 +946,12 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.samples = dsamp; it.frame = frame;
     it.samp_h = dqueue + 2 + iters;
     it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + iters;
+    if ((r = ctx_scratch(c, 9, viso_rot_bytes(iters), (void**)&it.rot)) < 0) return r;
     it.tr = dtr; it.ok = dmisc + 1; it.n_inl = dmisc + 2; it.inl = dinl;
     HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split)) < 0) return r;
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split, m)) < 0) return r;
     int res[4];
     HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(best_tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));

@@ -160,6 +160,26 @@ def test_support_sizes_of_the_counting_kernel_equal_get_inliers(viso, oracle):
     assert want.max() > 200
 
 
+@pytest.mark.parametrize("n_h,m", [(1, 1), (1, 63), (7, 65), (13, 300), (129, 700), (200, 1000)])
+def test_support_sizes_for_odd_counts_and_short_point_sets(viso, oracle, n_h, m):
+    """inlier_count_kernel walks the hypotheses two at a time (an odd count leaves half a pair), in blocks of 64 pairs
+    (129 and 200 hypotheses: two blocks), 64 points per wave (m not a multiple of 64, less than one wave); a motion that
+    is not a number supports nothing."""
+    rng = np.random.default_rng(1000 * n_h + m)
+    X, obs, tr_gt, param = synth.make_solver_case(21, m=max(m, 8), outlier_frac=0.25, noise=0.5)
+    X, obs = np.ascontiguousarray(X[:, :m]), np.ascontiguousarray(obs[:, :m])
+    motions = np.array([tr_gt + rng.normal(0, rng.choice([1e-4, 1e-2, 0.3]), 6) * np.array([0.05, 0.05, 0.05, 1, 1, 1]) for _ in range(n_h)])
+    if n_h > 2:
+        motions[n_h // 2, 1] = np.nan
+        motions[n_h - 1, 4] = 1e6              # a wild translation: its pair's bound, nobody else's
+    with np.errstate(all="ignore"):
+        want = np.array([len(oracle.get_inliers(X, obs, t, param)[0]) for t in motions])
+    got = libviso_amd.support_sizes(X, obs, motions, param)
+    assert np.array_equal(got, want), (got - want)
+    if n_h > 2:
+        assert got[n_h // 2] == 0
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_first_gn_step_at_the_convergence_threshold(viso, oracle, seed):
     """src/viso.cpp:1610 (Q7): "converged" iff no component of the step exceeds thresh.  thresh is set to the largest

@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/alone_ab.sh KERNEL A.so B.so ...: duration of one kernel of the full pipeline ALONE on the GPU (tools/run_alone.py under
+# rocprofv3 --kernel-trace --stats) for alternative builds of the library, in one gpurun call
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PYTHONPATH=.
+k=$1; shift
+for so in "$@"; do
+  export VISO_HIP_SO=$so
+  rm -rf gpurun_out/aab
+  rocprofv3 --kernel-trace --stats -d gpurun_out/aab -o s --output-format csv -- python3 tools/run_alone.py 512 12 > gpurun_out/aab.txt 2>&1
+  echo "$so: $(grep "$k" gpurun_out/aab/s_kernel_stats.csv | cut -d, -f1,2,4,6,7 | cut -c1-120)"
+done

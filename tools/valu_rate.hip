@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) a[i] = seed + i * 77u + threadIdx.x;
     const unsigned long long sel = seed * 0x9E3779B97F4A7C15ULL;   // a lane mask for v_cndmask
+    unsigned long long sm[2] = {0, 0};
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -64,6 +65,18 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
             if (KIND == 39) asm volatile("v_add_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(a[i]) : "v"(b));
             if (KIND == 40) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
             if (KIND == 41) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 42) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d[i]) : "v"(db), "v"(dc));
+            if (KIND == 43) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d[i]) : "s"(sel), "v"(dc));
+            if (KIND == 44) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(d[i]) : "v"(db));
+            if (KIND == 45) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(d[i]) : "v"(db));
+            if (KIND == 46) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 47) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(sm[i & 1]) : "v"(a[i]), "v"(b));
+            if (KIND == 48) asm volatile("v_add_f32_e64 %0, |%1|, |%0|" : "+v"(a[i]) : "v"(b));
+            if (KIND == 49) asm volatile("v_fma_f32 %0, |%1|, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (KIND == 50) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "s"(seed), "v"(c));
+            if (KIND == 51) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d[i]) : "s"(sel), "v"(dc));
+            if (KIND == 52) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (KIND == 53) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -71,6 +84,7 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) s += a[i] + (uint32_t)d[i];
+    s += (uint32_t)(sm[0] ^ sm[1]);
     if (s == 0x12345678u) out[0] = s;   // never true in practice; keeps the chains alive
 }
 
@@ -148,5 +162,17 @@ int main() {
     run<39>("v_add_u32 dpp row_shl:4 bank_mask", d, ghz);
     run<40>("v_bcnt_u32_b32", d, ghz);
     run<41>("v_cvt_i32_f32", d, ghz);
+    run<42>("v_pk_fma_f32", d, ghz);
+    run<43>("v_pk_fma_f32 (sgpr pair operand)", d, ghz);
+    run<51>("v_pk_fma_f32 (sgpr, op_sel_hi splat)", d, ghz);
+    run<44>("v_pk_mul_f32", d, ghz);
+    run<45>("v_pk_add_f32", d, ghz);
+    run<46>("v_rcp_f32", d, ghz);
+    run<47>("v_cmp_lt_f32_e64 (sgpr dst)", d, ghz);
+    run<53>("v_cmp_lt_f32_e32 (vcc)", d, ghz);
+    run<48>("v_add_f32 |a|, |b|", d, ghz);
+    run<49>("v_fma_f32 |a|, b, c", d, ghz);
+    run<50>("v_fma_f32 (sgpr operand)", d, ghz);
+    run<52>("v_mul_f32", d, ghz);
     return 0;
 }
