@@ -529,7 +529,10 @@ static int launch_inlier_count(hipStream_t s, const SolverArgs& a, int max_point
 }
 
 // ---- workgroup helpers ------------------------------------------------------
+#ifndef REFIT_THREADS
 #define REFIT_THREADS 256
+#endif
+#define REFIT_WAVES (REFIT_THREADS / 64)
 
 // ordered (ascending index) compaction of the inliers of `tr` into out[];
 // returns the count to every thread.  scratch: >= 8 ints of LDS.
@@ -551,7 +554,9 @@ __device__ int block_inliers(const double* tr, const SolverParamsDev& sp, const 
         __syncthreads();
         int off = running;
         for (int w = 0; w < wave; ++w) off += scratch[w];
-        const int total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < REFIT_WAVES; ++w) total += scratch[w];
         if (in) out[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(msk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk, 0u))] = i;
         running += total;
         __syncthreads();
@@ -623,7 +628,9 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
             const int r6 = min(row, 5), c7 = min(col, 6);
             const int lo = min(r6, c7), hi = max(r6, c7);
             const int k = c7 == 6 ? 21 + r6 : lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
-            double acc = ((red[k] + red[27 + k]) + red[54 + k]) + red[81 + k];
+            double acc = red[k];
+#pragma unroll
+            for (int w = 1; w < REFIT_WAVES; ++w) acc += red[27 * w + k];   // fixed order over the waves
             bool regular = lu_lane_step<0>(acc, lane, row, col);              // cv::solve(DECOMP_LU), :1602-1606
             regular = regular && lu_lane_step<1>(acc, lane, row, col);
             regular = regular && lu_lane_step<2>(acc, lane, row, col);
