@@ -368,7 +368,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
         }
 #undef MU_TEST4
         const bool list_ovf = ucnt > MU_UCAP;
-        const int nu = list_ovf ? 0 : ucnt;
+        const int nu = __builtin_amdgcn_readfirstlane(list_ovf ? 0 : ucnt);   // wave uniform: the pipeline's loop control stays scalar
         __builtin_amdgcn_wave_barrier();
         // padding behind the list: copies of the last entry with nobody's membership (scored, never counted)
         if (nu > 0 && lane < MU_PAD) ul[nu + lane] = ul[nu - 1] | 0xff000000u;
