@@ -465,9 +465,10 @@ def main():
                 valu_busy = {"rocprof_VALUBusy": sq["SQ_ACTIVE_INST_VALU"] / 256.0 / cyc,
                              "cycles_per_valu_instruction_per_simd": cyc * N_SIMD / sq["SQ_INSTS_VALU"],
                              "note": "rocprofv3's VALUBusy formula (SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE per XCD; the counter books "
-                                     "one quad-cycle per instruction, so the ~10 % full-rate instructions push it past 1): the vector ALUs "
-                                     "never idle. A SIMD issues one VALU instruction every ~3.85 shader cycles, the mix of 4-cycle and "
-                                     "2-cycle opcodes above: what is left to gain is fewer instructions, not a higher issue rate"}
+                                     "one quad-cycle per instruction): the share of the launch's cycles in which the vector ALUs execute. "
+                                     "cycles_per_valu_instruction_per_simd is the issue interval this launch sustained: 4 is what a loop of "
+                                     "half-rate opcodes can reach (tools/valu_rate.hip measures 4.2-4.7 for them, 2.4-2.7 for the full-rate "
+                                     "ones): what is left to gain is fewer or cheaper instructions, not a higher issue rate"}
         if "TCP_TCC_READ_REQ_sum" in sq:
             l2b = sq["TCP_TCC_READ_REQ_sum"] * L2_REQ_BYTES
             peak = L2_GATHER_PEAK_GBS if kname in GATHER_KERNELS else L2_STREAM_PEAK_GBS
@@ -475,11 +476,11 @@ def main():
             ceilings["l2"] = {"achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak,
                               "what": "TCP_TCC_READ_REQ_sum x 128 B (row gathers served by the XCD L2) against the guide's "
                                       + ("indexed-row gather rate" if kname in GATHER_KERNELS else "aggregate L2 rate")}
-    # The unit that is FULL names the bound: rocprofv3's VALUBusy >= 0.95 means the vector ALUs never idle, whatever the
+    # The unit that is FULL names the bound: rocprofv3's VALUBusy >= 0.90 means the vector ALUs hardly ever idle, whatever the
     # nominal-peak fractions say (they differ by a few hundredths and flip with the choice of a peak: 18.8 TB/s is the
     # guide's best case for another row shape, this kernel's own gather pattern measured 15-17 TB/s).  Otherwise the
     # highest fraction.
-    if valu_busy is not None and valu_busy["rocprof_VALUBusy"] >= 0.95 and "valu_issue" in ceilings:
+    if valu_busy is not None and valu_busy["rocprof_VALUBusy"] >= 0.90 and "valu_issue" in ceilings:
         bound = "valu_issue"
     else:
         bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
@@ -521,7 +522,7 @@ def main():
         "kernel_ms_in_timed_region_note": f"{n_streams} batches in flight share the CUs: not a per-step cost, may exceed ms_per_step",
         "ceilings": ceilings,
         "valu_busy": valu_busy,
-        "bound_rule": "valu_issue when rocprofv3's VALUBusy >= 0.95 (the unit that is full), else the highest nominal-peak fraction",
+        "bound_rule": "valu_issue when rocprofv3's VALUBusy >= 0.90 (the unit that is full), else the highest nominal-peak fraction",
         "step_hbm": step_hbm,
         "scored_pairs_per_launch": pairs,
         "overflow_queries_per_step": n_overflow,
