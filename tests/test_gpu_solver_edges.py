@@ -180,6 +180,42 @@ def test_support_sizes_for_odd_counts_and_short_point_sets(viso, oracle, n_h, m)
         assert got[n_h // 2] == 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_support_sizes_over_random_cameras_and_thresholds(viso, oracle, seed):
+    """The tier-1 bound of inlier_count_kernel is made of the camera's numbers (f, principal point, base), the points'
+    magnitudes, the pair's translations and the threshold: random cameras (focal lengths 50 .. 5000, principal points
+    inside, outside and far from the image, bases 0 .. 5), scenes scaled from centimetres to kilometres, thresholds
+    from 1e-3 to 1e3 pixels (and 0: nothing is an inlier), motions from exact to wild — the counts are get_inliers'."""
+    from libviso_amd.abi import Param
+    rng = np.random.default_rng(7700 + seed)
+    f = float(10 ** rng.uniform(1.7, 3.7))
+    cu, cv = float(rng.choice([0.0, 600.0, -3000.0, 40000.0])), float(rng.choice([0.0, 180.0, 9000.0]))
+    base = float(rng.choice([0.0, 0.1, 0.54, 5.0]))
+    scale = float(10 ** rng.uniform(-2, 3))
+    m = int(rng.integers(100, 1500))
+    param = Param.default(base=base, f=f, cu=cu, cv=cv)
+    Z = rng.uniform(2.0, 80.0, m) * scale
+    X = np.stack([rng.uniform(-1, 1, m) * Z, rng.uniform(-0.4, 0.4, m) * Z, Z])
+    tr_gt = np.r_[rng.normal(0, 0.02, 3), rng.normal(0, 0.5, 3) * scale]
+    from libviso_amd.synth import rot_from_tr
+    R, t = rot_from_tr(tr_gt)
+    Xc = (X.T @ R.T + t).T
+    obs = np.stack([f * Xc[0] / Xc[2] + cu, f * Xc[1] / Xc[2] + cv, f * (Xc[0] - base) / Xc[2] + cu, f * Xc[1] / Xc[2] + cv])
+    for thr in (0.0, 1e-3, 0.5, 2.0, 1e3):
+        param.inlier_threshold = thr
+        o = obs + rng.normal(0, max(thr, 0.3), obs.shape) * rng.choice([0.2, 0.7, 1.0, 3.0], (1, m))
+        motions = np.array([tr_gt] + [tr_gt + rng.normal(0, sd, 6) * np.r_[0.05, 0.05, 0.05, scale, scale, scale]
+                                     for sd in (1e-6, 1e-4, 1e-3, 1e-2, 0.1, 1.0, 30.0) for _ in range(3)])
+        with np.errstate(all="ignore"):
+            want = np.array([len(oracle.get_inliers(X, o, tmo, param)[0]) for tmo in motions])
+        got = libviso_amd.support_sizes(X, o, motions, param)
+        assert np.array_equal(got, want), (seed, thr, f, cu, cv, base, scale, got - want)
+        if thr == 0.0:
+            assert got.max() == 0
+        else:
+            assert 0 < want[0] < m, (thr, want[0], m)      # the exact motion: inliers and outliers both present
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_first_gn_step_at_the_convergence_threshold(viso, oracle, seed):
     """src/viso.cpp:1610 (Q7): "converged" iff no component of the step exceeds thresh.  thresh is set to the largest
