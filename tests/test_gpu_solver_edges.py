@@ -203,7 +203,7 @@ def test_support_sizes_over_random_cameras_and_thresholds(viso, oracle, seed):
     obs = np.stack([f * Xc[0] / Xc[2] + cu, f * Xc[1] / Xc[2] + cv, f * (Xc[0] - base) / Xc[2] + cu, f * Xc[1] / Xc[2] + cv])
     for thr in (0.0, 1e-3, 0.5, 2.0, 1e3):
         param.inlier_threshold = thr
-        o = obs + rng.normal(0, max(thr, 0.3), obs.shape) * rng.choice([0.2, 0.7, 1.0, 3.0], (1, m))
+        o = obs + rng.normal(0, thr if thr > 0 else 0.3, obs.shape) * rng.choice([0.2, 0.7, 1.0, 3.0], (1, m))   # errors around the threshold
         motions = np.array([tr_gt] + [tr_gt + rng.normal(0, sd, 6) * np.r_[0.05, 0.05, 0.05, scale, scale, scale]
                                      for sd in (1e-6, 1e-4, 1e-3, 1e-2, 0.1, 1.0, 30.0) for _ in range(3)])
         with np.errstate(all="ignore"):
