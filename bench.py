@@ -242,6 +242,9 @@ def main():
                     help="the K-step timed region is repeated until this much GPU work has been timed (at least 5 regions)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight per GPU, one HIP stream each (steps go round robin over them)")
+    ap.add_argument("--image-frames", type=int, default=512,
+                    help="frame pairs per batch of the image-in legs (128 until late in round 4: the synthetic images take 35 ms "
+                         "per frame to paint; 512 like the other legs: +16 %% / +6 %%)")
     ap.add_argument("--e2e-streams", type=int, default=5,
                     help="batches in flight for the end-to-end leg (each adds a RANSAC stream of its own: 5 measured +1.3 %% over 3; 0 = --streams)")
     ap.add_argument("--ab-variants", default="", help="matcher variants timed by --ab (default: all of the build)")
@@ -614,7 +617,7 @@ def main():
     # lanes' kernels.
     streaming = None
     iseq = None
-    nfi = min(nf, 129)
+    nfi = min(nf, max(2, args.image_frames + 1))
     if not args.no_streaming:
         hosts = []
         for rev in (False, True):
