@@ -7,6 +7,6 @@ k=$1; shift
 for so in "$@"; do
   export VISO_HIP_SO=$so
   rm -rf gpurun_out/aab
-  rocprofv3 --kernel-trace --stats -d gpurun_out/aab -o s --output-format csv -- python3 tools/run_alone.py 512 12 > gpurun_out/aab.txt 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/aab -o s --output-format csv -- python3 ${SCRIPT:-tools/run_alone.py} ${SCRIPT_ARGS:-512 12} > gpurun_out/aab.txt 2>&1
   echo "$so: $(grep "$k" gpurun_out/aab/s_kernel_stats.csv | cut -d, -f1,2,4,6,7 | cut -c1-120)"
 done

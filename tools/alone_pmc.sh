@@ -7,7 +7,7 @@ k=$1; shift
 for so in "$@"; do
   export VISO_HIP_SO=$so
   rm -rf gpurun_out/apmc
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace -d gpurun_out/apmc -o p --output-format csv -- python3 tools/run_alone.py 512 6 > /dev/null 2>gpurun_out/apmc.err
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace -d gpurun_out/apmc -o p --output-format csv -- python3 ${SCRIPT:-tools/run_alone.py} ${SCRIPT_ARGS:-512 6} > /dev/null 2>gpurun_out/apmc.err
   python3 - "$k" "$so" <<'PY'
 import collections, csv, sys
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
