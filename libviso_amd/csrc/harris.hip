@@ -133,9 +133,20 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
     for (int i = 0; i < 5; ++i) { H[i] = 0.f; G[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ra[i] = 0.f; rb[i] = 0.f; rc[i] = 0.f; }
+    // the five bytes of the NEXT row are asked for before this row's arithmetic (the LDS round trip at the top of every
+    // row was exposed: the walk is one dependent chain per row)
+    unsigned char nb0, nb1, nb2, nb3, nb4;
+    {
+        const unsigned char* p = s_img + (y0 - 3 + 3) * HW_PITCH + lxc;
+        nb0 = p[0]; nb1 = p[1]; nb2 = p[2]; nb3 = p[3]; nb4 = p[4];
+    }
     for (int q = y0 - 3; q < y1 + 3; ++q) {            // row-pass row q (relative to ty0) = LDS row q + 3
-        const unsigned char* p = s_img + (q + 3) * HW_PITCH + lxc;
-        const float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2], p3 = (float)p[3], p4 = (float)p[4];
+        const float p0 = (float)nb0, p1 = (float)nb1, p2 = (float)nb2, p3 = (float)nb3, p4 = (float)nb4;
+        {
+            const unsigned char* p = s_img + (min(q + 1, y1 + 2) + 3) * HW_PITCH + lxc;
+            nb0 = p[0]; nb1 = p[1]; nb2 = p[2]; nb3 = p[3]; nb4 = p[4];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { H[i] = H[i + 1]; G[i] = G[i + 1]; }
         // RowFilter: k0*S0, += k1*S1, ... left to right.  Derivative taps -1,-2,0,2,1: small integers, exact in any order
@@ -160,9 +171,20 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
         }
         // box filter, row sums: (S[x-1] + S[x]) + S[x+1]; the neighbours by DPP wave shifts (one instruction each, folded
         // into the adds by the compiler; a ds_bpermute shuffle costs four)
-        const float sa = (wave_shr1(ca) + ca) + wave_shl1(ca);
-        const float sb = (wave_shr1(cb) + cb) + wave_shl1(cb);
-        const float sc = (wave_shr1(cc) + cc) + wave_shl1(cc);
+        float sa, sb, sc;
+        {   // six v_add_f32 with a DPP operand (left to the compiler: six DPP moves and three packed adds).  One asm block
+            // behind an s_nop 1: a register written by the previous two vector instructions must not be a DPP source, and
+            // the compiler's hazard recognizer does not look inside inline asm; inside the block every DPP source is older
+            float ta, tb, tc;
+            asm("s_nop 1\n\t"
+                "v_add_f32_dpp %0, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32_dpp %1, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32_dpp %2, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32_dpp %3, %6, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32_dpp %4, %7, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32_dpp %5, %8, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(sa), "=&v"(sb), "=&v"(sc) : "v"(ca), "v"(cb), "v"(cc));
+        }
         ra[0] = ra[1]; ra[1] = ra[2]; ra[2] = sa;
         rb[0] = rb[1]; rb[1] = rb[2]; rb[2] = sb;
         rc[0] = rc[1]; rc[1] = rc[2]; rc[2] = sc;
@@ -171,13 +193,17 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
         const int gy = ty0 + y;
         if (gy >= rows) break;                         // uniform: rows below the image are nobody's
         // BORDER_REFLECT_101 of the cov image in y: row -1 is row 1, row `rows` is row rows - 2
-        float ua = ra[0], ub = rb[0], uc = rc[0], da = ra[2], db = rb[2], dc = rc[2];
-        if (rows > 1) {
-            if (gy == 0) { ua = da; ub = db; uc = dc; }
-            if (gy == rows - 1) { da = ra[0]; db = rb[0]; dc = rc[0]; }
-        } else { ua = ra[1]; ub = rb[1]; uc = rc[1]; da = ra[1]; db = rb[1]; dc = rc[1]; }
+        // (the image's first and last row only; as real branches — the empty asm keeps the compiler from turning them
+        // into selects on every row of every tile.  The overwritten sums belong to rows outside the image: dead)
+        if (gy == 0 || gy == rows - 1) {                   // uniform
+            asm volatile("" ::: "memory");
+            if (rows > 1) {
+                if (gy == 0) { ra[0] = ra[2]; rb[0] = rb[2]; rc[0] = rc[2]; }
+                if (gy == rows - 1) { ra[2] = ra[0]; rb[2] = rb[0]; rc[2] = rc[0]; }
+            } else { ra[0] = ra[1]; rb[0] = rb[1]; rc[0] = rc[1]; ra[2] = ra[1]; rb[2] = rb[1]; rc[2] = rc[1]; }
+        }
         // column sums: (rs[y-1] + rs[y]) + rs[y+1]
-        const float a = (ua + ra[1]) + da, b = (ub + rb[1]) + db, c = (uc + rc[1]) + dc;
+        const float a = (ra[0] + ra[1]) + ra[2], b = (rb[0] + rb[1]) + rb[2], c = (rc[0] + rc[1]) + rc[2];
         const float m1 = a * c, m2 = b * b;
         const float m3 = m1 - m2;
         const float tr = a + c;
@@ -441,13 +467,17 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
     unsigned long long tau = 0;
     int n = 0;
     harris_walk_band(s_img, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool valid) {
-        // push position of the reference's scan (x outer, y inner, :953-955)
-        const unsigned long long key = valid ? harris_key(fabsf(R), x * th + y) : 0ull;
-        const bool take = key > tau;
+        // a candidate is everything above tau; the test is on the key's HIGH word (|response| bits) alone: the few pixels
+        // that tie tau's high word come along and lose in harris_keep_best, and the 64-bit key (push position of the
+        // reference's scan: x outer, y inner, :953-955) is only built for the lanes that store one
+        const float v = fabsf(R);
+        const bool nz = !(fabsf(v - 0.f) <= 1e-6f * fabsf(v));   // isEqual(response, .0f), src/misc.cpp:10-14
+        const uint32_t hi = __float_as_uint(v);
+        const bool take = valid && nz && hi >= (uint32_t)(tau >> 32);
         const unsigned long long m = __ballot(take);
         if (m) {                                           // uniform
             const int at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (take) list[at] = key;
+            if (take) list[at] = ((unsigned long long)hi << 32) | (uint32_t)(0xffffffffu - (uint32_t)(x * th + y));
             n += __popcll(m);
             if (n > HD_CAND - 64) {                        // uniform: the next row might not fit
                 __builtin_amdgcn_wave_barrier();
