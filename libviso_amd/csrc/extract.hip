@@ -120,10 +120,13 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(const ImageView* __re
             if (k < nk && t < VISO_EXT_WIN * VISO_EXT_WIN) {
                 const int wy = t / VISO_EXT_WIN, wx = t - wy * VISO_EXT_WIN;
                 const int ry = py[k] - 6 + wy, rx = px[k] - 6 + wx;
-                // only neighbours of in-image centres (0 < y < rows, 0 < x < cols) are ever read: rows 0..rows,
-                // columns 0..cols, of which only `rows` / `cols` themselves need the reflection
-                if (ry >= 0 && ry <= rows && rx >= 0 && rx <= cols)
+                if (px[k] >= 6 && py[k] >= 6 && px[k] + 6 < cols && py[k] + 6 < rows) {   // wave uniform: the whole window inside the image
+                    w[k][u] = im[(uint32_t)(ry * cols + rx)];
+                } else if (ry >= 0 && ry <= rows && rx >= 0 && rx <= cols) {
+                    // only neighbours of in-image centres (0 < y < rows, 0 < x < cols) are ever read: rows 0..rows,
+                    // columns 0..cols, of which only `rows` / `cols` themselves need the reflection
                     w[k][u] = im[(size_t)reflect101(ry, rows) * cols + reflect101(rx, cols)];
+                }
             }
         }
     }
