@@ -84,44 +84,84 @@ __global__ __launch_bounds__(CIRC_THREADS) void circle_general_kernel(CircleArgs
 // collect_matches of the joined stereo match of frame t (:501-514), Xp_c column = triangulate_rectified<double> of the
 // joined stereo match of frame t-1 (:1137-1162, no clamp) — the same expressions, evaluated only for the rows the
 // solver will read, so the batch path needs no collect / triangulate launch of its own.
+#define CIRC_NCH 8   // chunks of CIRC_THREADS stereo matches whose lookups are in flight together
 __global__ __launch_bounds__(CIRC_THREADS) void circle_join_kernel(const JoinItem* items, int n_items, SolverParamsDev sp) {
-    __shared__ int scratch[8];
+    __shared__ int s_tot[CIRC_NCH][CIRC_THREADS / 64];
     if ((int)blockIdx.x >= n_items) return;
     const JoinItem J = items[blockIdx.x];
     const int M = *J.lr_cnt;
     int running = 0;
-    for (int base = 0; base < M; base += CIRC_THREADS) {
-        const int r = base + threadIdx.x;
-        int ok = 0, ileft = 0, iright = 0, ileft_prev = 0, iright_prev = 0, k = 0;
-        if (r < M) {
-            ileft = J.lr[3 * r]; iright = J.lr[3 * r + 1];
-            const int2 a = J.res11[ileft];
-            if (a.x >= 0) {
-                ileft_prev = a.x;
-                k = J.pos_lrp[ileft_prev];
-                if (k >= 0) {
-                    iright_prev = J.res_lrp[ileft_prev].x;
-                    ok = J.res22[iright].x == iright_prev;
+    // The join of a match is a chain of four dependent table lookups, and the output order needs a scan over the chunk:
+    // chunk by chunk (a chain, a scan, the stores, the next chain ...) the kernel was seven chains long for the bench's
+    // ~1 700 matches per frame (59 us, 4 us of it arithmetic).  The lookups of CIRC_NCH chunks are asked for together —
+    // one chain's latency for all of them — then the chunks are scanned and stored in order.
+    for (int base = 0; base < M; base += CIRC_NCH * CIRC_THREADS) {
+        int ok[CIRC_NCH], ileft[CIRC_NCH], iright[CIRC_NCH], ileft_prev[CIRC_NCH], iright_prev[CIRC_NCH], k[CIRC_NCH];
+#pragma unroll
+        for (int c = 0; c < CIRC_NCH; ++c) {
+            const int r = base + c * CIRC_THREADS + (int)threadIdx.x;
+            ok[c] = 0; ileft[c] = 0; iright[c] = 0; ileft_prev[c] = 0; iright_prev[c] = 0; k[c] = 0;
+            if (r < M) {
+                ileft[c] = J.lr[3 * r]; iright[c] = J.lr[3 * r + 1];
+                const int2 a = J.res11[ileft[c]];
+                if (a.x >= 0) {
+                    ileft_prev[c] = a.x;
+                    k[c] = J.pos_lrp[ileft_prev[c]];
+                    if (k[c] >= 0) {
+                        iright_prev[c] = J.res_lrp[ileft_prev[c]].x;
+                        ok[c] = J.res22[iright[c]].x == iright_prev[c];
+                    }
                 }
             }
         }
-        int total;
-        const int o = running + block_exclusive_scan(ok, &total, scratch);
-        if (ok) {
-            J.circ[4 * o + 0] = ileft; J.circ[4 * o + 1] = iright;
-            J.circ[4 * o + 2] = ileft_prev; J.circ[4 * o + 3] = iright_prev;
-            J.pcl[2 * o + 0] = r; J.pcl[2 * o + 1] = k;
-            const float2 a1 = J.kp1[ileft], a2 = J.kp2[iright];
-            J.x_c[0 * J.ldc + o] = (double)a1.x; J.x_c[1 * J.ldc + o] = (double)a1.y;
-            J.x_c[2 * J.ldc + o] = (double)a2.x; J.x_c[3 * J.ldc + o] = (double)a2.y;
-            const float2 p1 = J.kp1p[ileft_prev], p2 = J.kp2p[iright_prev];
-            const double uL = p1.x, vL = p1.y, uR = p2.x;
-            const double d = uL - uR;                       // src/viso.cpp:1148-1151, no clamp
-            J.Xp_c[0 * J.ldc + o] = sp.base * (uL - sp.cu) / d;
-            J.Xp_c[1 * J.ldc + o] = sp.base * (vL - sp.cv) / d;
-            J.Xp_c[2 * J.ldc + o] = sp.f * sp.base / d;
+        // output rows: the matches in order (chunk after chunk, thread after thread): ONE pass over the workgroup for all
+        // CIRC_NCH chunks — every wave scans its 64 flags per chunk and leaves its chunk totals in LDS
+        int o[CIRC_NCH];
+        {
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            int excl[CIRC_NCH];
+#pragma unroll
+            for (int c = 0; c < CIRC_NCH; ++c) {
+                const unsigned long long m = __ballot(ok[c] != 0);
+                excl[c] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (lane == 0) s_tot[c][wave] = __popcll(m);
+            }
+            __syncthreads();
+            int before = running;
+#pragma unroll
+            for (int c = 0; c < CIRC_NCH; ++c) {
+                int inwg = 0;
+#pragma unroll
+                for (int w = 0; w < CIRC_THREADS / 64; ++w) {
+                    const int t = s_tot[c][w];
+                    if (w < wave) inwg += t;
+                    running += t;
+                }
+                o[c] = before + inwg + excl[c];
+                before = running;
+            }
+            __syncthreads();   // s_tot is rewritten by the next super-chunk
         }
-        running += total;
+        // the joined rows' keypoints of all chunks asked for together, then triangulated and stored
+#pragma unroll
+        for (int c = 0; c < CIRC_NCH; ++c) {
+            if (ok[c]) {
+                const int r = base + c * CIRC_THREADS + (int)threadIdx.x;
+                const int oc = o[c];
+                J.circ[4 * oc + 0] = ileft[c]; J.circ[4 * oc + 1] = iright[c];
+                J.circ[4 * oc + 2] = ileft_prev[c]; J.circ[4 * oc + 3] = iright_prev[c];
+                J.pcl[2 * oc + 0] = r; J.pcl[2 * oc + 1] = k[c];
+                const float2 a1 = J.kp1[ileft[c]], a2 = J.kp2[iright[c]];
+                J.x_c[0 * J.ldc + oc] = (double)a1.x; J.x_c[1 * J.ldc + oc] = (double)a1.y;
+                J.x_c[2 * J.ldc + oc] = (double)a2.x; J.x_c[3 * J.ldc + oc] = (double)a2.y;
+                const float2 p1 = J.kp1p[ileft_prev[c]], p2 = J.kp2p[iright_prev[c]];
+                const double uL = p1.x, vL = p1.y, uR = p2.x;
+                const double d = uL - uR;                       // src/viso.cpp:1148-1151, no clamp
+                J.Xp_c[0 * J.ldc + oc] = sp.base * (uL - sp.cu) / d;
+                J.Xp_c[1 * J.ldc + oc] = sp.base * (vL - sp.cv) / d;
+                J.Xp_c[2 * J.ldc + oc] = sp.f * sp.base / d;
+            }
+        }
     }
     if (threadIdx.x == 0) *J.mc = running;
 }
