@@ -207,6 +207,30 @@ int viso_harris_response(const uint8_t* img, int rows, int cols, double k, float
 int viso_detect_harris_binned(const uint8_t* img, int rows, int cols, int n_features, int nbinx, int nbiny,
                               double k, float* kp, float* resp_out, int* n_out);
 
+/* Where a plain-family call's time goes (diagnostics; bench.py `drop_in_per_call`, viso_host_gputest).  The plain family is
+ * what the patched reference loop calls once per function per frame (src/viso.cpp:1240-1313: match_desc x3,
+ * collect_matches, triangulate_rectified, match_circle, ransac_minimize_reproj), so a frame's cost there is seven
+ * synchronous host->device->host round trips.  With profiling on, every call brackets its phases with hipEvents on the
+ * default context's stream: h2d_us = input copies, kernel_us = the kernels, d2h_us = result copies (up to the last byte
+ * on the host), wait_us = host time blocked in hipStreamSynchronize / blocking copies, host_us = wall time of the call.
+ * Sums over the calls since profiling was switched on.  Profiling costs a few microseconds per call: rates are quoted
+ * with it off. */
+#define VISO_PLAIN_MATCH_DESC 0
+#define VISO_PLAIN_COLLECT_MATCHES 1
+#define VISO_PLAIN_TRIANGULATE 2
+#define VISO_PLAIN_MATCH_CIRCLE 3
+#define VISO_PLAIN_RANSAC 4
+#define VISO_PLAIN_MINIMIZE 5
+#define VISO_PLAIN_GET_INLIERS 6
+#define VISO_PLAIN_N 7
+typedef struct viso_plain_times {
+    int64_t calls;
+    double host_us, h2d_us, kernel_us, d2h_us, wait_us;
+} viso_plain_times;
+int viso_plain_profile(int enable);                        /* 1: zero the sums and start; 0: stop */
+int viso_plain_profile_get(int fn, viso_plain_times* out); /* fn: VISO_PLAIN_* */
+const char* viso_plain_profile_name(int fn);
+
 /* ------------------------------------------- batched, device-resident family
  *
  * A frame set holds `n_frames` stereo frames resident in HBM:

@@ -151,7 +151,8 @@ def __getattr__(name):   # MATCHER_VARIANTS / DEFAULT_MATCHER: resolved on first
     if name == "MATCHER_VARIANTS":
         return matcher_variants()
     if name == "DEFAULT_MATCHER":   # the build's default, or $VISO_MATCHER (viso_matcher_default)
-        return int(load().viso_matcher_default())
+        L = load()   # builds older than viso_matcher_default (VISO_HIP_SO A/B runs) started every context with variant 3
+        return int(L.viso_matcher_default()) if hasattr(L, "viso_matcher_default") else 3
     raise AttributeError(name)
 
 

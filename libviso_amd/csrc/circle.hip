@@ -3,6 +3,8 @@
 // collect_matches, :1137-1162 triangulate_rectified, :1292-1305 gather).
 #include "common.h"
 
+#include <string.h>
+
 #define CIRC_THREADS 256
 
 // ------------------------------------------------------------------ general
@@ -12,7 +14,8 @@
 struct CircleArgs {
     const int* lr; const int* lrp; const int* m11; const int* m22;
     int n_lr, n_lrp, n11, n22;
-    int* circ; int* pcl; int cap; int* out_n;
+    int* rows;      // out: 6 ints per joined row: circ_match (ileft, iright, ileft_prev, iright_prev) | match_pcl (i, k)
+    int cap; int* out_n;
 };
 
 template <bool WRITE>
@@ -30,9 +33,9 @@ __device__ __forceinline__ int circle_row(const CircleArgs& a, int i, int off) {
                     if (WRITE) {
                         const int o = off + n;
                         if (o < a.cap) {
-                            a.circ[4 * o + 0] = ileft; a.circ[4 * o + 1] = iright;
-                            a.circ[4 * o + 2] = ileft_prev; a.circ[4 * o + 3] = iright_prev;
-                            a.pcl[2 * o + 0] = i; a.pcl[2 * o + 1] = k;
+                            a.rows[6 * o + 0] = ileft; a.rows[6 * o + 1] = iright;
+                            a.rows[6 * o + 2] = ileft_prev; a.rows[6 * o + 3] = iright_prev;
+                            a.rows[6 * o + 4] = i; a.rows[6 * o + 5] = k;
                         }
                     }
                     ++n;
@@ -61,16 +64,91 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* scra
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(CIRC_THREADS) void circle_general_kernel(CircleArgs a) {
-    __shared__ int scratch[8];
+// ------------------------------------------------------------------ plain family: tables when the keys allow it
+// viso_match_circle for the lists match_desc produces: at most one row per query index in match11 (key [0]), match_lr_prev
+// (key [0]) and match22 (key [0]), so every hop of the reference's nested loops (:215-240) hits at most one row and the
+// loops collapse to three table lookups per row of match_lr, in row order.  ONE workgroup: build the three tables
+// (key -> row, -1 = absent) in global scratch with compare-and-swap -- a second row with the same key, or a key outside
+// [0, tabn), sets `dup` and the SAME kernel falls back to the literal nested loops above (arbitrary lists, duplicate
+// keys included: the reference's semantics for any caller).  The general path on 1 500-row lists costs 200 ms (three nested
+// linear scans per row on one workgroup); the tables 10 us.  Result block: the row count, then 6 ints per row (circ_match | match_pcl).
+#define CIRCT_THREADS 1024
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total, int* scratch) {   // scratch: 16 ints of LDS
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CIRCT_THREADS / 64; ++w) { const int t = scratch[w]; if (w < wave) base += t; tot += t; }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs a, int* tab, int tabn) {
+    __shared__ int scratch[16];
+    __shared__ int s_dup;
+    int* t11 = tab; int* tlrp = tab + tabn; int* t22 = tab + 2 * tabn;
+    if (threadIdx.x == 0) s_dup = 0;
+    for (int i = threadIdx.x; i < 3 * tabn; i += CIRCT_THREADS) tab[i] = -1;
+    __syncthreads();
+    int dup = 0;
+    for (int j = threadIdx.x; j < a.n11; j += CIRCT_THREADS) {
+        const int key = a.m11[3 * j];
+        if (key < 0 || key >= tabn || atomicCAS(&t11[key], -1, j) != -1) dup = 1;
+    }
+    for (int k = threadIdx.x; k < a.n_lrp; k += CIRCT_THREADS) {
+        const int key = a.lrp[3 * k];
+        if (key < 0 || key >= tabn || atomicCAS(&tlrp[key], -1, k) != -1) dup = 1;
+    }
+    for (int l = threadIdx.x; l < a.n22; l += CIRCT_THREADS) {
+        const int key = a.m22[3 * l];
+        if (key < 0 || key >= tabn || atomicCAS(&t22[key], -1, l) != -1) dup = 1;
+    }
+    if (dup) s_dup = 1;
+    __threadfence_block();
+    __syncthreads();
     int running = 0;
-    for (int base = 0; base < a.n_lr; base += CIRC_THREADS) {
-        const int i = base + threadIdx.x;
-        const int cnt = (i < a.n_lr) ? circle_row<false>(a, i, 0) : 0;
-        int total;
-        const int off = running + block_exclusive_scan(cnt, &total, scratch);
-        if (cnt) circle_row<true>(a, i, off);
-        running += total;
+    if (s_dup) {   // arbitrary lists: the literal loops
+        for (int base = 0; base < a.n_lr; base += CIRCT_THREADS) {
+            const int i = base + threadIdx.x;
+            const int cnt = (i < a.n_lr) ? circle_row<false>(a, i, 0) : 0;
+            int total;
+            const int off = running + block_exclusive_scan_1024(cnt, &total, scratch);
+            if (cnt) circle_row<true>(a, i, off);
+            running += total;
+        }
+    } else {
+        for (int base = 0; base < a.n_lr; base += CIRCT_THREADS) {
+            const int i = base + threadIdx.x;
+            int ok = 0, ileft = 0, iright = 0, ileft_prev = 0, iright_prev = 0, k = 0;
+            if (i < a.n_lr) {
+                ileft = a.lr[3 * i]; iright = a.lr[3 * i + 1];
+                const int j = (ileft >= 0 && ileft < tabn) ? t11[ileft] : -1;
+                if (j >= 0) {
+                    ileft_prev = a.m11[3 * j + 1];
+                    k = (ileft_prev >= 0 && ileft_prev < tabn) ? tlrp[ileft_prev] : -1;
+                    if (k >= 0) {
+                        iright_prev = a.lrp[3 * k + 1];
+                        const int l = (iright >= 0 && iright < tabn) ? t22[iright] : -1;
+                        ok = l >= 0 && a.m22[3 * l + 1] == iright_prev;
+                    }
+                }
+            }
+            int total;
+            const int o = running + block_exclusive_scan_1024(ok, &total, scratch);
+            if (ok && o < a.cap) {
+                a.rows[6 * o + 0] = ileft; a.rows[6 * o + 1] = iright; a.rows[6 * o + 2] = ileft_prev; a.rows[6 * o + 3] = iright_prev;
+                a.rows[6 * o + 4] = i; a.rows[6 * o + 5] = k;
+            }
+            running += total;
+        }
     }
     if (threadIdx.x == 0) *a.out_n = running;
 }
@@ -212,6 +290,10 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double* x, int m
 }
 
 // ------------------------------------------------------------ plain family
+// Every call: inputs packed into the context's pinned block and sent with ONE copy (PlainStage), results fetched with
+// ONE copy behind ONE synchronize.
+#define CIRC_TAB_MAX (1 << 20)   // keys below this take the tables (3 ints each); larger or negative ones the literal loops
+
 extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_prev, int n_lrp,
                                  const int32_t* m11, int n11, const int32_t* m22, int n22,
                                  int32_t* circ, int32_t* pcl, int cap, int* out_n) {
@@ -225,29 +307,52 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    int *d[4], *dcirc, *dpcl, *dn;
-    const int32_t* h[4] = {lr, lr_prev, m11, m22};
-    const int n[4] = {n_lr, n_lrp, n11, n22};
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_MATCH_CIRCLE, c->stream);
+    // size of the tables: the largest key of the three keyed lists (a look at ~4 500 ints; argument inspection, no arithmetic of the path)
+    long long kmax = -1;
+    bool tables = true;
+    for (int j = 0; j < n11 && tables; ++j) { const int k = m11[3 * j]; if (k < 0 || k >= CIRC_TAB_MAX) tables = false; else if (k > kmax) kmax = k; }
+    for (int j = 0; j < n_lrp && tables; ++j) { const int k = lr_prev[3 * j]; if (k < 0 || k >= CIRC_TAB_MAX) tables = false; else if (k > kmax) kmax = k; }
+    for (int j = 0; j < n22 && tables; ++j) { const int k = m22[3 * j]; if (k < 0 || k >= CIRC_TAB_MAX) tables = false; else if (k > kmax) kmax = k; }
+    const int tabn = tables ? (int)(kmax + 1) : 0;   // 0: every key is "out of range" -> the kernel takes the literal loops
     int r;
-    for (int k = 0; k < 4; ++k) {
-        if ((r = ctx_scratch(c, k, sizeof(int) * 3 * (size_t)(n[k] + 1), (void**)&d[k])) < 0) return r;
-        if (n[k]) HIP_TRY(hipMemcpyAsync(d[k], h[k], sizeof(int) * 3 * (size_t)n[k], hipMemcpyHostToDevice, c->stream));
-    }
-    if ((r = ctx_scratch(c, 4, sizeof(int) * 4 * (size_t)(cap + 1), (void**)&dcirc)) < 0) return r;
-    if ((r = ctx_scratch(c, 5, sizeof(int) * 2 * (size_t)(cap + 1), (void**)&dpcl)) < 0) return r;
-    if ((r = ctx_scratch(c, 6, sizeof(int) * 4, (void**)&dn)) < 0) return r;
-    CircleArgs a{d[0], d[1], d[2], d[3], n_lr, n_lrp, n11, n22, dcirc, dpcl, cap, dn};
-    hipLaunchKernelGGL(circle_general_kernel, dim3(1), dim3(CIRC_THREADS), 0, c->stream, a);
+    PlainStage in;
+    const size_t in_bytes = PlainStage::need(sizeof(int) * 3 * (size_t)n_lr) + PlainStage::need(sizeof(int) * 3 * (size_t)n_lrp) +
+                            PlainStage::need(sizeof(int) * 3 * (size_t)n11) + PlainStage::need(sizeof(int) * 3 * (size_t)n22);
+    if ((r = in.begin(c, in_bytes)) < 0) return r;
+    CircleArgs a{};
+    a.lr = in.put(lr, 3 * (size_t)n_lr); a.lrp = in.put(lr_prev, 3 * (size_t)n_lrp);
+    a.m11 = in.put(m11, 3 * (size_t)n11); a.m22 = in.put(m22, 3 * (size_t)n22);
+    a.n_lr = n_lr; a.n_lrp = n_lrp; a.n11 = n11; a.n22 = n22; a.cap = cap;
+    char *dout, *hout; int* dtab;
+    const size_t out_bytes = 256 + sizeof(int) * 6 * (size_t)cap;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, out_bytes, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, out_bytes, &hout)) < 0) return r;
+    if ((r = ctx_scratch(c, 16, sizeof(int) * 3 * (size_t)(tabn + 1), (void**)&dtab)) < 0) return r;
+    a.out_n = reinterpret_cast<int*>(dout); a.rows = reinterpret_cast<int*>(dout + 256);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
+    hipLaunchKernelGGL(circle_table_kernel, dim3(1), dim3(CIRCT_THREADS), 0, c->stream, a, dtab, tabn);
     HIP_TRY(hipGetLastError());
-    int cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, dn, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    // with unique keys a row of match_lr joins at most once: n_lr rows bound the result; duplicate keys can give more
+    const int w1 = cap < n_lr ? cap : n_lr;
+    HIP_TRY(hipMemcpyAsync(hout, dout, 256 + sizeof(int) * 6 * (size_t)w1, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
-    *out_n = cnt;
+    const int cnt = *reinterpret_cast<const int*>(hout);
     const int w = cnt < cap ? cnt : cap;
-    if (w > 0) {
-        HIP_TRY(hipMemcpy(circ, dcirc, sizeof(int) * 4 * (size_t)w, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(pcl, dpcl, sizeof(int) * 2 * (size_t)w, hipMemcpyDeviceToHost));
+    if (w > w1) HIP_TRY(hipMemcpy(hout + 256 + sizeof(int) * 6 * (size_t)w1, dout + 256 + sizeof(int) * 6 * (size_t)w1,
+                                  sizeof(int) * 6 * (size_t)(w - w1), hipMemcpyDeviceToHost));
+    pp.wait_end();
+    *out_n = cnt;
+    const int* rows = reinterpret_cast<const int*>(hout + 256);
+    for (int i = 0; i < w; ++i) {
+        circ[4 * i + 0] = rows[6 * i + 0]; circ[4 * i + 1] = rows[6 * i + 1]; circ[4 * i + 2] = rows[6 * i + 2]; circ[4 * i + 3] = rows[6 * i + 3];
+        pcl[2 * i + 0] = rows[6 * i + 4]; pcl[2 * i + 1] = rows[6 * i + 5];
     }
+    pp.mark(3);
     if (cnt > cap) { viso_set_error("viso_match_circle: %d rows needed, cap %d", cnt, cap); return VISO_ERR_ARG; }
     return VISO_OK;
 }
@@ -267,24 +372,35 @@ extern "C" int viso_collect_matches(const float* kp1, int n1, const float* kp2, 
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    float2 *dk1, *dk2; int *dm, *dcnt; double* dx; TriItem* dit;
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_COLLECT_MATCHES, c->stream);
     int r;
-    if ((r = ctx_scratch(c, 0, sizeof(float2) * (size_t)n1, (void**)&dk1)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(float2) * (size_t)n2, (void**)&dk2)) < 0) return r;
-    if ((r = ctx_scratch(c, 2, sizeof(int) * 3 * (size_t)n, (void**)&dm)) < 0) return r;
-    if ((r = ctx_scratch(c, 3, sizeof(double) * 4 * (size_t)n, (void**)&dx)) < 0) return r;
-    if ((r = ctx_scratch(c, 4, sizeof(int) * 4, (void**)&dcnt)) < 0) return r;
-    if ((r = ctx_scratch(c, 5, sizeof(TriItem), (void**)&dit)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(dk1, kp1, sizeof(float2) * (size_t)n1, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dk2, kp2, sizeof(float2) * (size_t)n2, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dm, match, sizeof(int) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dcnt, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    TriItem it{dk1, dk2, dm, dcnt, dx, nullptr, n};
-    HIP_TRY(hipMemcpyAsync(dit, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    PlainStage in;
+    const size_t in_bytes = PlainStage::need(sizeof(float2) * (size_t)n1) + PlainStage::need(sizeof(float2) * (size_t)n2) +
+                            PlainStage::need(sizeof(int) * 3 * (size_t)n) + PlainStage::need(sizeof(int)) + PlainStage::need(sizeof(TriItem));
+    if ((r = in.begin(c, in_bytes)) < 0) return r;
+    char *dout, *hout;
+    const size_t out_bytes = sizeof(double) * 4 * (size_t)n;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, out_bytes, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, out_bytes, &hout)) < 0) return r;
+    TriItem it{};
+    it.kp1 = in.put(reinterpret_cast<const float2*>(kp1), (size_t)n1);
+    it.kp2 = in.put(reinterpret_cast<const float2*>(kp2), (size_t)n2);
+    it.match = in.put(match, 3 * (size_t)n);
+    it.m_cnt = in.put(&n, 1);
+    it.x = reinterpret_cast<double*>(dout); it.X = nullptr; it.ld = n;
+    const TriItem* dit = in.put(&it, 1);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
     SolverParamsDev sp{};
     if ((r = launch_collect_triangulate(c->stream, dit, 1, sp, n)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(x, dx, sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    pp.wait_end();
+    memcpy(x, hout, out_bytes);
+    pp.mark(3);
     return VISO_OK;
 }
 
@@ -294,16 +410,28 @@ extern "C" int viso_triangulate_rectified(const double* x, int m, const viso_par
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    double *dx, *dX;
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_TRIANGULATE, c->stream);
     int r;
-    if ((r = ctx_scratch(c, 0, sizeof(double) * 4 * (size_t)m, (void**)&dx)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(double) * 3 * (size_t)m, (void**)&dX)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(dx, x, sizeof(double) * 4 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    PlainStage in;
+    if ((r = in.begin(c, PlainStage::need(sizeof(double) * 4 * (size_t)m))) < 0) return r;
+    char *dout, *hout;
+    const size_t out_bytes = sizeof(double) * 3 * (size_t)m;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, out_bytes, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, out_bytes, &hout)) < 0) return r;
+    const double* dx = in.put(x, 4 * (size_t)m);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dx, m, sp, dX);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dx, m, sp, reinterpret_cast<double*>(dout));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(X, dX, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    pp.wait_end();
+    memcpy(X, hout, out_bytes);
+    pp.mark(3);
     return VISO_OK;
 }

@@ -113,13 +113,59 @@ struct viso_ctx {
     // (measured: 9 streams for 3 busy batches -> two chains on one queue, 0.43 -> 0.68 ms per step).
     hipStream_t solver_stream;
     // grow-only scratch for the plain (host-pointer) family
-    void* scratch[16];
-    size_t scratch_bytes[16];
+    void* scratch[24];
+    size_t scratch_bytes[24];
+    // pinned staging of the plain family (grow-only): [0] a call's inputs, packed back to back and sent with ONE
+    // host-to-device copy; [1] a call's results, fetched with ONE device-to-host copy behind ONE synchronize
+    char* pin[2];
+    size_t pin_bytes[2];
+    struct PlainCache* plain;    // the plain family's image cache (plain.hip), created on first use
 };
 
 struct PlainLock { PlainLock(); ~PlainLock(); };   // serialises the plain family on the default context
+// viso_plain_profile: phases of one plain-family call, bracketed by four events on the call's stream (ctx.hip).  Used
+// inside a PlainLock.  mark(1) = inputs enqueued, mark(2) = kernels enqueued, mark(3) = results on the host.
+struct PlainProf {
+    PlainProf(int fn, hipStream_t s);
+    ~PlainProf();
+    void mark(int k);
+    void wait_begin();
+    void wait_end();
+    int fn; hipStream_t s; bool on; int marks; double t0, tw, wait;
+};
 int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
+int ctx_pinned(viso_ctx* c, int which, size_t bytes, char** out);
+void plain_cache_free(viso_ctx* c);   // plain.hip; from viso_ctx_destroy
 viso_ctx* viso_default_ctx();
+
+// One plain-family call's inputs: appended to the context's pinned block (256-B aligned pieces), mirrored at the same
+// offsets in one device block, sent with ONE hipMemcpyAsync.  A pageable hipMemcpyAsync costs 5-10 us of host time
+// per call whatever its size; the plain family used to issue 4-7 of them per function (tools/h2d_probe.hip).
+#define PLAIN_SLOT_IN 14      // ctx_scratch slots of the staging blocks
+#define PLAIN_SLOT_OUT 15
+struct PlainStage {
+    char* h = nullptr; char* d = nullptr; size_t off = 0, cap = 0;
+    static size_t need(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    int begin(viso_ctx* c, size_t bytes) {
+        cap = bytes; off = 0;
+        int r = ctx_pinned(c, 0, bytes, &h);
+        if (r < 0) return r;
+        return ctx_scratch(c, PLAIN_SLOT_IN, bytes, (void**)&d);
+    }
+    template <class T> T* put(const T* src, size_t count) {   // returns the DEVICE address
+        const size_t b = sizeof(T) * count;
+        if (b) __builtin_memcpy(h + off, src, b);
+        T* r = reinterpret_cast<T*>(d + off);
+        off += need(b);
+        return r;
+    }
+    template <class T> T* host_of(const T* dev) const { return reinterpret_cast<T*>(h + (reinterpret_cast<const char*>(dev) - d)); }
+    int flush(hipStream_t s) {
+        if (off == 0) return VISO_OK;
+        HIP_TRY(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, s));
+        return VISO_OK;
+    }
+};
 
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
@@ -141,11 +187,16 @@ int launch_pack_i16(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap
 // bad: int[2] zeroed before the run ([0] any image flagged by the pack kernel, [1] scratch counter of the stereo kernels)
 int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                  const MatchParamsDev mp[2], int* bad, int variant, const int2* ovf_q, const int* ovf_cnt, int r8s);
+// kinds: which problems the launch can contain (the plain family knows: one call = one problem) -- kernels that would
+// find nothing to do are not launched.  VISO_KIND_TEMPORAL: problems without the epipolar gate, VISO_KIND_STEREO: with it.
+#define VISO_KIND_TEMPORAL 1
+#define VISO_KIND_STEREO 2
+#define VISO_KIND_ALL 3
 // general_possible = 0: the rows cannot be flagged (descriptors extracted on the device from uint8 images), the
 // kernels of the general (double) path are not even launched
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
                        const MatchParamsDev mp[2], int* bad, hipEvent_t e0, hipEvent_t e1, int layout, int variant,
-                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible = 1);
+                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible = 1, int kinds = VISO_KIND_ALL);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 6
 int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
@@ -210,7 +261,8 @@ struct BatchMatchArgs {          // kernarg of match_batch_kernel / match_union_
     MatchParamsDev mp[2];
 };
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s);
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s,
+                       int kinds = VISO_KIND_ALL);
 int launch_match_union_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);

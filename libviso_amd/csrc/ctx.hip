@@ -68,7 +68,9 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
     note(hipSetDevice(c->device));
     note(hipStreamSynchronize(c->stream));
     if (c->solver_stream) { note(hipStreamSynchronize(c->solver_stream)); note(hipStreamDestroy(c->solver_stream)); }
-    for (int i = 0; i < 16; ++i) if (c->scratch[i]) note(hipFree(c->scratch[i]));
+    plain_cache_free(c);
+    for (int i = 0; i < 24; ++i) if (c->scratch[i]) note(hipFree(c->scratch[i]));
+    for (int i = 0; i < 2; ++i) if (c->pin[i]) note(hipHostFree(c->pin[i]));
     if (c->own_stream) note(hipStreamDestroy(c->stream));
     delete c;
     if (first != hipSuccess) { viso_set_error("viso_ctx_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -162,6 +164,22 @@ int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out) {
     return VISO_OK;
 }
 
+int ctx_pinned(viso_ctx* c, int which, size_t bytes, char** out) {
+    if (bytes < 4096) bytes = 4096;
+    if (c->pin_bytes[which] < bytes) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // nothing in flight reads the old block
+        if (c->pin[which]) HIP_TRY(hipHostFree(c->pin[which]));
+        c->pin[which] = nullptr;
+        c->pin_bytes[which] = 0;
+        const size_t want = bytes + bytes / 2;
+        HIP_TRY(hipHostMalloc((void**)&c->pin[which], want, hipHostMallocDefault));
+        c->pin_bytes[which] = want;
+    }
+    *out = c->pin[which];
+    return VISO_OK;
+}
+
 // The plain family serialises on one lazily created context (the reference is
 // single threaded; callers that want concurrency use explicit contexts).
 static std::mutex g_mu;
@@ -181,100 +199,59 @@ viso_ctx* viso_default_ctx() {
     return g_default;
 }
 
-// match_desc, reference src/viso.cpp:669-726.
-extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n2,
-                               const float* d1, const float* d2, int dlen,
-                               const viso_match_params* mp, int32_t* out_match, int* out_n) {
-    if (n1 < 0 || n2 < 0 || dlen <= 0 || !mp || !out_n || mp->max_neighbors <= 0 ||
-        (n1 && (!kp1 || !d1 || !out_match)) || (n2 && (!kp2 || !d2))) {
-        viso_set_error("viso_match_desc: bad argument (the reference asserts d1.cols==d2.cols, src/viso.cpp:676)");
-        return VISO_ERR_ARG;
+// ---- viso_plain_profile: where a plain-family call's time goes ---------------------------------------------------
+#include <chrono>
+static bool g_prof_on = false;
+static viso_plain_times g_prof[VISO_PLAIN_N];
+static hipEvent_t g_prof_ev[4];
+static bool g_prof_ev_ok = false;
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+PlainProf::PlainProf(int fn_, hipStream_t s_) : fn(fn_), s(s_), on(g_prof_on), marks(0), t0(0), tw(0), wait(0) {
+    if (!on) return;
+    if (!g_prof_ev_ok) {
+        for (int i = 0; i < 4; ++i) if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) { on = false; return; }
+        g_prof_ev_ok = true;
     }
-    *out_n = 0;
-    if (n1 == 0) return VISO_OK;
+    t0 = now_us();
+    if (hipEventRecord(g_prof_ev[0], s) == hipSuccess) marks = 1;
+}
+void PlainProf::mark(int k) { if (on && hipEventRecord(g_prof_ev[k], s) == hipSuccess) marks |= 1 << k; }
+void PlainProf::wait_begin() { if (on) tw = now_us(); }
+void PlainProf::wait_end() { if (on) wait += now_us() - tw; }
+PlainProf::~PlainProf() {
+    if (!on) return;
+    viso_plain_times& p = g_prof[fn];
+    p.calls += 1;
+    p.host_us += now_us() - t0;
+    p.wait_us += wait;
+    if (marks == 15 && hipEventSynchronize(g_prof_ev[3]) == hipSuccess) {
+        float a = 0, b = 0, c = 0;
+        if (hipEventElapsedTime(&a, g_prof_ev[0], g_prof_ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&b, g_prof_ev[1], g_prof_ev[2]) == hipSuccess &&
+            hipEventElapsedTime(&c, g_prof_ev[2], g_prof_ev[3]) == hipSuccess) {
+            p.h2d_us += a * 1e3; p.kernel_us += b * 1e3; p.d2h_us += c * 1e3;
+        }
+    }
+}
+
+extern "C" int viso_plain_profile(int enable) {
     PlainLock lk;
-    viso_ctx* c = viso_default_ctx();
-    if (!c) return VISO_ERR_HIP;
-    hipStream_t s = c->stream;
-    float2 *dk1, *dk2; float *df1, *df2; uint16_t *du1, *du2; int2* dres; int *dsorted, *dpos, *dmisc;
-    unsigned char* daux;
-    MatchProblem* dprob;
-    int r;
-    const size_t n2a = (size_t)(n2 > 0 ? n2 : 1);
-    if (n1 > VISO_SORT_MAX || n2 > VISO_SORT_MAX) {
-        viso_set_error("viso_match_desc: more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
-        return VISO_ERR_UNSUPPORTED;
-    }
-    if ((r = ctx_scratch(c, 0, sizeof(float2) * n1, (void**)&dk1)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(float2) * n2a, (void**)&dk2)) < 0) return r;
-    if ((r = ctx_scratch(c, 2, sizeof(float) * (size_t)n1 * dlen, (void**)&df1)) < 0) return r;
-    if ((r = ctx_scratch(c, 3, sizeof(float) * n2a * dlen, (void**)&df2)) < 0) return r;
-    if ((r = ctx_scratch(c, 4, sizeof(uint16_t) * (size_t)n1 * VISO_ROW, (void**)&du1)) < 0) return r;
-    if ((r = ctx_scratch(c, 5, sizeof(uint16_t) * n2a * VISO_ROW, (void**)&du2)) < 0) return r;
-    if ((r = ctx_scratch(c, 6, sizeof(int2) * n1, (void**)&dres)) < 0) return r;
-    if ((r = ctx_scratch(c, 7, sizeof(int) * 3 * (size_t)n1, (void**)&dsorted)) < 0) return r;
-    if ((r = ctx_scratch(c, 8, sizeof(int) * n1, (void**)&dpos)) < 0) return r;
-    if ((r = ctx_scratch(c, 9, sizeof(int) * 16, (void**)&dmisc)) < 0) return r;
-    if ((r = ctx_scratch(c, 10, sizeof(MatchProblem) + 2 * sizeof(ImageView), (void**)&dprob)) < 0) return r;
-    // per image: skp (8n) + sidx (4n) + rank (4n) + bstart (4(NB+1)) + xinfo (32) + qord (n rounded up to 64) + sums (8n) + rows8 (128n), 16-B aligned pieces
-    auto aux_bytes = [](size_t n) { return ((16 * n + 15) / 16) * 16 + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16 + ((n + 63) / 64) * 64 + ((8 * n + 15) / 16) * 16 + VISO_ROW8 * n; };
-    if ((r = ctx_scratch(c, 11, aux_bytes((size_t)n1) + aux_bytes(n2a), (void**)&daux)) < 0) return r;
-    int* dtile;
-    if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(dk1, kp1, sizeof(float2) * n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(df1, d1, sizeof(float) * (size_t)n1 * dlen, hipMemcpyHostToDevice, s));
-    if (n2) {
-        HIP_TRY(hipMemcpyAsync(dk2, kp2, sizeof(float2) * n2, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(df2, d2, sizeof(float) * (size_t)n2 * dlen, hipMemcpyHostToDevice, s));
-    }
-    // dmisc: [0]=n1 [1]=n2 [2]=bad (both images share one flag) [3]=m_cnt [4..5]=scored (u64) [6]=ovf_cnt [7]=bad_any
-    int hm[10] = {n1, n2, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = tiles match_stereo_kernel declines (follows bad_any)
-    // the planes' shift (matcher variant 6): one call, no previous run to learn it from: the default, or the forced one
-    const int r8s = c->row8_force >= 0 ? c->row8_force : VISO_R8_DEFAULT;
-    HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, s));
-    auto view = [&](unsigned char* base, size_t n, const float2* kp, const float* f, const int* np, uint16_t* rows) {
-        ImageView v{};
-        v.kp = kp; v.frows = f; v.n = np; v.rows = rows; v.bad = dmisc + 2;
-        v.skp = (float2*)base;
-        v.sidx = (int*)(base + 8 * n);
-        v.rank = (int*)(base + 12 * n);
-        unsigned char* tail = base + ((16 * n + 15) / 16) * 16;
-        v.bstart = (int*)tail;
-        v.xinfo = (float*)(tail + 4 * (VISO_NB + 1));
-        v.qord = (uint8_t*)(tail + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16);
-        v.sums = (uint2*)((unsigned char*)v.qord + ((n + 63) / 64) * 64);
-        v.rows8 = (uint8_t*)v.sums + ((8 * n + 15) / 16) * 16;
-        return v;
-    };
-    MatchProblem P{};
-    P.q = view(daux, (size_t)n1, dk1, df1, dmisc + 0, du1);
-    P.t = view(daux + aux_bytes((size_t)n1), n2a, dk2, df2, dmisc + 1, du2);
-    P.res = dres; P.sorted = dsorted; P.pos = dpos;
-    P.m_cnt = dmisc + 3; P.scored = (unsigned long long*)(dmisc + 4); P.pidx = 0; P.cap = n1;
-    P.tile_flag = dtile;
-    int2* dovf;
-    if ((r = ctx_scratch(c, 13, sizeof(int2) * (size_t)n1, (void**)&dovf)) < 0) return r;
-    P.ovf = dovf; P.ovf_cnt = dmisc + 6;
-    struct { MatchProblem p; ImageView v[2]; } up;
-    up.p = P; up.v[0] = P.q; up.v[1] = P.t;
-    HIP_TRY(hipMemcpyAsync(dprob, &up, sizeof(up), hipMemcpyHostToDevice, s));
-    const ImageView* dviews = reinterpret_cast<const ImageView*>(dprob + 1);
-    const int capmax = n1 > n2 ? n1 : (int)n2a;
-    if ((r = launch_sort_kp(s, dviews, 2, capmax)) < 0) return r;
-    if (dlen > VISO_ROW) {   // rows do not fit: the one shared flag
-        const int one[1] = {1};
-        HIP_TRY(hipMemcpyAsync(dmisc + 2, one, sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(dmisc + 7, one, sizeof(int), hipMemcpyHostToDevice, s));
-    } else if ((r = launch_pack(s, dviews, 2, capmax, dlen, dmisc + 2, dmisc + 7, pack_extras(c->matcher_variant, dlen), r8s, nullptr)) < 0) return r;
-    MatchParamsDev mpd[2];
-    fill_match_params(&mpd[0], mp);
-    mpd[1] = mpd[0];
-    if ((r = launch_match(s, dprob, 1, n1, dlen, mpd, dmisc + 7, c->matcher_variant, dovf, dmisc + 6, r8s)) < 0) return r;
-    if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
-    int m = 0;
-    HIP_TRY(hipMemcpyAsync(&m, dmisc + 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (m > 0) HIP_TRY(hipMemcpy(out_match, dsorted, sizeof(int) * 3 * (size_t)m, hipMemcpyDeviceToHost));
-    *out_n = m;
+    if (enable) memset(g_prof, 0, sizeof(g_prof));
+    g_prof_on = enable != 0;
     return VISO_OK;
 }
+extern "C" int viso_plain_profile_get(int fn, viso_plain_times* out) {
+    if (fn < 0 || fn >= VISO_PLAIN_N || !out) { viso_set_error("viso_plain_profile_get: bad argument"); return VISO_ERR_ARG; }
+    PlainLock lk;
+    *out = g_prof[fn];
+    return VISO_OK;
+}
+extern "C" const char* viso_plain_profile_name(int fn) {
+    static const char* names[VISO_PLAIN_N] = {"match_desc", "collect_matches", "triangulate_rectified", "match_circle",
+                                              "ransac_minimize_reproj", "minimize_reproj", "get_inliers"};
+    return fn >= 0 && fn < VISO_PLAIN_N ? names[fn] : "";
+}
+

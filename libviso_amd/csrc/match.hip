@@ -934,7 +934,7 @@ const char* matcher_kernel_name(int variant) {
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
                        int dlen, const MatchParamsDev mp[2], int* bad,
                        hipEvent_t e0, hipEvent_t e1, int layout, int variant,
-                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible) {
+                       const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible, int kinds) {
     if (n_probs <= 0 || cap_max <= 0) return VISO_OK;
     variant = matcher_effective(variant, dlen);
     MatchArgs a;
@@ -953,15 +953,17 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
     a.vblocks = (int)blocks;
     if (e0) HIP_TRY(hipEventRecord(e0, s));
     {
-        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, variant, r8s);
+        const int r = launch_match_batch(s, probs_dev, n_probs, cap_max, mp, bad, layout, e1, variant, r8s, kinds);
         if (r < 0) return r;
     }
     // general (non-u16) path: normally idle (no image is flagged and every block leaves at once), so
     // it gets a small grid that strides over the (problem, tile) slots when it does have work
     const unsigned gblocks = (unsigned)(blocks < 512 ? blocks : 512);
-    if (general_possible) {
+    if (general_possible && (kinds & VISO_KIND_TEMPORAL)) {
         hipLaunchKernelGGL((match_kernel<true, 0>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());
+    }
+    if (general_possible && (kinds & VISO_KIND_STEREO)) {
         hipLaunchKernelGGL((match_kernel<true, 1>), dim3(gblocks), dim3(VISO_MATCH_THREADS), 0, s, a);
         HIP_TRY(hipGetLastError());
     }

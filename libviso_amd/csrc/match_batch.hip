@@ -458,7 +458,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(MB_THREA
 }
 
 int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max,
-                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s) {
+                       const MatchParamsDev mp[2], int* bad, int layout, hipEvent_t e_mid, int variant, int r8s, int kinds) {
     BatchMatchArgs a;
     a.probs = probs_dev;
     a.n_probs = n_probs;
@@ -477,6 +477,7 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
     }
     if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
+    if (!(kinds & VISO_KIND_TEMPORAL)) { /* no temporal problem in this launch */ } else
 #ifdef VISO_DEBUG_VARIANTS
     if (variant == 2) {
         at.vblocks = (int)bt;
@@ -501,6 +502,7 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         if (r < 0) return r;
     }
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, s));
+    if (!(kinds & VISO_KIND_STEREO)) return VISO_OK;
     {   // stereo problems: lane-per-query kernel for tiles with a narrow epipolar band, the kernel below for the rest
         const int r = launch_match_stereo(s, as, cap_max);
         if (r < 0) return r;

@@ -10,6 +10,7 @@
 // memory (check with -Rpass-analysis=kernel-resource-usage after any change).
 #include "solver_dev.h"
 
+#include <string.h>
 #include <vector>
 
 struct SolverArgs {
@@ -765,14 +766,15 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
 struct GnArgs {
     const double* X; const double* obs; int m, ld;
     const int* active; int n;
-    double* tr; int* ok; int* inl; int* n_inl; double* rms;
+    const double* tr_in;   // the caller's tr (input block)
+    double* tr; int* ok; int* inl; int* n_inl; double* rms;   // result block
     SolverParamsDev sp;
 };
 
 __global__ __launch_bounds__(REFIT_THREADS) void minimize_reproj_kernel(GnArgs a) {
     __shared__ double tr_s[6];
     __shared__ double red[4 * 27 + 8];
-    if (threadIdx.x < 6) tr_s[threadIdx.x] = a.tr[threadIdx.x];
+    if (threadIdx.x < 6) tr_s[threadIdx.x] = a.tr_in[threadIdx.x];
     __syncthreads();
     const int ok = gn_block(a.X, a.obs, a.ld, a.active, a.n, tr_s, a.sp, red);
     __syncthreads();
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void get_inliers_kernel(GnArgs a) {
     __shared__ double last;
     double tr[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) tr[j] = a.tr[j];
+    for (int j = 0; j < 6; ++j) tr[j] = a.tr_in[j];
     if (threadIdx.x == 0) last = 0;
     __syncthreads();
     const int n = block_inliers(tr, a.sp, a.X, a.obs, a.ld, a.m, a.inl, scratch, &last);
@@ -815,26 +817,33 @@ extern "C" int viso_minimize_reproj(const double* X, const double* obs, int m, d
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    double *dX, *dobs, *dtr; int *dact, *dok;
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_MINIMIZE, c->stream);
     int r;
-    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
-    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
-    if ((r = ctx_scratch(c, 3, sizeof(int) * n_active, (void**)&dact)) < 0) return r;
-    if ((r = ctx_scratch(c, 4, sizeof(int) * 4, (void**)&dok)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dtr, tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dact, active, sizeof(int) * n_active, hipMemcpyHostToDevice, c->stream));
+    PlainStage in;   // ONE upload: X | obs | active; ONE read-back: tr[6], ok
+    if ((r = in.begin(c, PlainStage::need(sizeof(double) * 3 * (size_t)m) + PlainStage::need(sizeof(double) * 4 * (size_t)m) +
+                         PlainStage::need(sizeof(int) * (size_t)n_active) + PlainStage::need(64))) < 0) return r;
+    char *dout, *hout;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, 128, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, 128, &hout)) < 0) return r;
     GnArgs a{};
-    a.X = dX; a.obs = dobs; a.m = m; a.ld = m; a.active = dact; a.n = n_active; a.tr = dtr; a.ok = dok;
+    a.X = in.put(X, 3 * (size_t)m); a.obs = in.put(obs, 4 * (size_t)m); a.m = m; a.ld = m;
+    a.active = in.put(active, (size_t)n_active); a.n = n_active;
+    a.tr_in = in.put(tr, 6);
+    a.tr = reinterpret_cast<double*>(dout); a.ok = reinterpret_cast<int*>(dout + 64);
     fill_solver_params(&a.sp, p);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
     hipLaunchKernelGGL(minimize_reproj_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
-    int ok = 0;
-    HIP_TRY(hipMemcpyAsync(tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&ok, dok, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    HIP_TRY(hipMemcpyAsync(hout, dout, 128, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    pp.wait_end();
+    memcpy(tr, hout, sizeof(double) * 6);
+    const int ok = *reinterpret_cast<const int*>(hout + 64);
+    pp.mark(3);
     return ok ? 1 : 0;
 }
 
@@ -849,29 +858,35 @@ extern "C" int viso_get_inliers(const double* X, const double* obs, int m, const
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    double *dX, *dobs, *dtr; int *dinl, *dn;
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_GET_INLIERS, c->stream);
     int r;
-    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
-    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
-    if ((r = ctx_scratch(c, 3, sizeof(int) * m, (void**)&dinl)) < 0) return r;
-    if ((r = ctx_scratch(c, 4, sizeof(int) * 4, (void**)&dn)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dtr, tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    PlainStage in;   // ONE upload: X | obs | tr; ONE read-back: {n, rms} | inliers[m]
+    if ((r = in.begin(c, PlainStage::need(sizeof(double) * 3 * (size_t)m) + PlainStage::need(sizeof(double) * 4 * (size_t)m) + PlainStage::need(64))) < 0) return r;
+    char *dout, *hout;
+    const size_t out_bytes = 64 + sizeof(int) * (size_t)m;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, out_bytes, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, out_bytes, &hout)) < 0) return r;
     GnArgs a{};
-    a.X = dX; a.obs = dobs; a.m = m; a.ld = m; a.tr = dtr; a.inl = dinl; a.n_inl = dn; a.rms = dtr + 6;
+    a.X = in.put(X, 3 * (size_t)m); a.obs = in.put(obs, 4 * (size_t)m); a.m = m; a.ld = m;
+    a.tr_in = in.put(tr, 6);
+    a.n_inl = reinterpret_cast<int*>(dout); a.rms = reinterpret_cast<double*>(dout + 8); a.inl = reinterpret_cast<int*>(dout + 64);
     fill_solver_params(&a.sp, p);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
     hipLaunchKernelGGL(get_inliers_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
-    int n = 0;
-    double rmsv = 0;
-    HIP_TRY(hipMemcpyAsync(&n, dn, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&rmsv, dtr + 6, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n > 0) HIP_TRY(hipMemcpy(inliers, dinl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    pp.wait_end();
+    const int n = *reinterpret_cast<const int*>(hout);
+    if (n < 0 || n > m) { viso_set_error("viso_get_inliers: device returned %d inliers of %d points", n, m); return VISO_ERR_HIP; }
+    if (n > 0) memcpy(inliers, hout + 64, sizeof(int) * (size_t)n);
     *n_inliers = n;
-    if (rms) *rms = rmsv;
+    if (rms) memcpy(rms, hout + 8, sizeof(double));
+    pp.mark(3);
     return VISO_OK;
 }
 
@@ -929,41 +944,51 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();
     if (!c) return VISO_ERR_HIP;
-    double *dX, *dobs, *dtr, *dtrh; int *dinl, *dmisc, *dsamp = nullptr; SolverItem* ditem;
+    HIP_TRY(hipSetDevice(c->device));
+    PlainProf pp(VISO_PLAIN_RANSAC, c->stream);
     int r;
-    if ((r = ctx_scratch(c, 0, sizeof(double) * 3 * m, (void**)&dX)) < 0) return r;
-    if ((r = ctx_scratch(c, 1, sizeof(double) * 4 * m, (void**)&dobs)) < 0) return r;
-    if ((r = ctx_scratch(c, 2, sizeof(double) * 8, (void**)&dtr)) < 0) return r;
-    if ((r = ctx_scratch(c, 3, sizeof(int) * m, (void**)&dinl)) < 0) return r;
-    if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dmisc)) < 0) return r;
+    // ONE upload: X | obs | samples | {m} | the item; ONE read-back: {-, ok, n_inl} | tr[6] | inliers[m]
+    PlainStage in;
+    if ((r = in.begin(c, PlainStage::need(sizeof(double) * 3 * (size_t)m) + PlainStage::need(sizeof(double) * 4 * (size_t)m) +
+                         PlainStage::need(sizeof(int) * 3 * (size_t)(iters + 1)) + PlainStage::need(16) + PlainStage::need(sizeof(SolverItem)))) < 0) return r;
+    char *dout, *hout;
+    const size_t out_bytes = 128 + sizeof(int) * (size_t)m;
+    if ((r = ctx_scratch(c, PLAIN_SLOT_OUT, out_bytes, (void**)&dout)) < 0) return r;
+    if ((r = ctx_pinned(c, 1, out_bytes, &hout)) < 0) return r;
+    double* dtrh; int *dhyp, *dqueue;
+    if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dhyp)) < 0) return r;
     if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)(iters + 1), (void**)&dtrh)) < 0) return r;
-    if ((r = ctx_scratch(c, 6, sizeof(SolverItem), (void**)&ditem)) < 0) return r;
-    if (samples) {
-        if ((r = ctx_scratch(c, 7, sizeof(int) * 3 * (size_t)(iters + 1), (void**)&dsamp)) < 0) return r;
-        HIP_TRY(hipMemcpyAsync(dsamp, samples, sizeof(int) * 3 * iters, hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(dX, X, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dobs, obs, sizeof(double) * 4 * m, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dtr, best_tr, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
-    int hm[4] = {m, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(dmisc, hm, sizeof(hm), hipMemcpyHostToDevice, c->stream));
-    int* dqueue;   // undecided-hypothesis list, then the triples in use
+    // undecided-hypothesis list, then the triples in use
     if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&dqueue)) < 0) return r;
     SolverItem it{};
-    it.X = dX; it.obs = dobs; it.m_ptr = dmisc; it.ld = m; it.samples = dsamp; it.frame = frame;
+    it.X = in.put(X, 3 * (size_t)m); it.obs = in.put(obs, 4 * (size_t)m); it.ld = m; it.frame = frame;
+    it.samples = samples ? in.put(samples, 3 * (size_t)iters) : nullptr;
+    const int hm[4] = {m, 0, 0, 0};
+    it.m_ptr = in.put(hm, 4);
     it.samp_h = dqueue + 2 + iters;
-    it.tr_h = dtrh; it.ok_h = dmisc + 4; it.cnt_h = dmisc + 4 + iters;
+    it.tr_h = dtrh; it.ok_h = dhyp; it.cnt_h = dhyp + iters;
     if ((r = ctx_scratch(c, 9, viso_rot_bytes(iters), (void**)&it.rot)) < 0) return r;
-    it.tr = dtr; it.ok = dmisc + 1; it.n_inl = dmisc + 2; it.inl = dinl;
-    HIP_TRY(hipMemcpyAsync(ditem, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    // the refit writes tr, ok and n_inl whatever happens (refit_item): nothing of the result block needs a value in advance.
+    // (best_tr is an input of the reference's function only as the value that stays when no hypothesis finds support,
+    // and sequence_odometry passes zeros, src/viso.cpp:1312: the stage leaves zeros in that case.)
+    it.ok = reinterpret_cast<int*>(dout) + 1; it.n_inl = reinterpret_cast<int*>(dout) + 2;
+    it.tr = reinterpret_cast<double*>(dout + 64); it.inl = reinterpret_cast<int*>(dout + 128);
+    const SolverItem* ditem = in.put(&it, 1);
+    if ((r = in.flush(c->stream)) < 0) return r;
+    pp.mark(1);
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
     if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split, m)) < 0) return r;
-    int res[4];
-    HIP_TRY(hipMemcpyAsync(res, dmisc, sizeof(res), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(best_tr, dtr, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    pp.mark(2);
+    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    pp.wait_end();
+    const int* res = reinterpret_cast<const int*>(hout);
+    if (res[2] < 0 || res[2] > m) { viso_set_error("viso_ransac_minimize_reproj: device returned %d inliers of %d points", res[2], m); return VISO_ERR_HIP; }
+    memcpy(best_tr, hout + 64, sizeof(double) * 6);
     *n_inl = res[2];
-    if (res[2] > 0) HIP_TRY(hipMemcpy(best_inl, dinl, sizeof(int) * res[2], hipMemcpyDeviceToHost));
+    if (res[2] > 0) memcpy(best_inl, hout + 128, sizeof(int) * (size_t)res[2]);
+    pp.mark(3);
     return res[1] ? 1 : 0;
 }

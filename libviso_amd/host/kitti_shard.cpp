@@ -140,6 +140,7 @@ static thread_local viso::OdometryStats g_last_stats;
 static thread_local int g_decode_threads = 0;
 
 extern "C" const char* viso_host_last_error(void) { return g_host_err.c_str(); }
+namespace viso { void set_host_error(const std::string& s) { g_host_err = s; } }   // for the other C entry points (drop_in.cpp)
 
 extern "C" int viso_kitti_count_frames(const char* seq_base, int begin, int end) {
     if (!seq_base || begin < 0 || end < begin) { g_host_err = "viso_kitti_count_frames: bad argument"; return VISO_ERR_ARG; }

@@ -153,6 +153,29 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
                                  int chunk = 64, uint64_t ransac_seed = 0, uint64_t first_frame_index = 0,
                                  int device = 0);
 
+// The LITERAL drop-in flow: the loop body of the reference's sequence_odometry (src/viso.cpp:1205-1327) over the plain
+// family — one C-ABI call per reference function, in the reference's order (match_desc :1240, collect_matches :1246,
+// triangulate_rectified :1247, match_desc :1264 and :1275, match_circle :1282, the gather of :1292-1305 on the host,
+// ransac_minimize_reproj :1313), one frame at a time, with the copyTo carry-over of :1208-1222.  This is what an
+// unchanged kitti.cpp gets from adapters/libviso_hip.patch; sequence_odometry above is the batched form of the same loop.
+// `per_call` (may be null) receives, per VISO_PLAIN_* function, the number of calls and the wall time spent inside this
+// mirror's wrapper of it (container reshaping included, as in the adapter).  `trace` (may be null) keeps every frame's
+// match lists and circle size for comparisons with the batch family.
+struct PerCallStats {
+    long calls[VISO_PLAIN_N] = {0, 0, 0, 0, 0, 0, 0};
+    double us[VISO_PLAIN_N] = {0, 0, 0, 0, 0, 0, 0};
+    double wall_s = 0;            // the whole loop, generator excluded
+    double carry_s = 0;           // the copyTo carry-over of :1208-1222 (the reference's own host cost)
+    int frames = 0;
+};
+struct PerCallTrace {
+    std::vector<Matches> match_lr, match11, match22;   // per frame (match11 / match22 empty for the first)
+    std::vector<int> n_circle;
+};
+OdometryResult sequence_odometry_per_call(const Matd& F, param prm, StereoFeatureGenerator frames,
+                                          uint64_t first_frame_index = 0, PerCallStats* per_call = nullptr,
+                                          PerCallTrace* trace = nullptr);
+
 }  // namespace viso
 
 // ---------------------------------------------------------------------------

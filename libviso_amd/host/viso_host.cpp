@@ -432,6 +432,90 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoFeatureGe
     return out;
 }
 
+// ---- the literal per-call loop (see viso.hpp) -------------------------------
+OdometryResult sequence_odometry_per_call(const Matd& F, param prm, StereoFeatureGenerator frames,
+                                          uint64_t first_frame_index, PerCallStats* per_call, PerCallTrace* trace) {
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t0) { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    PerCallStats local;
+    PerCallStats& st = per_call ? *per_call : local;
+    auto timed = [&](int fn, auto&& call) {
+        const auto t0 = clk::now();
+        call();
+        st.us[fn] += us_since(t0);
+        st.calls[fn] += 1;
+    };
+    OdometryResult out;
+    out.poses.push_back(Matd::eye(4));                                // :1189-1190
+    out.frame_of_pose.push_back(0);
+    double pose[16];
+    std::memcpy(pose, out.poses[0].ptr(), sizeof(pose));
+    const MatchParams stereo(F), temporal;
+    Matd X, X_prev;
+    Descriptors d1, d2, d1_prev, d2_prev;
+    KeyPoints kp1, kp2, kp1_prev, kp2_prev;
+    Matches match_lr, match_lr_prev;
+    bool first = true;
+    double gen_s = 0;
+    const auto t_loop = clk::now();
+    for (int iter_num = 0;; ++iter_num) {
+        const auto tg = clk::now();
+        std::optional<StereoFeatures> f = frames();
+        gen_s += us_since(tg) * 1e-6;
+        if (!f) break;
+        prm.frame_index = first_frame_index + (uint64_t)iter_num;   // adapters/libviso_hip.patch, :1207
+        if (!first) {                                                 // :1208-1222
+            const auto tc = clk::now();
+            d1_prev = d1; d2_prev = d2;                               // copyTo: a copy, not a header
+            kp1_prev = kp1; kp2_prev = kp2;
+            match_lr_prev = match_lr;
+            X_prev = X;
+            kp1.clear(); kp2.clear(); match_lr.clear();
+            st.carry_s += us_since(tc) * 1e-6;
+        }
+        kp1 = std::move(f->kp1); kp2 = std::move(f->kp2);             // detector.detect / extractor.compute, :1226-1231
+        d1 = std::move(f->d1); d2 = std::move(f->d2);
+        timed(VISO_PLAIN_MATCH_DESC, [&] { match_desc(kp1, kp2, d1, d2, match_lr, stereo); });                 // :1240
+        Matd x;
+        timed(VISO_PLAIN_COLLECT_MATCHES, [&] { collect_matches(kp1, kp2, match_lr, x); });                    // :1246
+        timed(VISO_PLAIN_TRIANGULATE, [&] { X = triangulate_rectified(x, prm); });                             // :1247
+        st.frames += 1;
+        out.ok.push_back(0); out.n_inliers.push_back(0); out.tr.push_back(std::array<double, 6>{});
+        if (trace) { trace->match_lr.push_back(match_lr); trace->match11.emplace_back(); trace->match22.emplace_back(); trace->n_circle.push_back(0); }
+        if (first) { first = false; continue; }                      // :1256-1260
+        Matches match11, match22;
+        timed(VISO_PLAIN_MATCH_DESC, [&] { match_desc(kp1, kp1_prev, d1, d1_prev, match11, temporal); });       // :1264
+        timed(VISO_PLAIN_MATCH_DESC, [&] { match_desc(kp2, kp2_prev, d2, d2_prev, match22, temporal); });       // :1275
+        Matches match_pcl;
+        std::vector<Vec4i> circ_match;
+        timed(VISO_PLAIN_MATCH_CIRCLE, [&] { match_circle(match_lr, match_lr_prev, match11, match22, circ_match, match_pcl); });   // :1282
+        if (trace) { trace->match11.back() = match11; trace->match22.back() = match22; trace->n_circle.back() = (int)circ_match.size(); }
+        if (circ_match.size() < 3) continue;                         // :1283-1288
+        const int mc = (int)circ_match.size();
+        Matd Xp_c(3, mc), x_c(4, mc);                                 // :1292-1305
+        for (int i = 0; i < mc; ++i) {
+            for (int r = 0; r < 4; ++r) x_c.at(r, i) = x.at(r, match_pcl[(size_t)i][0]);
+            for (int r = 0; r < 3; ++r) Xp_c.at(r, i) = X_prev.at(r, match_pcl[(size_t)i][1]);
+        }
+        std::vector<int> inliers;
+        std::vector<double> tr(6, 0.0);
+        bool ok = false;
+        timed(VISO_PLAIN_RANSAC, [&] { ok = ransac_minimize_reproj(Xp_c, x_c, tr, inliers, prm); });            // :1313
+        out.ok.back() = ok ? 1 : 0;
+        out.n_inliers.back() = (int)inliers.size();
+        for (int j = 0; j < 6; ++j) out.tr.back()[(size_t)j] = tr[(size_t)j];
+        if (ok) {                                                     // :1315-1321
+            viso_pose_update(pose, tr.data(), pose);
+            Matd P(4, 4);
+            std::memcpy(P.ptr(), pose, sizeof(pose));
+            out.poses.push_back(P);
+            out.frame_of_pose.push_back(iter_num);
+        }
+    }
+    st.wall_s = us_since(t_loop) * 1e-6 - gen_s;
+    return out;
+}
+
 }  // namespace viso
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,109 @@
+// h2d_probe — what a synchronous host->device->host round trip costs on this box: the floor of one plain-family call
+// (tools/README.md).  pageable hipMemcpyAsync vs staging through pinned memory with 1..T copy threads, an empty kernel
+// + 4-byte read-back, and the single-thread memcpy rate.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+__global__ void empty_kernel(int* p) { if (threadIdx.x == 0) p[0] += 1; }
+
+struct Pool {   // spinning helpers: thread i copies slice i when `gen` advances
+    std::vector<std::thread> th; std::atomic<int> gen{0}, done{0}; std::atomic<bool> stop{false};
+    const char* src = nullptr; char* dst = nullptr; size_t bytes = 0; int n = 0;
+    explicit Pool(int n_) : n(n_) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this, i] {
+            int seen = 0;
+            while (!stop.load(std::memory_order_relaxed)) {
+                if (gen.load(std::memory_order_acquire) == seen) { __builtin_ia32_pause(); continue; }
+                ++seen;
+                const size_t lo = bytes * i / (n + 1), hi = bytes * (i + 1) / (n + 1);
+                memcpy(dst + lo, src + lo, hi - lo);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    }
+    void copy(char* d, const char* s, size_t b) {   // caller takes the last slice
+        src = s; dst = d; bytes = b; done.store(0); gen.fetch_add(1, std::memory_order_release);
+        const size_t lo = b * n / (n + 1);
+        memcpy(d + lo, s + lo, b - lo);
+        while (done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+    }
+    ~Pool() { stop = true; gen.fetch_add(1); for (auto& t : th) t.join(); }
+};
+
+int main() {
+    const size_t B = 2000 * 121 * 4;   // one image's descriptors
+    char *pin, *dev; int* dflag; int* hflag;
+    CK(hipHostMalloc((void**)&pin, 4 * B)); CK(hipMalloc((void**)&dev, 4 * B)); CK(hipMalloc((void**)&dflag, 64)); CK(hipHostMalloc((void**)&hflag, 64));
+    CK(hipMemset(dflag, 0, 64));
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    std::vector<std::vector<char>> src(16, std::vector<char>(2 * B, 1));   // rotate: not always cache hot
+    const int R = 200;
+    // (0) empty kernel + 4-byte pinned read-back + synchronize
+    for (int w = 0; w < 2; ++w) {
+        double t0 = now();
+        for (int i = 0; i < R; ++i) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipMemcpyAsync(hflag, dflag, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
+        if (w) printf("empty kernel + 4 B D2H (pinned) + sync: %.1f us\n", (now() - t0) / R);
+    }
+    for (int w = 0; w < 2; ++w) {
+        double t0 = now();
+        for (int i = 0; i < R; ++i) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipStreamSynchronize(s)); }
+        if (w) printf("empty kernel + sync: %.1f us\n", (now() - t0) / R);
+    }
+    { int x; double t0 = now();
+      for (int i = 0; i < R; ++i) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipMemcpyAsync(&x, dflag, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
+      printf("empty kernel + 4 B D2H (pageable) + sync: %.1f us\n", (now() - t0) / R); }
+    { double t0 = now();
+      for (int i = 0; i < R; ++i) { for (int k = 0; k < 6; ++k) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipStreamSynchronize(s)); }
+      printf("6 empty kernels + sync: %.1f us\n", (now() - t0) / R); }
+    // (1) pageable hipMemcpyAsync H2D, then sync
+    for (size_t bytes : {B, 2 * B}) {
+        double t0 = now();
+        for (int i = 0; i < R; ++i) { CK(hipMemcpyAsync(dev, src[i % 16].data(), bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+        double dt = (now() - t0) / R;
+        printf("pageable H2D %zu B + sync: %.1f us = %.1f GB/s\n", bytes, dt, bytes / dt * 1e-3);
+    }
+    // (2) single-thread memcpy to pinned + pinned H2D
+    for (size_t bytes : {B, 2 * B}) {
+        double t0 = now(), tc = 0;
+        for (int i = 0; i < R; ++i) { double a = now(); memcpy(pin, src[i % 16].data(), bytes); tc += now() - a; CK(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+        double dt = (now() - t0) / R;
+        printf("memcpy->pinned (%.1f us = %.1f GB/s) + pinned H2D %zu B + sync: %.1f us\n", tc / R, bytes / (tc / R) * 1e-3, bytes, dt);
+    }
+    // (3) chunked: memcpy chunk k while chunk k-1 is on the wire
+    for (int chunks : {2, 4, 8}) {
+        const size_t bytes = 2 * B, cb = bytes / chunks;
+        double t0 = now();
+        for (int i = 0; i < R; ++i) {
+            for (int k = 0; k < chunks; ++k) { memcpy(pin + k * cb, src[i % 16].data() + k * cb, cb); CK(hipMemcpyAsync(dev + k * cb, pin + k * cb, cb, hipMemcpyHostToDevice, s)); }
+            CK(hipStreamSynchronize(s));
+        }
+        double dt = (now() - t0) / R;
+        printf("chunked x%d memcpy->pinned + H2D %zu B + sync: %.1f us = %.1f GB/s\n", chunks, bytes, dt, bytes / dt * 1e-3);
+    }
+    // (4) T helper threads copy slices, then one H2D
+    for (int T : {1, 2, 3, 5, 7}) {
+        Pool pool(T);
+        const size_t bytes = 2 * B;
+        double t0 = now(), tc = 0;
+        for (int i = 0; i < R; ++i) { double a = now(); pool.copy(pin, src[i % 16].data(), bytes); tc += now() - a; CK(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+        double dt = (now() - t0) / R;
+        printf("%d+1 threads memcpy->pinned (%.1f us = %.1f GB/s) + H2D %zu B + sync: %.1f us = %.1f GB/s\n", T, tc / R, bytes / (tc / R) * 1e-3, bytes, dt, bytes / dt * 1e-3);
+    }
+    // (5) D2H of 24 KB: pinned vs pageable
+    { std::vector<char> out(24000); double t0 = now();
+      for (int i = 0; i < R; ++i) { CK(hipMemcpyAsync(pin, dev, 24000, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); memcpy(out.data(), pin, 24000); }
+      printf("D2H 24 KB pinned + sync + memcpy: %.1f us\n", (now() - t0) / R);
+      t0 = now();
+      for (int i = 0; i < R; ++i) { CK(hipMemcpyAsync(out.data(), dev, 24000, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
+      printf("D2H 24 KB pageable + sync: %.1f us\n", (now() - t0) / R);
+      t0 = now();
+      for (int i = 0; i < R; ++i) { CK(hipMemcpy(out.data(), dev, 24000, hipMemcpyDeviceToHost)); }
+      printf("D2H 24 KB blocking hipMemcpy pageable: %.1f us\n", (now() - t0) / R); }
+    return 0;
+}
