@@ -336,15 +336,12 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     hipLaunchKernelGGL(circle_table_kernel, dim3(1), dim3(CIRCT_THREADS), 0, c->stream, a, dtab, tabn);
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    // with unique keys a row of match_lr joins at most once: n_lr rows bound the result; duplicate keys can give more
-    const int w1 = cap < n_lr ? cap : n_lr;
-    HIP_TRY(hipMemcpyAsync(hout, dout, 256 + sizeof(int) * 6 * (size_t)w1, hipMemcpyDeviceToHost, c->stream));
+    // the rows that exist (the count is on the device), by a copy kernel into pinned memory
+    if ((r = plain_blit(c->stream, dout, hout, 64, a.out_n, 6, cap)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int cnt = *reinterpret_cast<const int*>(hout);
     const int w = cnt < cap ? cnt : cap;
-    if (w > w1) HIP_TRY(hipMemcpy(hout + 256 + sizeof(int) * 6 * (size_t)w1, dout + 256 + sizeof(int) * 6 * (size_t)w1,
-                                  sizeof(int) * 6 * (size_t)(w - w1), hipMemcpyDeviceToHost));
     pp.wait_end();
     *out_n = cnt;
     const int* rows = reinterpret_cast<const int*>(hout + 256);
@@ -395,7 +392,7 @@ extern "C" int viso_collect_matches(const float* kp1, int n1, const float* kp2, 
     SolverParamsDev sp{};
     if ((r = launch_collect_triangulate(c->stream, dit, 1, sp, n)) < 0) return r;
     pp.mark(2);
-    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     pp.wait_end();
@@ -427,7 +424,7 @@ extern "C" int viso_triangulate_rectified(const double* x, int m, const viso_par
     hipLaunchKernelGGL(triangulate_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dx, m, sp, reinterpret_cast<double*>(dout));
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     pp.wait_end();

@@ -160,12 +160,14 @@ struct PlainStage {
         return r;
     }
     template <class T> T* host_of(const T* dev) const { return reinterpret_cast<T*>(h + (reinterpret_cast<const char*>(dev) - d)); }
-    int flush(hipStream_t s) {
-        if (off == 0) return VISO_OK;
-        HIP_TRY(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, s));
-        return VISO_OK;
-    }
+    // Small blocks go through a copy KERNEL that reads the pinned block over PCIe itself: the copy engine costs ~10 us
+    // of latency per transfer whatever its size, a launch 2-3 (tools/h2d_probe.hip: H2D + kernel + D2H + synchronize
+    // 29 us by copy engine, 18 us by copy kernels).
+    int flush(hipStream_t s);
 };
+// words = 32-bit units.  dst[0..head) = src[0..head), then min(*n_rows, max_rows) rows of row_words behind them (n_rows
+// may be null: head only).  Either side may be pinned host memory.
+int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows = nullptr, int row_words = 0, int max_rows = 0);
 
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)

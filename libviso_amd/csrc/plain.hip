@@ -15,8 +15,114 @@
 // to fit the u16 rows) are not launched.
 #include "common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// ---- helper threads for the two large host-side passes of a call ---------------------------------------------------
+// A miss copies the caller's 968 KB of descriptors into the slot's pinned shadow, a hit compares them with it.  One core
+// does that at 10-12 GB/s when the caller's array comes from DRAM (85 us: more than the upload and the kernels
+// together) and at 40-75 GB/s from its cache.  $VISO_PLAIN_THREADS helpers (default 3, 0 = none) take a slice each;
+// they spin for a few tens of microseconds after a job -- the next call of the frame is that close -- and sleep on a
+// condition variable otherwise.  Used under the PlainLock only.
+struct PlainPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<unsigned long long> gen{0};
+    std::atomic<int> done{0}, differ{0}, sleepers{0};
+    std::atomic<bool> stop{false};
+    int op = 0;                       // 0 = copy, 1 = compare
+    const char* a = nullptr; char* b = nullptr; size_t bytes = 0;
+    int n = 0;
+
+    static void slice(size_t bytes, int parts, int i, size_t* lo, size_t* hi) {
+        *lo = (bytes * (size_t)i / (size_t)parts) & ~(size_t)63;
+        *hi = i + 1 == parts ? bytes : (bytes * (size_t)(i + 1) / (size_t)parts) & ~(size_t)63;
+    }
+    void work(int i) {
+        size_t lo, hi;
+        slice(bytes, n + 1, i, &lo, &hi);
+        if (hi <= lo) return;
+        if (op == 0) memcpy(b + lo, a + lo, hi - lo);
+        else if (memcmp(b + lo, a + lo, hi - lo) != 0) differ.store(1, std::memory_order_relaxed);
+    }
+    void run(int i) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(60)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1);
+                    cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(); });
+                    sleepers.fetch_sub(1);
+                    break;
+                }
+            }
+            if (stop.load()) return;
+            seen = gen.load(std::memory_order_acquire);
+            work(i);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    explicit PlainPool(int n_) : n(n_) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this, i] { run(i); });
+    }
+    ~PlainPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    // the caller takes the last slice; returns 1 if (op == compare and) the blocks differ
+    int go(int op_, const void* src, void* dst, size_t bytes_) {
+        op = op_; a = (const char*)src; b = (char*)dst; bytes = bytes_;
+        done.store(0, std::memory_order_relaxed); differ.store(0, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(mu); gen.fetch_add(1, std::memory_order_release); }
+        if (sleepers.load() > 0) cv.notify_all();
+        work(n);
+        while (done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        return differ.load(std::memory_order_relaxed);
+    }
+};
+static PlainPool* g_pool = nullptr;
+static bool g_pool_tried = false;
+static struct PlainPoolReaper { ~PlainPoolReaper() { delete g_pool; g_pool = nullptr; } } g_pool_reaper;
+
+static PlainPool* plain_pool() {
+    if (!g_pool_tried) {
+        g_pool_tried = true;
+        int n = 3;
+        if (const char* e = getenv("VISO_PLAIN_THREADS")) n = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw - 1) n = hw - 1;
+        if (n > 15) n = 15;
+        if (n > 0) g_pool = new PlainPool(n);
+    }
+    return g_pool;
+}
+#define PLAIN_POOL_MIN (128 * 1024)   // smaller blocks are not worth a hand-over
+static void big_copy(void* dst, const void* src, size_t bytes) {
+    PlainPool* p = bytes >= PLAIN_POOL_MIN ? plain_pool() : nullptr;
+    if (p) p->go(0, src, dst, bytes); else if (bytes) memcpy(dst, src, bytes);
+}
+static bool big_equal(const void* shadow, const void* user, size_t bytes) {
+    if (bytes == 0) return true;
+    const size_t head = bytes < 4096 ? bytes : 4096;   // other images differ within the first bytes: no hand-over for them
+    if (memcmp(shadow, user, head) != 0) return false;
+    if (bytes == head) return true;
+    PlainPool* p = bytes >= PLAIN_POOL_MIN ? plain_pool() : nullptr;
+    if (p) return p->go(1, (const char*)user + head, (char*)shadow + head, bytes - head) == 0;
+    return memcmp((const char*)shadow + head, (const char*)user + head, bytes - head) == 0;
+}
 
 #define PLAIN_SLOTS 4
 #define PLAIN_HDR 256      // bytes of an image's header block {n, bad}
@@ -37,6 +143,39 @@ struct PlainCache {
     long long hits, misses;
     int enabled;
 };
+
+// ---- copy kernels: small blocks between pinned host memory and the device without the copy engine ------------------
+__global__ __launch_bounds__(256) void plain_blit_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, unsigned head_words,
+                                                         const int* __restrict__ n_rows, int row_words, int max_rows) {
+    unsigned total = head_words;
+    if (n_rows) {
+        int n = *n_rows;
+        n = n < 0 ? 0 : n > max_rows ? max_rows : n;
+        total += (unsigned)n * (unsigned)row_words;
+    }
+    const unsigned i = blockIdx.x * 1024u + threadIdx.x;   // four words per thread, 256 apart: coalesced
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned j = i + 256u * k;
+        if (j < total) dst[j] = src[j];
+    }
+}
+
+int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows, int row_words, int max_rows) {
+    const size_t total = head_words + (n_rows ? (size_t)max_rows * (size_t)row_words : 0);
+    if (total == 0) return VISO_OK;
+    if (total > 0x7fffffffu) { viso_set_error("plain_blit: block too large"); return VISO_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(plain_blit_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), (unsigned)head_words, n_rows, row_words, max_rows);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
+}
+
+int PlainStage::flush(hipStream_t s) {
+    if (off == 0) return VISO_OK;
+    if (off > (1u << 20)) { HIP_TRY(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, s)); return VISO_OK; }   // large: the copy engine is faster
+    return plain_blit(s, h, d, off / 4);
+}
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 static size_t aux_bytes(size_t n) {   // skp 8n + sidx 4n + rank 4n | bstart + xinfo | qord | sums | rows8, 16-B aligned pieces
@@ -84,6 +223,27 @@ extern "C" int viso_plain_cache_stats(int64_t* hits, int64_t* misses) {
     return VISO_OK;
 }
 
+// $VISO_PLAIN_TRACE=1: host microseconds of viso_match_desc by phase, summed per call kind (0 = both images resident,
+// 1 / 2 = one / two uploaded), printed to stderr by viso_plain_trace_dump() (a measurement aid, tools/dropin_probe.py)
+static double g_tr_us[3][6];
+static long g_tr_n[3];
+static int g_tr_on = -1;
+static double g_acq_us[2];
+static long g_acq_n;
+static double tr_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+extern "C" void viso_plain_trace_dump(void) {
+    static const char* ph[6] = {"acquire_q", "acquire_t", "setup+blit_in", "launches", "wait", "copy_out"};
+    for (int k = 0; k < 3; ++k) {
+        if (!g_tr_n[k]) continue;
+        fprintf(stderr, "viso_match_desc, %d image(s) uploaded, %ld calls:", k, g_tr_n[k]);
+        for (int j = 0; j < 6; ++j) fprintf(stderr, "  %s %.1f", ph[j], g_tr_us[k][j] / g_tr_n[k]);
+        fprintf(stderr, "  (us per call)\n");
+    }
+    if (g_acq_n) fprintf(stderr, "uploads: %ld, copy into the shadow %.1f us, hipMemcpyAsync call %.1f us\n", g_acq_n, g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n);
+    g_acq_us[0] = g_acq_us[1] = 0; g_acq_n = 0;
+    memset(g_tr_us, 0, sizeof(g_tr_us)); memset(g_tr_n, 0, sizeof(g_tr_n));
+}
+
 // The slot that holds (kp, d) -- found by comparing bytes, or filled now: shadow copy, ONE upload of kp | desc | hdr.
 // `keep` is a slot that must not be evicted (the call's other image), -1 for none.
 static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const float* d, int n, int dlen, int extras, int r8s,
@@ -94,14 +254,13 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
         for (int i = 0; i < PLAIN_SLOTS; ++i) {
             PlainSlot& s = pc->slot[i];
             if (!s.valid || s.n != n || s.dlen != dlen || s.extras != extras || s.r8s != r8s) continue;
-            if ((kb && memcmp(s.pin, kp, kb) != 0) || (db && memcmp(s.pin + s.o_desc, d, db) != 0)) continue;
-            s.stamp = ++pc->clock;
-            pc->hits += 1;
-            *hit = true;
-            return i;
+            if ((kb && memcmp(s.pin, kp, kb) != 0) || !big_equal(s.pin + s.o_desc, d, db)) continue;
+            pc->hits += 1;   // the stamp stays the upload's: slots are recycled oldest UPLOAD first.  (Refreshed on a hit -- LRU --
+            *hit = true;     // the loop's own order evicts frame t-1's left image when frame t's arrives: its last use was the
+            return i;        // temporal-left call, before the right images' -- and the temporal calls of frame t upload it again.)
         }
     pc->misses += 1;
-    int vi = -1;   // an empty slot, else the least recently used one
+    int vi = -1;   // an empty slot, else the one uploaded longest ago
     for (int i = 0; i < PLAIN_SLOTS && vi < 0; ++i)
         if (i != keep && !pc->slot[i].valid) vi = i;
     for (int i = 0; i < PLAIN_SLOTS && (vi < 0 || pc->slot[vi].valid); ++i)
@@ -125,12 +284,15 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
         HIP_TRY(hipMalloc((void**)&s.dev, total + total / 4));
         s.dev_bytes = total + total / 4;
     }
+    const double ta0 = g_tr_on > 0 ? tr_now() : 0;
     if (kb) memcpy(s.pin, kp, kb);
-    if (db) memcpy(s.pin + o_desc, d, db);
+    big_copy(s.pin + o_desc, d, db);
+    const double ta1 = g_tr_on > 0 ? tr_now() : 0;
     int* hdr = reinterpret_cast<int*>(s.pin + o_hdr);
     hdr[0] = n;
     hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
     HIP_TRY(hipMemcpyAsync(s.dev, s.pin, up, hipMemcpyHostToDevice, c->stream));
+    if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
     s.n = n; s.dlen = dlen; s.extras = extras; s.r8s = r8s;
     s.bad_host = dlen > VISO_ROW ? 1 : -1;
     s.o_desc = o_desc; s.up_bytes = up;
@@ -186,10 +348,15 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     const int r8s = c->row8_force >= 0 ? c->row8_force : VISO_R8_DEFAULT;
     // ---- the two images: resident already, or uploaded now (the uploads start before anything else is prepared)
     bool hit_q = false, hit_t = false;
+    if (g_tr_on < 0) { const char* e = getenv("VISO_PLAIN_TRACE"); g_tr_on = e && *e == '1'; }
+    double tt[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (g_tr_on) tt[0] = tr_now();
     const int iq = plain_acquire(c, pc, kp1, d1, n1, dlen, extras, r8s, -1, &hit_q);
     if (iq < 0) return iq;
+    if (g_tr_on) tt[1] = tr_now();
     const int it = plain_acquire(c, pc, kp2, d2, n2, dlen, extras, r8s, iq, &hit_t);
     if (it < 0) return it;
+    if (g_tr_on) tt[2] = tr_now();
     PlainSlot &sq = pc->slot[iq], &st = pc->slot[it];
     // ---- per-call device memory: one block {problem, views | misc | sorted rows}: its head is uploaded, its tail read back
     struct Head { MatchProblem p; ImageView v[2]; ImageView miss[2]; };
@@ -221,8 +388,9 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     int n_miss = 0, cap_miss = 1;
     if (!hit_q) { H->miss[n_miss++] = P.q; cap_miss = n1 > cap_miss ? n1 : cap_miss; }
     if (!hit_t && it != iq) { H->miss[n_miss++] = P.t; cap_miss = n2 > cap_miss ? n2 : cap_miss; }
-    HIP_TRY(hipMemcpyAsync(blk, hin, o_sorted, hipMemcpyHostToDevice, s));
+    if ((r = plain_blit(s, hin, blk, o_sorted / 4)) < 0) return r;
     pp.mark(1);
+    if (g_tr_on) tt[3] = tr_now();
     const MatchProblem* dprob = reinterpret_cast<const MatchProblem*>(blk);
     const ImageView* dmiss = reinterpret_cast<const ImageView*>(blk + offsetof(Head, miss));
     if (n_miss) {
@@ -238,17 +406,25 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
                                 general_possible, kinds)) < 0) return r;
     if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
     pp.mark(2);
-    // ---- ONE read-back: misc + the worst-case rows (12 B x n1: microseconds of PCIe), then the rows that count
-    HIP_TRY(hipMemcpyAsync(hout, blk + o_misc, blk_bytes - o_misc, hipMemcpyDeviceToHost, s));
+    // ---- ONE read-back: a copy kernel writes misc + the rows that exist (the count is on the device) into pinned memory
+    if ((r = plain_blit(s, blk + o_misc, hout, 64, dmisc + 3, 3, n1)) < 0) return r;
+    if (g_tr_on) tt[4] = tr_now();
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(s));
     pp.wait_end();
+    if (g_tr_on) tt[5] = tr_now();
     const int* omisc = reinterpret_cast<const int*>(hout);
     const int m = omisc[3];
     if (m < 0 || m > n1) { viso_set_error("viso_match_desc: device returned %d matches for %d queries", m, n1); return VISO_ERR_HIP; }
     if (m > 0) memcpy(out_match, hout + 256, sizeof(int) * 3 * (size_t)m);
     if (omisc[7] == 0) { sq.bad_host = 0; st.bad_host = 0; }   // no image of this call is flagged: both fit the u16 rows
     pp.mark(3);
+    if (g_tr_on) {
+        tt[6] = tr_now();
+        const int k = (hit_q ? 0 : 1) + (hit_t ? 0 : 1);
+        for (int j = 0; j < 6; ++j) g_tr_us[k][j] += tt[j + 1] - tt[j];
+        g_tr_n[k] += 1;
+    }
     *out_n = m;
     return VISO_OK;
 }

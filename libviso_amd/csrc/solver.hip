@@ -837,7 +837,7 @@ extern "C" int viso_minimize_reproj(const double* X, const double* obs, int m, d
     hipLaunchKernelGGL(minimize_reproj_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    HIP_TRY(hipMemcpyAsync(hout, dout, 128, hipMemcpyDeviceToHost, c->stream));
+    if ((r = plain_blit(c->stream, dout, hout, 32)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     pp.wait_end();
@@ -877,7 +877,7 @@ extern "C" int viso_get_inliers(const double* X, const double* obs, int m, const
     hipLaunchKernelGGL(get_inliers_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if ((r = plain_blit(c->stream, dout, hout, 16, a.n_inl, 1, m)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     pp.wait_end();
@@ -978,9 +978,12 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     pp.mark(1);
     SolverParamsDev sp;
     fill_solver_params(&sp, p);
-    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split, m)) < 0) return r;
+    // one frame's 50 hypotheses are ONE wave of the lane-per-hypothesis kernel (5 us per iteration): hand over to the
+    // wave-per-hypothesis kernel after the first iteration (2.7 us each, all hypotheses side by side) unless a split was asked
+    // for (viso_ctx_set_gn_split): 203 -> 183 us per call (tools/dropin_probe.py, GN_SPLIT sweep); same hypotheses bit for bit
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split ? c->gn_split : 1, m)) < 0) return r;
     pp.mark(2);
-    HIP_TRY(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if ((r = plain_blit(c->stream, dout, hout, 32, it.n_inl, 1, m)) < 0) return r;
     pp.wait_begin();
     HIP_TRY(hipStreamSynchronize(c->stream));
     pp.wait_end();

@@ -5,10 +5,15 @@ from libviso_amd import synth, drop_in
 from libviso_amd.abi import MatchParams
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 101
 kp = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+import os
+if os.environ.get("GN_SPLIT"): libviso_amd.set_gn_split(int(os.environ["GN_SPLIT"]))
 seq = synth.make_sequence(1000, nf, n_kp=kp)
 # warm
 drop_in.run(seq["kp"][:4], seq["desc"][:4], seq["n"][:4], seq["F"], seq["param"], seed=1)
 o = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=1)
+import ctypes
+try: libviso_amd.load().viso_plain_trace_dump()
+except Exception as e: print(e)
 print("frames", o["frames"], "loop_s", o["loop_s"], "fps", (o["frames"]-1)/o["loop_s"], "carry_s", o["carry_s"])
 for k,(c,us) in o["calls"].items(): print(f"  {k:28s} calls {c:5d}  {us/c:9.1f} us/call  {us/(o['frames']-1):9.1f} us/frame")
 drop_in.plain_profile(True)

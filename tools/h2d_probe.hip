@@ -12,6 +12,14 @@
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 __global__ void empty_kernel(int* p) { if (threadIdx.x == 0) p[0] += 1; }
 
+__global__ void blit_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+__global__ void blit_stride_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct Pool {   // spinning helpers: thread i copies slice i when `gen` advances
     std::vector<std::thread> th; std::atomic<int> gen{0}, done{0}; std::atomic<bool> stop{false};
     const char* src = nullptr; char* dst = nullptr; size_t bytes = 0; int n = 0;
@@ -94,6 +102,53 @@ int main() {
         for (int i = 0; i < R; ++i) { double a = now(); pool.copy(pin, src[i % 16].data(), bytes); tc += now() - a; CK(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
         double dt = (now() - t0) / R;
         printf("%d+1 threads memcpy->pinned (%.1f us = %.1f GB/s) + H2D %zu B + sync: %.1f us = %.1f GB/s\n", T, tc / R, bytes / (tc / R) * 1e-3, bytes, dt, bytes / dt * 1e-3);
+    }
+    // (6) blit kernels instead of the copy engine: the GPU reads pinned host memory / writes it itself
+    {
+        const size_t small = 34 * 1024, res = 24 * 1024;
+        for (int w = 0; w < 2; ++w) {
+            double t0 = now();
+            for (int i = 0; i < R; ++i) {
+                CK(hipMemcpyAsync(dev, pin, small, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag);
+                CK(hipMemcpyAsync(pin + B, dev, res, hipMemcpyDeviceToHost, s));
+                CK(hipStreamSynchronize(s));
+            }
+            if (w) printf("small call, copy engine: H2D 34 KB + kernel + D2H 24 KB + sync: %.1f us\n", (now() - t0) / R);
+        }
+        for (int w = 0; w < 2; ++w) {
+            double t0 = now();
+            for (int i = 0; i < R; ++i) {
+                hipLaunchKernelGGL(blit_kernel, dim3((small / 16 + 255) / 256), dim3(256), 0, s, (const uint4*)pin, (uint4*)dev, small / 16);
+                hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag);
+                hipLaunchKernelGGL(blit_kernel, dim3((res / 16 + 255) / 256), dim3(256), 0, s, (const uint4*)dev, (uint4*)(pin + B), res / 16);
+                CK(hipStreamSynchronize(s));
+            }
+            if (w) printf("small call, blit kernels: pinned->dev 34 KB + kernel + dev->pinned 24 KB + sync: %.1f us\n", (now() - t0) / R);
+        }
+        for (int w = 0; w < 2; ++w) {
+            double t0 = now();
+            for (int i = 0; i < R; ++i) {
+                hipLaunchKernelGGL(blit_kernel, dim3((small / 16 + 255) / 256), dim3(256), 0, s, (const uint4*)pin, (uint4*)(pin + B), res / 16);
+                CK(hipStreamSynchronize(s));
+            }
+            if (w) printf("small call, ONE kernel reading and writing pinned memory + sync: %.1f us\n", (now() - t0) / R);
+        }
+        for (size_t bytes : {B, 2 * B}) {
+            for (int blocks : {64, 256, 1024}) {
+                double t0 = now();
+                for (int i = 0; i < R; ++i) {
+                    hipLaunchKernelGGL(blit_stride_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)pin, (uint4*)dev, bytes / 16);
+                    CK(hipStreamSynchronize(s));
+                }
+                double dt = (now() - t0) / R;
+                printf("blit pinned->dev %zu B, %d blocks + sync: %.1f us = %.1f GB/s\n", bytes, blocks, dt, bytes / dt * 1e-3);
+            }
+            double t0 = now();
+            for (int i = 0; i < R; ++i) { CK(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); }
+            double dt = (now() - t0) / R;
+            printf("copy engine pinned->dev %zu B + sync: %.1f us = %.1f GB/s\n", bytes, dt, bytes / dt * 1e-3);
+        }
     }
     // (5) D2H of 24 KB: pinned vs pageable
     { std::vector<char> out(24000); double t0 = now();
