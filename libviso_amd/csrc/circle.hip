@@ -11,12 +11,6 @@
 // Literal semantics of the reference's four nested loops for ARBITRARY lists
 // (duplicate keys included): thread i owns row i of match_lr, enumerates its
 // (j,k,l) hits in loop order; a workgroup scan keeps the output in i order.
-struct CircleArgs {
-    const int* lr; const int* lrp; const int* m11; const int* m22;
-    int n_lr, n_lrp, n11, n22;
-    int* rows;      // out: 6 ints per joined row: circ_match (ileft, iright, ileft_prev, iright_prev) | match_pcl (i, k)
-    int cap; int* out_n;
-};
 
 template <bool WRITE>
 __device__ __forceinline__ int circle_row(const CircleArgs& a, int i, int off) {
@@ -94,6 +88,10 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total, int*
 __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs a, int* tab, int tabn) {
     __shared__ int scratch[16];
     __shared__ int s_dup;
+    if (a.n_lr_p) a.n_lr = *a.n_lr_p;      // lists that an earlier kernel of the chain produced: their lengths are on the device
+    if (a.n_lrp_p) a.n_lrp = *a.n_lrp_p;
+    if (a.n11_p) a.n11 = *a.n11_p;
+    if (a.n22_p) a.n22 = *a.n22_p;
     int* t11 = tab; int* tlrp = tab + tabn; int* t22 = tab + 2 * tabn;
     if (threadIdx.x == 0) s_dup = 0;
     for (int i = threadIdx.x; i < 3 * tabn; i += CIRCT_THREADS) tab[i] = -1;
@@ -151,6 +149,12 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
         }
     }
     if (threadIdx.x == 0) *a.out_n = running;
+}
+
+int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn) {
+    hipLaunchKernelGGL(circle_table_kernel, dim3(1), dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
+    HIP_TRY(hipGetLastError());
+    return VISO_OK;
 }
 
 // ------------------------------------------------------------------ table join
@@ -309,6 +313,10 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     if (!c) return VISO_ERR_HIP;
     HIP_TRY(hipSetDevice(c->device));
     PlainProf pp(VISO_PLAIN_MATCH_CIRCLE, c->stream);
+    {   // the frame's stereo call may have joined exactly these lists already (plain.hip)
+        int ret = VISO_OK;
+        if (plain_try_circle(c, lr, n_lr, lr_prev, n_lrp, m11, n11, m22, n22, circ, pcl, cap, out_n, &ret)) return ret;
+    }
     // size of the tables: the largest key of the three keyed lists (a look at ~4 500 ints; argument inspection, no arithmetic of the path)
     long long kmax = -1;
     bool tables = true;
@@ -333,8 +341,7 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     a.out_n = reinterpret_cast<int*>(dout); a.rows = reinterpret_cast<int*>(dout + 256);
     if ((r = in.flush(c->stream)) < 0) return r;
     pp.mark(1);
-    hipLaunchKernelGGL(circle_table_kernel, dim3(1), dim3(CIRCT_THREADS), 0, c->stream, a, dtab, tabn);
-    HIP_TRY(hipGetLastError());
+    if ((r = launch_circle_table(c->stream, a, dtab, tabn)) < 0) return r;
     pp.mark(2);
     // the rows that exist (the count is on the device), by a copy kernel into pinned memory
     if ((r = plain_blit(c->stream, dout, hout, 64, a.out_n, 6, cap)) < 0) return r;
@@ -344,6 +351,7 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     const int w = cnt < cap ? cnt : cap;
     pp.wait_end();
     *out_n = cnt;
+    plain_note_circle(c, cnt);
     const int* rows = reinterpret_cast<const int*>(hout + 256);
     for (int i = 0; i < w; ++i) {
         circ[4 * i + 0] = rows[6 * i + 0]; circ[4 * i + 1] = rows[6 * i + 1]; circ[4 * i + 2] = rows[6 * i + 2]; circ[4 * i + 3] = rows[6 * i + 3];
@@ -371,6 +379,7 @@ extern "C" int viso_collect_matches(const float* kp1, int n1, const float* kp2, 
     if (!c) return VISO_ERR_HIP;
     HIP_TRY(hipSetDevice(c->device));
     PlainProf pp(VISO_PLAIN_COLLECT_MATCHES, c->stream);
+    if (plain_try_collect(c, kp1, n1, kp2, n2, match, n, x)) return VISO_OK;   // the frame's stereo call computed it (plain.hip)
     int r;
     PlainStage in;
     const size_t in_bytes = PlainStage::need(sizeof(float2) * (size_t)n1) + PlainStage::need(sizeof(float2) * (size_t)n2) +
@@ -409,6 +418,7 @@ extern "C" int viso_triangulate_rectified(const double* x, int m, const viso_par
     if (!c) return VISO_ERR_HIP;
     HIP_TRY(hipSetDevice(c->device));
     PlainProf pp(VISO_PLAIN_TRIANGULATE, c->stream);
+    if (plain_try_triangulate(c, x, m, p, X)) return VISO_OK;   // the frame's stereo call computed it (plain.hip)
     int r;
     PlainStage in;
     if ((r = in.begin(c, PlainStage::need(sizeof(double) * 4 * (size_t)m))) < 0) return r;

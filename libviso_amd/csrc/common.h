@@ -136,6 +136,25 @@ struct PlainProf {
 int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
 int ctx_pinned(viso_ctx* c, int which, size_t bytes, char** out);
 void plain_cache_free(viso_ctx* c);   // plain.hip; from viso_ctx_destroy
+// plain.hip: a call of the reference's loop that the frame's stereo call has already answered (1 = served, 0 = go to the device)
+int plain_try_collect(viso_ctx* c, const float* kp1, int n1, const float* kp2, int n2, const int32_t* match, int n, double* x);
+int plain_try_triangulate(viso_ctx* c, const double* x, int m, const viso_param* p, double* X);
+int plain_try_circle(viso_ctx* c, const int32_t* lr, int n_lr, const int32_t* lr_prev, int n_lrp, const int32_t* m11, int n11,
+                     const int32_t* m22, int n22, int32_t* circ, int32_t* pcl, int cap, int* out_n, int* ret);
+void plain_note_circle(viso_ctx* c, int cnt);
+int plain_try_ransac(viso_ctx* c, const double* X, const double* obs, int m, double best_tr[6], int32_t* best_inl, int* n_inl,
+                     const viso_param* p, const int32_t* samples, uint64_t seed, uint64_t frame, int* ret);
+
+// match_circle on lists in device memory (circle.hip): counts by value, or read from the device when the pointers are set
+struct CircleArgs {
+    const int* lr; const int* lrp; const int* m11; const int* m22;
+    int n_lr, n_lrp, n11, n22;
+    const int* n_lr_p; const int* n_lrp_p; const int* n11_p; const int* n22_p;   // device counts (override the values), or null
+    int* rows;      // out: 6 ints per joined row: circ_match (ileft, iright, ileft_prev, iright_prev) | match_pcl (i, k)
+    int cap; int* out_n;
+};
+// tab: 3 * tabn ints of device scratch; keys outside [0, tabn) or duplicate keys take the literal nested loops
+int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn);
 viso_ctx* viso_default_ctx();
 
 // One plain-family call's inputs: appended to the context's pinned block (256-B aligned pieces), mirrored at the same

@@ -137,11 +137,58 @@ struct PlainSlot {
     size_t o_desc, up_bytes;
     ImageView v;                    // device pointers into dev
 };
+// ---- the frame a stereo call opens ----------------------------------------------------------------------------------
+// The reference's loop body is a fixed sequence (src/viso.cpp:1240-1313), and after the stereo call of frame t everything
+// its next calls will ask for is already determined by data the library holds: the temporal calls match the two images it
+// has just been given against the two of the previous stereo call (resident in their slots), collect_matches /
+// triangulate_rectified read the stereo matches and the keypoints.  So the stereo call -- the one round trip the frame
+// cannot avoid -- also runs those problems, in the same launches (three match_desc problems in one matcher launch, as the
+// batch family does), and keeps the results.  A later call is answered from them only if its ARGUMENTS are byte for byte
+// what was assumed (the images by their slots -- already a byte comparison --, match lists, x, the parameter structs by
+// memcmp): the functions are pure, equal inputs give the result the direct path would compute, and any other input takes
+// the direct path.  Nothing is predicted about the DATA, only about which call comes next; a wrong guess costs the
+// guessed work, never a result.  $VISO_PLAIN_SPECULATE=0 / viso_plain_speculate(0) switch it off (every call direct).
+#define PF_PROBS 3      // 0 = stereo (L, R), 1 = temporal (L, previous L), 2 = temporal (R, previous R)
+struct PlainFrame {
+    bool valid;
+    int L, R;                              // image slots of the stereo call
+    unsigned long long sL, sR;             // their upload stamps (a recycled slot invalidates what was computed from it)
+    int cap;                               // rows per problem the blocks are laid out for
+    char* dev; size_t dev_bytes;
+    char* host; size_t host_bytes;         // pinned mirror of the result part [o_misc, o_end)
+    size_t o_misc, o_sorted[PF_PROBS], o_x, o_X, o_circ, o_xc, o_Xpc, o_rs, o_end;
+    bool have[PF_PROBS], used[PF_PROBS];
+    int nq[PF_PROBS], m[PF_PROBS];
+    int tq[PF_PROBS], tt[PF_PROBS];
+    unsigned long long stq[PF_PROBS], stt[PF_PROBS];
+    viso_match_params mp[PF_PROBS];
+    bool have_xX, used_x, used_X;          // collect_matches / triangulate_rectified of the stereo matches
+    viso_param tri_p;
+    // second part of the chain, still running when the stereo call returns: match_circle of the frame's four lists, the
+    // gather of src/viso.cpp:1292-1305, ransac_minimize_reproj with the parameters / stream key the loop is expected to pass
+    bool have_B, pending_B, used_circ, used_rs;
+    int n_circ;                            // rows of the join (host, once B has been waited for)
+    viso_param rs_p; uint64_t rs_seed, rs_frame;
+    hipEvent_t evA;                        // behind the first part's copy-out
+};
 struct PlainCache {
     PlainSlot slot[PLAIN_SLOTS];
     unsigned long long clock;
     long long hits, misses;
     int enabled;
+    // frames: [cur] the last stereo call's, [cur ^ 1] the one before, [2] scratch of the calls outside a frame
+    PlainFrame frame[3];
+    int cur;
+    int speculate;                         // 0 = every call direct
+    bool tm_known, tm_pattern;             // temporal params seen; a temporal call fitted (L, previous L) / (R, previous R)
+    viso_match_params tm;
+    bool tri_known, x_pattern;             // triangulate's param seen; a collect call fitted the stereo call's outputs
+    viso_param tri_p;
+    bool circ_pattern;                     // a match_circle call took the frame's own lists
+    unsigned long long frame_no, circ_seen_no; int circ_seen_cnt;
+    bool rs_known, rs_pattern, rs_delta_stable;   // ransac's param / seed seen; the call fitted; the stream key advances regularly
+    viso_param rs_p; uint64_t rs_seed, rs_last_frame, rs_delta;
+    long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
 
 // ---- copy kernels: small blocks between pinned host memory and the device without the copy engine ------------------
@@ -188,6 +235,8 @@ static PlainCache* plain_cache(viso_ctx* c) {
         if (!c->plain) return nullptr;
         const char* e = getenv("VISO_PLAIN_CACHE");   // 0: every image is uploaded and packed again (A/B and test aid)
         c->plain->enabled = !(e && *e == '0');
+        e = getenv("VISO_PLAIN_SPECULATE");
+        c->plain->speculate = !(e && *e == '0');
     }
     return c->plain;
 }
@@ -197,6 +246,11 @@ void plain_cache_free(viso_ctx* c) {
     for (int i = 0; i < PLAIN_SLOTS; ++i) {
         if (c->plain->slot[i].pin) (void)hipHostFree(c->plain->slot[i].pin);
         if (c->plain->slot[i].dev) (void)hipFree(c->plain->slot[i].dev);
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (c->plain->frame[i].host) (void)hipHostFree(c->plain->frame[i].host);
+        if (c->plain->frame[i].dev) (void)hipFree(c->plain->frame[i].dev);
+        if (c->plain->frame[i].evA) (void)hipEventDestroy(c->plain->frame[i].evA);
     }
     free(c->plain);
     c->plain = nullptr;
@@ -208,8 +262,34 @@ extern "C" int viso_plain_cache(int enable) {
     if (!c) return VISO_ERR_HIP;
     PlainCache* pc = plain_cache(c);
     if (!pc) { viso_set_error("viso_plain_cache: out of memory"); return VISO_ERR_NOMEM; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     pc->enabled = enable != 0;
     for (int i = 0; i < PLAIN_SLOTS; ++i) pc->slot[i].valid = false;
+    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; }
+    return VISO_OK;
+}
+
+extern "C" int viso_plain_speculate(int enable) {
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c) return VISO_ERR_HIP;
+    PlainCache* pc = plain_cache(c);
+    if (!pc) { viso_set_error("viso_plain_speculate: out of memory"); return VISO_ERR_NOMEM; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    pc->speculate = enable != 0;
+    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; }
+    pc->tm_pattern = pc->x_pattern = pc->circ_pattern = pc->rs_pattern = pc->rs_delta_stable = false;
+    return VISO_OK;
+}
+
+// out[0..3] = calls answered from a frame's results (temporal match_desc, collect_matches, triangulate_rectified, -),
+// out[4..7] = results computed ahead that no call asked for
+extern "C" int viso_plain_speculate_stats(int64_t out[8]) {
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    if (!c || !out) return VISO_ERR_HIP;
+    PlainCache* pc = plain_cache(c);
+    for (int i = 0; i < 4; ++i) { out[i] = pc ? pc->spec_served[i] : 0; out[4 + i] = pc ? pc->spec_wasted[i] : 0; }
     return VISO_OK;
 }
 
@@ -318,6 +398,109 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     return vi;
 }
 
+// ---- results out: every region's rows that exist (counts on the device) into the pinned mirror, ONE launch ----------
+struct OutRegion { const uint32_t* src; uint32_t* dst; const int* cnt; int row_words, max_rows; };
+#define OUT_REGIONS 24
+struct OutArgs { OutRegion r[OUT_REGIONS]; };
+__global__ __launch_bounds__(256) void plain_out_kernel(OutArgs a) {
+    const OutRegion R = a.r[blockIdx.y];
+    int n = R.max_rows;
+    if (R.cnt) { const int c = *R.cnt; n = c < 0 ? 0 : c < n ? c : n; }
+    const unsigned total = (unsigned)n * (unsigned)R.row_words;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) R.dst[i] = R.src[i];
+}
+
+static bool params_equal(const viso_match_params& a, const viso_match_params& b) {
+    return a.enforce_epipolar == b.enforce_epipolar && a.enforce_2nd_best == b.enforce_2nd_best && a.max_neighbors == b.max_neighbors &&
+           memcmp(a.F, b.F, sizeof(a.F)) == 0 && memcmp(&a.sampson_thresh, &b.sampson_thresh, 8) == 0 &&
+           memcmp(&a.ratio_2nd_best, &b.ratio_2nd_best, 8) == 0 && memcmp(&a.radius, &b.radius, 8) == 0;
+}
+static bool tri_equal(const viso_param& a, const viso_param& b) {   // the fields triangulate_rectified reads, bit for bit
+    return memcmp(&a.base, &b.base, 8) == 0 && memcmp(&a.f, &b.f, 8) == 0 && memcmp(&a.cu, &b.cu, 8) == 0 && memcmp(&a.cv, &b.cv, 8) == 0;
+}
+
+struct FrameHead { MatchProblem p[PF_PROBS]; ImageView miss[2]; TriItem tri; SolverItem rs; };
+
+// x_c / Xp_c of src/viso.cpp:1292-1305: columns of x (this frame) and of the previous frame's X picked by match_pcl
+__global__ __launch_bounds__(256) void plain_gather_kernel(const int* __restrict__ rows, const int* __restrict__ cnt, int cap,
+                                                           const double* __restrict__ x, int ld_x, const double* __restrict__ Xp, int ld_Xp,
+                                                           double* __restrict__ x_c, double* __restrict__ Xp_c, int ldc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int n = *cnt;
+    n = n < cap ? n : cap;
+    if (i >= n) return;
+    const int a = rows[6 * i + 4], k = rows[6 * i + 5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x_c[(size_t)r * ldc + i] = x[(size_t)r * ld_x + a];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Xp_c[(size_t)r * ldc + i] = Xp[(size_t)r * ld_Xp + k];
+}
+
+// lays a frame's blocks out for `cap` rows per problem (grow only)
+static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
+    const size_t C = (size_t)(cap > 0 ? cap : 1);
+    size_t o = al256(sizeof(FrameHead));
+    f.o_misc = o; o += 256;
+    for (int p = 0; p < PF_PROBS; ++p) { f.o_sorted[p] = o; o += al256(sizeof(int) * 3 * C); }
+    f.o_x = o; o += al256(sizeof(double) * 4 * C);
+    f.o_X = o; o += al256(sizeof(double) * 3 * C);
+    f.o_circ = o; o += al256(sizeof(int) * 6 * C);
+    f.o_xc = o; o += al256(sizeof(double) * 4 * C);
+    f.o_Xpc = o; o += al256(sizeof(double) * 3 * C);
+    f.o_rs = o; o += 128 + al256(sizeof(int) * C);
+    f.o_end = o;
+    const size_t scratch = PF_PROBS * (al256(sizeof(int2) * C) + al256(sizeof(int) * C) + al256(sizeof(int) * (C / 64 + 1))) + al256(sizeof(int2) * PF_PROBS * C);
+    const size_t total = o + scratch;
+    if (f.dev_bytes < total) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (f.dev) HIP_TRY(hipFree(f.dev));
+        f.dev = nullptr; f.dev_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&f.dev, total + total / 4));
+        f.dev_bytes = total + total / 4;
+    }
+    if (f.host_bytes < f.o_end - f.o_misc) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (f.host) HIP_TRY(hipHostFree(f.host));
+        f.host = nullptr; f.host_bytes = 0;
+        const size_t want = (f.o_end - f.o_misc) + (f.o_end - f.o_misc) / 4;
+        HIP_TRY(hipHostMalloc((void**)&f.host, want, hipHostMallocDefault));
+        f.host_bytes = want;
+    }
+    if (!f.evA) HIP_TRY(hipEventCreateWithFlags(&f.evA, hipEventDisableTiming));
+    f.cap = cap;
+    return VISO_OK;
+}
+
+static void frame_reset(PlainFrame& f) {
+    f.valid = false;
+    for (int p = 0; p < PF_PROBS; ++p) { f.have[p] = f.used[p] = false; f.m[p] = 0; }
+    f.have_xX = f.used_x = f.used_X = false;
+    f.have_B = f.used_circ = f.used_rs = false;
+    f.n_circ = 0;
+}
+
+// the second part of a frame's chain has finished: its counters are in the mirror
+static int frame_wait_B(viso_ctx* c, PlainFrame& f) {
+    if (!f.pending_B) return VISO_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    f.pending_B = false;
+    const int* om = reinterpret_cast<const int*>(f.host);
+    f.n_circ = om[32];
+    return VISO_OK;
+}
+
+// what a frame computed ahead and nobody asked for: the pattern it was guessed from no longer holds
+static void frame_retire(PlainCache* pc, PlainFrame& f) {
+    if (!f.valid) return;
+    if ((f.have[1] && !f.used[1]) || (f.have[2] && !f.used[2])) { pc->tm_pattern = false; pc->spec_wasted[0] += 1; }
+    if (f.have_xX && !f.used_x) { pc->x_pattern = false; pc->spec_wasted[1] += 1; }
+    if (f.have_xX && f.used_x && !f.used_X) pc->spec_wasted[2] += 1;
+    if (f.have_B && !f.used_circ) { pc->circ_pattern = false; pc->spec_wasted[2] += 1; }
+    if (f.have_B && !f.used_rs) { pc->rs_pattern = false; pc->spec_wasted[3] += 1; }
+}
+
+static const int* frame_rows(const PlainFrame& f, int p) { return reinterpret_cast<const int*>(f.host + (f.o_sorted[p] - f.o_misc)); }
+
 // match_desc, reference src/viso.cpp:669-726.
 extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n2,
                                const float* d1, const float* d2, int dlen,
@@ -357,68 +540,221 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     const int it = plain_acquire(c, pc, kp2, d2, n2, dlen, extras, r8s, iq, &hit_t);
     if (it < 0) return it;
     if (g_tr_on) tt[2] = tr_now();
+    const bool stereo_call = mp->enforce_epipolar != 0;
+    // ---- a temporal call the frame's stereo call has already answered?
+    if (!stereo_call) {
+        PlainFrame& cur = pc->frame[pc->cur];
+        PlainFrame& prv = pc->frame[pc->cur ^ 1];
+        if (pc->speculate && cur.valid)
+            for (int p = 1; p < PF_PROBS; ++p)
+                if (cur.have[p] && cur.tq[p] == iq && cur.tt[p] == it && pc->slot[iq].stamp == cur.stq[p] &&
+                    pc->slot[it].stamp == cur.stt[p] && params_equal(*mp, cur.mp[p])) {
+                    const int m = cur.m[p];
+                    if (m > 0) memcpy(out_match, frame_rows(cur, p), sizeof(int) * 3 * (size_t)m);
+                    *out_n = m;
+                    cur.used[p] = true;
+                    pc->spec_served[0] += 1;
+                    return VISO_OK;
+                }
+        // the direct path it is; remember what a temporal call looks like, and whether it is the loop's
+        pc->tm = *mp; pc->tm_known = true;
+        if (cur.valid && prv.valid && ((iq == cur.L && it == prv.L && pc->slot[it].stamp == prv.sL) ||
+                                       (iq == cur.R && it == prv.R && pc->slot[it].stamp == prv.sR))) pc->tm_pattern = true;
+    }
+    // ---- which frame object takes the call, and which problems ride along
+    PlainFrame* f = &pc->frame[2];
+    int np = 1;
+    bool spec_x = false, spec_B = false;
+    if (stereo_call && pc->speculate) {
+        if (pc->frame[pc->cur ^ 1].pending_B && (r = frame_wait_B(c, pc->frame[pc->cur ^ 1])) < 0) return r;
+        frame_retire(pc, pc->frame[pc->cur ^ 1]);   // the frame that leaves
+        pc->frame_no += 1;
+        pc->cur ^= 1;
+        f = &pc->frame[pc->cur];
+        PlainFrame& prv = pc->frame[pc->cur ^ 1];
+        frame_reset(*f);
+        f->L = iq; f->R = it; f->sL = pc->slot[iq].stamp; f->sR = pc->slot[it].stamp;
+        if (pc->tm_known && pc->tm_pattern && prv.valid && iq != it && prv.L != prv.R &&
+            pc->slot[prv.L].valid && pc->slot[prv.L].stamp == prv.sL && pc->slot[prv.R].valid && pc->slot[prv.R].stamp == prv.sR &&
+            pc->slot[prv.L].dlen == dlen && pc->slot[prv.R].dlen == dlen && pc->slot[prv.L].extras == extras && pc->slot[prv.R].extras == extras &&
+            pc->slot[prv.L].r8s == r8s && pc->slot[prv.R].r8s == r8s && prv.L != iq && prv.L != it && prv.R != iq && prv.R != it)
+            np = 3;
+        spec_x = pc->tri_known && pc->x_pattern;
+        spec_B = np == 3 && spec_x && prv.have_xX && prv.have[0] && pc->circ_pattern && pc->rs_known && pc->rs_pattern && pc->rs_delta_stable &&
+                 pc->rs_p.ransac_iter >= 0 && pc->rs_p.ransac_iter <= 4096;
+    } else {
+        frame_reset(*f);
+    }
     PlainSlot &sq = pc->slot[iq], &st = pc->slot[it];
-    // ---- per-call device memory: one block {problem, views | misc | sorted rows}: its head is uploaded, its tail read back
-    struct Head { MatchProblem p; ImageView v[2]; ImageView miss[2]; };
-    const size_t o_misc = al256(sizeof(Head)), o_sorted = o_misc + 256, blk_bytes = o_sorted + al256(sizeof(int) * 3 * (size_t)n1);
-    char *blk, *hin, *hout;
-    int2 *dres, *dovf; int *dpos, *dtile;
-    if ((r = ctx_scratch(c, PLAIN_SLOT_IN, blk_bytes, (void**)&blk)) < 0) return r;
-    if ((r = ctx_pinned(c, 0, o_sorted, &hin)) < 0) return r;
-    if ((r = ctx_pinned(c, 1, blk_bytes - o_misc, &hout)) < 0) return r;
-    if ((r = ctx_scratch(c, 6, sizeof(int2) * (size_t)n1, (void**)&dres)) < 0) return r;
-    if ((r = ctx_scratch(c, 8, sizeof(int) * (size_t)n1, (void**)&dpos)) < 0) return r;
-    if ((r = ctx_scratch(c, 12, sizeof(int) * ((size_t)n1 / 64 + 1), (void**)&dtile)) < 0) return r;
-    if ((r = ctx_scratch(c, 13, sizeof(int2) * (size_t)n1, (void**)&dovf)) < 0) return r;
-    int* dmisc = reinterpret_cast<int*>(blk + o_misc);
-    // misc: [3] m_cnt  [4..5] scored (u64)  [6] ovf_cnt  [7] "some image of this call is flagged" (lets the general
-    // kernels leave at once)  [8] tiles match_stereo_kernel declines (follows [7]: BatchMatchArgs::bad[1])
-    Head* H = reinterpret_cast<Head*>(hin);
-    memset(hin + o_misc, 0, 256);
-    int* hmisc = reinterpret_cast<int*>(hin + o_misc);
-    // a resident image whose flag the host has not seen yet may be flagged: say so, the kernels look at the image's own flag
-    if ((hit_q && sq.bad_host != 0) || (hit_t && st.bad_host != 0) || dlen > VISO_ROW) hmisc[7] = 1;
-    MatchProblem P{};
-    P.q = sq.v; P.t = st.v;
-    P.res = dres; P.sorted = reinterpret_cast<int*>(blk + o_sorted); P.pos = dpos;
-    P.m_cnt = dmisc + 3; P.scored = reinterpret_cast<unsigned long long*>(dmisc + 4); P.pidx = 0; P.cap = n1;
-    P.tile_flag = dtile;
-    P.ovf = dovf; P.ovf_cnt = dmisc + 6;
-    H->p = P; H->v[0] = P.q; H->v[1] = P.t;
+    f->have[0] = true; f->nq[0] = n1; f->tq[0] = iq; f->tt[0] = it; f->stq[0] = sq.stamp; f->stt[0] = st.stamp; f->mp[0] = *mp;
+    if (np == 3) {
+        PlainFrame& prv = pc->frame[pc->cur ^ 1];
+        f->have[1] = true; f->nq[1] = sq.n; f->tq[1] = iq; f->tt[1] = prv.L; f->stq[1] = sq.stamp; f->stt[1] = prv.sL; f->mp[1] = pc->tm;
+        f->have[2] = true; f->nq[2] = st.n; f->tq[2] = it; f->tt[2] = prv.R; f->stq[2] = st.stamp; f->stt[2] = prv.sR; f->mp[2] = pc->tm;
+    }
+    int cap = n1;
+    for (int p = 1; p < np; ++p) cap = f->nq[p] > cap ? f->nq[p] : cap;
+    if ((r = frame_reserve(c, *f, cap)) < 0) return r;
+    const size_t C = (size_t)(cap > 0 ? cap : 1);
+    // ---- the head of the frame's block: problems, the images to sort and pack, zeroed counters -- ONE copy in
+    char* hin;
+    if ((r = ctx_pinned(c, 0, f->o_misc + 256, &hin)) < 0) return r;
+    FrameHead* H = reinterpret_cast<FrameHead*>(hin);
+    memset(hin + f->o_misc, 0, 256);
+    int* hmisc = reinterpret_cast<int*>(hin + f->o_misc);
+    int* dmisc = reinterpret_cast<int*>(f->dev + f->o_misc);
+    // misc: [6] overflow queue length  [7] "some image of this launch is flagged" (lets the general kernels leave at once)
+    // [8] tiles match_stereo_kernel declines (BatchMatchArgs::bad[1])  [16 + 4p] matches of problem p, [18 + 4p] its scored pairs (u64)
+    char* sc = f->dev + f->o_end;
+    int2* dovf = reinterpret_cast<int2*>(sc + PF_PROBS * (al256(sizeof(int2) * C) + al256(sizeof(int) * C) + al256(sizeof(int) * (C / 64 + 1))));
+    bool all_good = true;
     int n_miss = 0, cap_miss = 1;
-    if (!hit_q) { H->miss[n_miss++] = P.q; cap_miss = n1 > cap_miss ? n1 : cap_miss; }
-    if (!hit_t && it != iq) { H->miss[n_miss++] = P.t; cap_miss = n2 > cap_miss ? n2 : cap_miss; }
-    if ((r = plain_blit(s, hin, blk, o_sorted / 4)) < 0) return r;
+    for (int p = 0; p < np; ++p) {
+        PlainSlot &a = pc->slot[f->tq[p]], &b = pc->slot[f->tt[p]];
+        if (a.bad_host != 0 || b.bad_host != 0) all_good = false;
+        MatchProblem P{};
+        P.q = a.v; P.t = b.v;
+        char* ps = sc + p * (al256(sizeof(int2) * C) + al256(sizeof(int) * C) + al256(sizeof(int) * (C / 64 + 1)));
+        P.res = reinterpret_cast<int2*>(ps);
+        P.pos = reinterpret_cast<int*>(ps + al256(sizeof(int2) * C));
+        P.tile_flag = reinterpret_cast<int*>(ps + al256(sizeof(int2) * C) + al256(sizeof(int) * C));
+        P.sorted = reinterpret_cast<int*>(f->dev + f->o_sorted[p]);
+        P.m_cnt = dmisc + 16 + 4 * p; P.scored = reinterpret_cast<unsigned long long*>(dmisc + 18 + 4 * p);
+        P.pidx = p == 0 ? 0 : 1; P.cap = cap;
+        P.ovf = dovf; P.ovf_cnt = dmisc + 6;
+        H->p[p] = P;
+    }
+    // a resident image whose flag the host has not seen yet may be flagged: say so, the kernels look at the image's own flag
+    if ((hit_q && sq.bad_host != 0) || (hit_t && st.bad_host != 0) || dlen > VISO_ROW || (np == 3 && !all_good)) hmisc[7] = 1;
+    if (!hit_q) { H->miss[n_miss++] = sq.v; cap_miss = n1 > cap_miss ? n1 : cap_miss; }
+    if (!hit_t && it != iq) { H->miss[n_miss++] = st.v; cap_miss = n2 > cap_miss ? n2 : cap_miss; }
+    if (spec_x) {
+        TriItem T{};
+        T.kp1 = sq.v.kp; T.kp2 = st.v.kp; T.match = reinterpret_cast<const int*>(f->dev + f->o_sorted[0]); T.m_cnt = dmisc + 16;
+        T.x = reinterpret_cast<double*>(f->dev + f->o_x); T.X = reinterpret_cast<double*>(f->dev + f->o_X); T.ld = (int)C;
+        H->tri = T;
+    }
+    int *rs_tab = nullptr, *rs_queue = nullptr, rs_tabn = 0;
+    if (spec_B) {
+        PlainFrame& prv = pc->frame[pc->cur ^ 1];
+        const int iters = pc->rs_p.ransac_iter;
+        double* dtrh; int* dhyp; char* drot;
+        rs_tabn = sq.n > st.n ? sq.n : st.n;
+        if (pc->slot[prv.L].n > rs_tabn) rs_tabn = pc->slot[prv.L].n;
+        if ((r = ctx_scratch(c, 16, sizeof(int) * 3 * (size_t)(rs_tabn + 1), (void**)&rs_tab)) < 0) return r;
+        if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dhyp)) < 0) return r;
+        if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)(iters + 1), (void**)&dtrh)) < 0) return r;
+        if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&rs_queue)) < 0) return r;
+        if ((r = ctx_scratch(c, 9, viso_rot_bytes(iters), (void**)&drot)) < 0) return r;
+        f->rs_p = pc->rs_p; f->rs_seed = pc->rs_seed; f->rs_frame = pc->rs_last_frame + pc->rs_delta;
+        SolverItem it{};
+        it.X = reinterpret_cast<const double*>(f->dev + f->o_Xpc); it.obs = reinterpret_cast<const double*>(f->dev + f->o_xc);
+        it.m_ptr = dmisc + 32; it.ld = (int)C; it.samples = nullptr; it.samp_h = rs_queue + 2 + iters; it.frame = f->rs_frame;
+        it.tr_h = dtrh; it.ok_h = dhyp; it.cnt_h = dhyp + iters; it.rot = drot;
+        int* rso = reinterpret_cast<int*>(f->dev + f->o_rs);
+        it.ok = rso + 1; it.n_inl = rso + 2; it.tr = reinterpret_cast<double*>(f->dev + f->o_rs + 64); it.inl = reinterpret_cast<int*>(f->dev + f->o_rs + 128);
+        H->rs = it;
+        (void)prv;
+    }
+    if ((r = plain_blit(s, hin, f->dev, (f->o_misc + 256) / 4)) < 0) return r;
     pp.mark(1);
     if (g_tr_on) tt[3] = tr_now();
-    const MatchProblem* dprob = reinterpret_cast<const MatchProblem*>(blk);
-    const ImageView* dmiss = reinterpret_cast<const ImageView*>(blk + offsetof(Head, miss));
+    const MatchProblem* dprob = reinterpret_cast<const MatchProblem*>(f->dev);
+    const ImageView* dmiss = reinterpret_cast<const ImageView*>(f->dev + offsetof(FrameHead, miss));
     if (n_miss) {
         if ((r = launch_sort_kp(s, dmiss, n_miss, cap_miss)) < 0) return r;
         if (dlen <= VISO_ROW && (r = launch_pack(s, dmiss, n_miss, cap_miss, dlen, nullptr, dmisc + 7, extras, r8s, nullptr)) < 0) return r;
     }
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
-    mpd[1] = mpd[0];
-    const int general_possible = !(sq.bad_host == 0 && st.bad_host == 0);
-    const int kinds = mpd[0].epi ? VISO_KIND_STEREO : VISO_KIND_TEMPORAL;
-    if ((r = launch_match_timed(s, dprob, 1, n1, dlen, mpd, dmisc + 7, nullptr, nullptr, 0, variant, dovf, dmisc + 6, r8s,
+    if (np == 3) fill_match_params(&mpd[1], &pc->tm); else mpd[1] = mpd[0];
+    const int general_possible = !all_good;
+    const int kinds = np == 3 ? VISO_KIND_ALL : mpd[0].epi ? VISO_KIND_STEREO : VISO_KIND_TEMPORAL;
+    if ((r = launch_match_timed(s, dprob, np, cap, dlen, mpd, dmisc + 7, nullptr, nullptr, 0, variant, dovf, dmisc + 6, r8s,
                                 general_possible, kinds)) < 0) return r;
-    if ((r = launch_sort(s, dprob, 1, n1)) < 0) return r;
+    if ((r = launch_sort(s, dprob, np, cap)) < 0) return r;
+    if (spec_x) {
+        SolverParamsDev sp;
+        fill_solver_params(&sp, &pc->tri_p);
+        if ((r = launch_collect_triangulate(s, reinterpret_cast<const TriItem*>(f->dev + offsetof(FrameHead, tri)), 1, sp, n1)) < 0) return r;
+    }
     pp.mark(2);
-    // ---- ONE read-back: a copy kernel writes misc + the rows that exist (the count is on the device) into pinned memory
-    if ((r = plain_blit(s, blk + o_misc, hout, 64, dmisc + 3, 3, n1)) < 0) return r;
+    // ---- ONE read-back: a copy kernel writes the counters and the rows that exist into the frame's pinned mirror
+    {
+        OutArgs oa{};
+        int nr = 0;
+        auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
+            oa.r[nr].src = reinterpret_cast<const uint32_t*>(f->dev + off);
+            oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host + (off - f->o_misc));
+            oa.r[nr].cnt = cnt; oa.r[nr].row_words = row_words; oa.r[nr].max_rows = max_rows;
+            ++nr;
+        };
+        region(f->o_misc, nullptr, 64, 1);
+        for (int p = 0; p < np; ++p) region(f->o_sorted[p], dmisc + 16 + 4 * p, 3, f->nq[p]);
+        if (spec_x) {
+            for (int k = 0; k < 4; ++k) region(f->o_x + sizeof(double) * C * k, dmisc + 16, 2, n1);
+            for (int k = 0; k < 3; ++k) region(f->o_X + sizeof(double) * C * k, dmisc + 16, 2, n1);
+        }
+        const unsigned gx = (unsigned)((3 * C + 1023) / 1024);
+        hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, oa);
+        HIP_TRY(hipGetLastError());
+    }
+    pp.mark(3);
+    if (spec_B) {   // ---- the second part: it keeps running while the caller goes through collect / triangulate / the temporal calls
+        PlainFrame& prv = pc->frame[pc->cur ^ 1];
+        HIP_TRY(hipEventRecord(f->evA, s));
+        const int* pmisc = reinterpret_cast<const int*>(prv.dev + prv.o_misc);
+        CircleArgs ca{};
+        ca.lr = reinterpret_cast<const int*>(f->dev + f->o_sorted[0]); ca.lrp = reinterpret_cast<const int*>(prv.dev + prv.o_sorted[0]);
+        ca.m11 = reinterpret_cast<const int*>(f->dev + f->o_sorted[1]); ca.m22 = reinterpret_cast<const int*>(f->dev + f->o_sorted[2]);
+        ca.n_lr_p = dmisc + 16; ca.n_lrp_p = pmisc + 16; ca.n11_p = dmisc + 20; ca.n22_p = dmisc + 24;
+        ca.rows = reinterpret_cast<int*>(f->dev + f->o_circ); ca.cap = cap; ca.out_n = dmisc + 32;
+        if ((r = launch_circle_table(s, ca, rs_tab, rs_tabn)) < 0) return r;
+        hipLaunchKernelGGL(plain_gather_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, ca.rows, dmisc + 32, cap,
+                           reinterpret_cast<const double*>(f->dev + f->o_x), (int)C,
+                           reinterpret_cast<const double*>(prv.dev + prv.o_X), prv.cap > 0 ? prv.cap : 1,
+                           reinterpret_cast<double*>(f->dev + f->o_xc), reinterpret_cast<double*>(f->dev + f->o_Xpc), (int)C);
+        HIP_TRY(hipGetLastError());
+        SolverParamsDev sp;
+        fill_solver_params(&sp, &f->rs_p);
+        if ((r = launch_ransac(s, reinterpret_cast<const SolverItem*>(f->dev + offsetof(FrameHead, rs)), 1, f->rs_p.ransac_iter, f->rs_seed, sp,
+                               rs_queue, c->gn_split ? c->gn_split : 1, cap)) < 0) return r;
+        OutArgs ob{};
+        int nr = 0;
+        auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
+            ob.r[nr].src = reinterpret_cast<const uint32_t*>(f->dev + off);
+            ob.r[nr].dst = reinterpret_cast<uint32_t*>(f->host + (off - f->o_misc));
+            ob.r[nr].cnt = cnt; ob.r[nr].row_words = row_words; ob.r[nr].max_rows = max_rows;
+            ++nr;
+        };
+        region(f->o_misc + 128, nullptr, 16, 1);                         // misc[32..47]: the join's row count
+        region(f->o_circ, dmisc + 32, 6, cap);
+        for (int k = 0; k < 4; ++k) region(f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
+        for (int k = 0; k < 3; ++k) region(f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
+        region(f->o_rs, nullptr, 32, 1);
+        region(f->o_rs + 128, reinterpret_cast<const int*>(f->dev + f->o_rs) + 2, 1, cap);
+        const unsigned gx = (unsigned)((6 * C + 1023) / 1024);
+        hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, ob);
+        HIP_TRY(hipGetLastError());
+        f->have_B = true; f->pending_B = true;
+    }
     if (g_tr_on) tt[4] = tr_now();
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(s));
+    if (spec_B) HIP_TRY(hipEventSynchronize(f->evA)); else HIP_TRY(hipStreamSynchronize(s));
     pp.wait_end();
     if (g_tr_on) tt[5] = tr_now();
-    const int* omisc = reinterpret_cast<const int*>(hout);
-    const int m = omisc[3];
-    if (m < 0 || m > n1) { viso_set_error("viso_match_desc: device returned %d matches for %d queries", m, n1); return VISO_ERR_HIP; }
-    if (m > 0) memcpy(out_match, hout + 256, sizeof(int) * 3 * (size_t)m);
-    if (omisc[7] == 0) { sq.bad_host = 0; st.bad_host = 0; }   // no image of this call is flagged: both fit the u16 rows
-    pp.mark(3);
+    const int* omisc = reinterpret_cast<const int*>(f->host);
+    for (int p = 0; p < np; ++p) {
+        const int m = omisc[16 + 4 * p];
+        if (m < 0 || m > f->nq[p]) { frame_reset(*f); viso_set_error("viso_match_desc: device returned %d matches for %d queries", m, f->nq[p]); return VISO_ERR_HIP; }
+        f->m[p] = m;
+    }
+    if (omisc[7] == 0)   // no image of this launch is flagged: all of them fit the u16 rows
+        for (int p = 0; p < np; ++p) { pc->slot[f->tq[p]].bad_host = 0; pc->slot[f->tt[p]].bad_host = 0; }
+    const int m = f->m[0];
+    if (m > 0) memcpy(out_match, frame_rows(*f, 0), sizeof(int) * 3 * (size_t)m);
+    f->valid = stereo_call && pc->speculate;
+    f->have_xX = spec_x; f->tri_p = pc->tri_p;
     if (g_tr_on) {
         tt[6] = tr_now();
         const int k = (hit_q ? 0 : 1) + (hit_t ? 0 : 1);
@@ -427,4 +763,125 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     }
     *out_n = m;
     return VISO_OK;
+}
+
+// ---- the frame's other calls (circle.hip asks before it goes to the device) ----------------------------------------
+// collect_matches(kp1, kp2, match) of the stereo call's own output: x is there already.  1 = served, 0 = not.
+int plain_try_collect(viso_ctx* c, const float* kp1, int n1, const float* kp2, int n2, const int32_t* match, int n, double* x) {
+    PlainCache* pc = c->plain;
+    if (!pc || !pc->speculate) return 0;
+    PlainFrame& f = pc->frame[pc->cur];
+    if (!f.valid || !f.have[0] || f.m[0] != n || n <= 0) return 0;
+    const PlainSlot &a = pc->slot[f.L], &b = pc->slot[f.R];
+    if (!a.valid || !b.valid || a.stamp != f.sL || b.stamp != f.sR || a.n != n1 || b.n != n2) return 0;
+    if (memcmp(a.pin, kp1, sizeof(float2) * (size_t)n1) != 0 || memcmp(b.pin, kp2, sizeof(float2) * (size_t)n2) != 0) return 0;
+    if (memcmp(frame_rows(f, 0), match, sizeof(int) * 3 * (size_t)n) != 0) return 0;
+    // the call is the loop's: worth computing ahead from the next frame on
+    pc->x_pattern = true;
+    if (!f.have_xX) return 0;
+    const size_t C = (size_t)(f.cap > 0 ? f.cap : 1);
+    const double* hx = reinterpret_cast<const double*>(f.host + (f.o_x - f.o_misc));
+    for (int k = 0; k < 4; ++k) memcpy(x + (size_t)k * n, hx + C * k, sizeof(double) * (size_t)n);
+    f.used_x = true;
+    pc->spec_served[1] += 1;
+    return 1;
+}
+
+// triangulate_rectified(x, param) of that x with the parameters of the last call: X is there already.
+int plain_try_triangulate(viso_ctx* c, const double* x, int m, const viso_param* p, double* X) {
+    PlainCache* pc = c->plain;
+    if (!pc) return 0;
+    pc->tri_p = *p; pc->tri_known = true;
+    if (!pc->speculate) return 0;
+    PlainFrame& f = pc->frame[pc->cur];
+    if (!f.valid || !f.have_xX || f.m[0] != m || m <= 0 || !tri_equal(*p, f.tri_p)) return 0;
+    const size_t C = (size_t)(f.cap > 0 ? f.cap : 1);
+    const double* hx = reinterpret_cast<const double*>(f.host + (f.o_x - f.o_misc));
+    for (int k = 0; k < 4; ++k)
+        if (memcmp(hx + C * k, x + (size_t)k * m, sizeof(double) * (size_t)m) != 0) return 0;
+    const double* hX = reinterpret_cast<const double*>(f.host + (f.o_X - f.o_misc));
+    for (int k = 0; k < 3; ++k) memcpy(X + (size_t)k * m, hX + C * k, sizeof(double) * (size_t)m);
+    f.used_X = true;
+    pc->spec_served[2] += 1;
+    return 1;
+}
+
+static bool rows_equal(const int* a, const int32_t* b, int n) { return n == 0 || memcmp(a, b, sizeof(int) * 3 * (size_t)n) == 0; }
+
+// match_circle(match_lr, match_lr_prev, match11, match22) of the frame's own four lists: joined already.
+int plain_try_circle(viso_ctx* c, const int32_t* lr, int n_lr, const int32_t* lr_prev, int n_lrp, const int32_t* m11, int n11,
+                     const int32_t* m22, int n22, int32_t* circ, int32_t* pcl, int cap, int* out_n, int* ret) {
+    PlainCache* pc = c->plain;
+    if (!pc || !pc->speculate) return 0;
+    PlainFrame& f = pc->frame[pc->cur];
+    PlainFrame& prv = pc->frame[pc->cur ^ 1];
+    if (!f.valid || !prv.valid || !f.have[0] || !prv.have[0] || f.m[0] != n_lr || prv.m[0] != n_lrp) return 0;
+    if (!rows_equal(frame_rows(f, 0), lr, n_lr) || !rows_equal(frame_rows(prv, 0), lr_prev, n_lrp)) return 0;
+    const bool full = f.have[1] && f.have[2] && f.m[1] == n11 && f.m[2] == n22 && rows_equal(frame_rows(f, 1), m11, n11) && rows_equal(frame_rows(f, 2), m22, n22);
+    if (f.have[1] && f.have[2] && !full) return 0;
+    pc->circ_pattern = true;   // the loop's call: the stereo lists of this frame and the last
+    if (!f.have_B || !full) return 0;
+    if (frame_wait_B(c, f) < 0) return 0;
+    const int cnt = f.n_circ;
+    if (cnt < 0 || cnt > f.cap) return 0;
+    const int w = cnt < cap ? cnt : cap;
+    const int* rows = reinterpret_cast<const int*>(f.host + (f.o_circ - f.o_misc));
+    for (int i = 0; i < w; ++i) {
+        circ[4 * i + 0] = rows[6 * i + 0]; circ[4 * i + 1] = rows[6 * i + 1]; circ[4 * i + 2] = rows[6 * i + 2]; circ[4 * i + 3] = rows[6 * i + 3];
+        pcl[2 * i + 0] = rows[6 * i + 4]; pcl[2 * i + 1] = rows[6 * i + 5];
+    }
+    *out_n = cnt;
+    f.used_circ = true;
+    pc->circ_seen_no = pc->frame_no; pc->circ_seen_cnt = cnt;
+    pc->spec_served[2] += 1;
+    *ret = VISO_OK;
+    if (cnt > cap) { viso_set_error("viso_match_circle: %d rows needed, cap %d", cnt, cap); *ret = VISO_ERR_ARG; }
+    return 1;
+}
+
+// match_circle took the direct path with `cnt` rows: remember it (the RANSAC call of the same frame is recognised by it)
+void plain_note_circle(viso_ctx* c, int cnt) {
+    PlainCache* pc = c->plain;
+    if (!pc) return;
+    pc->circ_seen_no = pc->frame_no; pc->circ_seen_cnt = cnt;
+}
+
+static bool rs_param_equal(const viso_param& a, const viso_param& b) {   // every field the solver reads, bit for bit
+    return tri_equal(a, b) && a.ransac_iter == b.ransac_iter && memcmp(&a.inlier_threshold, &b.inlier_threshold, 8) == 0 &&
+           memcmp(&a.thresh, &b.thresh, 8) == 0;
+}
+
+// ransac_minimize_reproj on the gathered columns of that join, with the parameters and the stream key that were expected.
+int plain_try_ransac(viso_ctx* c, const double* X, const double* obs, int m, double best_tr[6], int32_t* best_inl, int* n_inl,
+                     const viso_param* p, const int32_t* samples, uint64_t seed, uint64_t frame, int* ret) {
+    PlainCache* pc = c->plain;
+    if (!pc) return 0;
+    PlainFrame& f = pc->frame[pc->cur];
+    bool served = false;
+    if (pc->speculate && !samples && f.valid && f.have_B && rs_param_equal(*p, f.rs_p) && seed == f.rs_seed && frame == f.rs_frame &&
+        frame_wait_B(c, f) >= 0 && f.n_circ == m && m >= 3 && m <= f.cap) {
+        const size_t C = (size_t)(f.cap > 0 ? f.cap : 1);
+        const double* hXp = reinterpret_cast<const double*>(f.host + (f.o_Xpc - f.o_misc));
+        const double* hxc = reinterpret_cast<const double*>(f.host + (f.o_xc - f.o_misc));
+        bool same = true;
+        for (int k = 0; k < 3 && same; ++k) same = memcmp(hXp + C * k, X + (size_t)k * m, sizeof(double) * (size_t)m) == 0;
+        for (int k = 0; k < 4 && same; ++k) same = memcmp(hxc + C * k, obs + (size_t)k * m, sizeof(double) * (size_t)m) == 0;
+        const int* rso = reinterpret_cast<const int*>(f.host + (f.o_rs - f.o_misc));
+        if (same && rso[2] >= 0 && rso[2] <= m) {
+            memcpy(best_tr, f.host + (f.o_rs - f.o_misc) + 64, sizeof(double) * 6);
+            *n_inl = rso[2];
+            if (rso[2] > 0) memcpy(best_inl, f.host + (f.o_rs - f.o_misc) + 128, sizeof(int) * (size_t)rso[2]);
+            *ret = rso[1] ? 1 : 0;
+            f.used_rs = true;
+            pc->spec_served[3] += 1;
+            served = true;
+        }
+    }
+    if (!samples) {   // what the next frame's call is expected to look like
+        const uint64_t d = frame - pc->rs_last_frame;
+        pc->rs_delta_stable = pc->rs_known && d == pc->rs_delta;
+        pc->rs_delta = d; pc->rs_last_frame = frame; pc->rs_seed = seed; pc->rs_p = *p; pc->rs_known = true;
+        if (served || (pc->circ_seen_no == pc->frame_no && pc->circ_seen_cnt == m)) pc->rs_pattern = true;
+    }
+    return served ? 1 : 0;
 }

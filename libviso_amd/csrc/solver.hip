@@ -946,6 +946,10 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     if (!c) return VISO_ERR_HIP;
     HIP_TRY(hipSetDevice(c->device));
     PlainProf pp(VISO_PLAIN_RANSAC, c->stream);
+    {   // the frame's stereo call may have solved exactly this problem already (plain.hip)
+        int ret = 0;
+        if (plain_try_ransac(c, X, obs, m, best_tr, best_inl, n_inl, p, samples, seed, frame, &ret)) return ret;
+    }
     int r;
     // ONE upload: X | obs | samples | {m} | the item; ONE read-back: {-, ok, n_inl} | tr[6] | inliers[m]
     PlainStage in;

@@ -16,6 +16,7 @@ try: libviso_amd.load().viso_plain_trace_dump()
 except Exception as e: print(e)
 print("frames", o["frames"], "loop_s", o["loop_s"], "fps", (o["frames"]-1)/o["loop_s"], "carry_s", o["carry_s"])
 for k,(c,us) in o["calls"].items(): print(f"  {k:28s} calls {c:5d}  {us/c:9.1f} us/call  {us/(o['frames']-1):9.1f} us/frame")
+st=(ctypes.c_int64*8)(); libviso_amd.load().viso_plain_speculate_stats(st); print("speculation served (temporal, collect, tri/circle, ransac):", list(st)[:4], "wasted:", list(st)[4:])
 drop_in.plain_profile(True)
 o2 = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=1)
 drop_in.plain_profile(False)
