@@ -220,7 +220,7 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
                        const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible = 1, int kinds = VISO_KIND_ALL);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 6
-int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max);
+int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty = 0);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);
 

@@ -999,7 +999,7 @@ int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int 
 // trips instead of the 66 stages of a 2048-key bitonic network.  Distances piled into one bucket (all equal, say)
 // would make the counting quadratic: such problems (and those beyond VISO_SORT_FAST_MAX keys) take the network.
 __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const MatchProblem* probs,
-                                                                         int n_probs, int npad_alloc, int fast) {
+                                                                         int n_probs, int npad_alloc, int fast, int flagged_empty) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_cnt;
@@ -1010,6 +1010,9 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     const int prob = blockIdx.x;
     if (prob >= n_probs) return;
     const MatchProblem P = probs[prob];
+    // a launch that left the general kernels out (plain.hip: every image so far fitted the u16 rows, the new ones are
+    // expected to) has NO results for a problem with a flagged image: an empty list, the host sees the flag and repeats
+    if (flagged_empty && (*P.q.bad | *P.t.bad) != 0) { if (threadIdx.x == 0) *P.m_cnt = 0; return; }
     const int n1 = *P.q.n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // compaction first: only the accepted queries carry a key (the ratio test rejects about half of the temporal ones)
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     }
 }
 
-int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max) {
+int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty) {
     if (n_probs <= 0) return VISO_OK;
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("match_desc: more than %d queries per call is not supported by this build", VISO_SORT_MAX);
@@ -1166,7 +1169,7 @@ int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int c
     const size_t lds = (size_t)npad * sizeof(unsigned long long) * (fast ? 2 : 1) + 16;   // keys (+ the keys in bucket order)
     if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_matches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS), lds, s, probs_dev, n_probs, npad, fast);
+    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS), lds, s, probs_dev, n_probs, npad, fast, flagged_empty);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -28,10 +28,13 @@
 
 // ---- helper threads for the two large host-side passes of a call ---------------------------------------------------
 // A miss copies the caller's 968 KB of descriptors into the slot's pinned shadow, a hit compares them with it.  One core
-// does that at 10-12 GB/s when the caller's array comes from DRAM (85 us: more than the upload and the kernels
-// together) and at 40-75 GB/s from its cache.  $VISO_PLAIN_THREADS helpers (default 3, 0 = none) take a slice each;
-// they spin for a few tens of microseconds after a job -- the next call of the frame is that close -- and sleep on a
-// condition variable otherwise.  Used under the PlainLock only.
+// does that at 10-16 GB/s when the caller's array comes from DRAM and at 40-75 GB/s from its cache.  $VISO_PLAIN_THREADS
+// helpers (default 0 = none) take a slice each; they spin for a few tens of microseconds after a job and sleep on a
+// condition variable otherwise.  OFF by default, measured (tools/dropin_probe.py, 201 frames): with three helpers the
+// copy into the shadow is no faster (the helpers sleep between frames, waking them costs what they save) and the CALLER's
+// next pass over the same array -- the loop's `d1.copyTo(d1_prev)`, src/viso.cpp:1213 -- goes from 30-40 to 65-130 us per
+// frame, because slices of it now sit in other cores' caches: 1290 against 1400 frames/s.  Kept for hosts whose arrays are
+// larger.  Used under the PlainLock only.
 struct PlainPool {
     std::vector<std::thread> th;
     std::mutex mu;
@@ -100,7 +103,7 @@ static struct PlainPoolReaper { ~PlainPoolReaper() { delete g_pool; g_pool = nul
 static PlainPool* plain_pool() {
     if (!g_pool_tried) {
         g_pool_tried = true;
-        int n = 3;
+        int n = 0;
         if (const char* e = getenv("VISO_PLAIN_THREADS")) n = atoi(e);
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && n > hw - 1) n = hw - 1;
@@ -132,10 +135,10 @@ struct PlainSlot {
     int n, dlen, extras, r8s;
     int bad_host;                   // ImageView::bad as the host knows it: 0 / 1, -1 = not read back yet
     unsigned long long stamp;       // LRU clock
-    char* pin; size_t pin_bytes;    // shadow of the caller's arrays, in upload layout: kp | desc | hdr
-    char* dev; size_t dev_bytes;    // kp | desc | hdr | rows | aux
-    size_t o_desc, up_bytes;
-    ImageView v;                    // device pointers into dev
+    char* pin; size_t pin_bytes;    // shadow of the caller's arrays: kp | hdr {n, bad, the ImageView} | desc
+    char* dev; size_t dev_bytes;    // kp | hdr | rows | aux          (the f32 rows stay in the shadow: see plain_acquire)
+    size_t o_desc, o_hdr;
+    ImageView v;                    // device pointers into dev (frows: the pinned shadow)
 };
 // ---- the frame a stereo call opens ----------------------------------------------------------------------------------
 // The reference's loop body is a fixed sequence (src/viso.cpp:1240-1313), and after the stereo call of frame t everything
@@ -188,6 +191,8 @@ struct PlainCache {
     unsigned long long frame_no, circ_seen_no; int circ_seen_cnt;
     bool rs_known, rs_pattern, rs_delta_stable;   // ransac's param / seed seen; the call fitted; the stream key advances regularly
     viso_param rs_p; uint64_t rs_seed, rs_last_frame, rs_delta;
+    int good_streak;                       // launches in a row whose images all fitted the u16 rows
+    long long general_reruns;
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
 
@@ -319,7 +324,7 @@ extern "C" void viso_plain_trace_dump(void) {
         for (int j = 0; j < 6; ++j) fprintf(stderr, "  %s %.1f", ph[j], g_tr_us[k][j] / g_tr_n[k]);
         fprintf(stderr, "  (us per call)\n");
     }
-    if (g_acq_n) fprintf(stderr, "uploads: %ld, copy into the shadow %.1f us, hipMemcpyAsync call %.1f us\n", g_acq_n, g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n);
+    if (g_acq_n) fprintf(stderr, "uploads: %ld, copy into the shadow %.1f us, sort_kp + pack launches %.1f us\n", g_acq_n, g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n);
     g_acq_us[0] = g_acq_us[1] = 0; g_acq_n = 0;
     memset(g_tr_us, 0, sizeof(g_tr_us)); memset(g_tr_n, 0, sizeof(g_tr_n));
 }
@@ -347,18 +352,27 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
         if (i != keep && (vi < 0 || pc->slot[i].stamp < pc->slot[vi].stamp)) vi = i;
     PlainSlot& s = pc->slot[vi];
     s.valid = false;
+    // The image comes to the device in two pieces.  Keypoints + header (16 KB) by a copy kernel.  The f32 descriptor rows
+    // (968 KB) are read ONCE, by pack_desc_kernel, which turns them into the u16 rows the matchers use: it reads them straight
+    // from the pinned shadow over PCIe -- no copy-engine transfer (25 us on the wire + 20 us of host time in
+    // hipMemcpyAsync per image, and every kernel of the call queued behind both) and no second copy of the rows in device
+    // memory.  sort_kp_kernel and pack_desc_kernel of THIS image are launched here, so the GPU works on it while the host
+    // copies the call's other image into its shadow.  (Only the general path reads f32 rows again -- images with non-integer
+    // descriptors -- and then from the shadow: slow, correct.)
     const size_t na = (size_t)(n > 0 ? n : 1);
-    const size_t o_desc = al256(sizeof(float2) * na), o_hdr = o_desc + al256(sizeof(float) * na * dlen);
-    const size_t up = o_hdr + PLAIN_HDR;
-    const size_t o_rows = up, o_aux = o_rows + al256(sizeof(uint16_t) * VISO_ROW * na);
+    const size_t o_hdr = al256(sizeof(float2) * na), o_desc = o_hdr + PLAIN_HDR;
+    const size_t pin_need = o_desc + al256(sizeof(float) * na * dlen);
+    const size_t o_rows = o_desc, o_aux = o_rows + al256(sizeof(uint16_t) * VISO_ROW * na);
     const size_t total = o_aux + al256(aux_bytes(na));
-    if (s.pin_bytes < up) {
+    if (s.pin_bytes < pin_need) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // a kernel of an earlier call may still read the old shadow
         if (s.pin) HIP_TRY(hipHostFree(s.pin));
         s.pin = nullptr; s.pin_bytes = 0;
-        HIP_TRY(hipHostMalloc((void**)&s.pin, up + up / 4, hipHostMallocDefault));
-        s.pin_bytes = up + up / 4;
+        HIP_TRY(hipHostMalloc((void**)&s.pin, pin_need + pin_need / 4, hipHostMallocDefault));
+        s.pin_bytes = pin_need + pin_need / 4;
     }
     if (s.dev_bytes < total) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
         if (s.dev) HIP_TRY(hipFree(s.dev));
         s.dev = nullptr; s.dev_bytes = 0;
         HIP_TRY(hipMalloc((void**)&s.dev, total + total / 4));
@@ -366,19 +380,9 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     }
     const double ta0 = g_tr_on > 0 ? tr_now() : 0;
     if (kb) memcpy(s.pin, kp, kb);
-    big_copy(s.pin + o_desc, d, db);
-    const double ta1 = g_tr_on > 0 ? tr_now() : 0;
-    int* hdr = reinterpret_cast<int*>(s.pin + o_hdr);
-    hdr[0] = n;
-    hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
-    HIP_TRY(hipMemcpyAsync(s.dev, s.pin, up, hipMemcpyHostToDevice, c->stream));
-    if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
-    s.n = n; s.dlen = dlen; s.extras = extras; s.r8s = r8s;
-    s.bad_host = dlen > VISO_ROW ? 1 : -1;
-    s.o_desc = o_desc; s.up_bytes = up;
     ImageView v{};
     v.kp = reinterpret_cast<const float2*>(s.dev);
-    v.frows = reinterpret_cast<const float*>(s.dev + o_desc);
+    v.frows = reinterpret_cast<const float*>(s.pin + o_desc);
     v.n = reinterpret_cast<const int*>(s.dev + o_hdr);
     v.bad = reinterpret_cast<int*>(s.dev + o_hdr) + 1;
     v.rows = reinterpret_cast<uint16_t*>(s.dev + o_rows);
@@ -392,6 +396,21 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     v.qord = (uint8_t*)(tail + ((4 * (VISO_NB + 1) + 32 + 15) / 16) * 16);
     v.sums = (uint2*)((unsigned char*)v.qord + ((na + 63) / 64) * 64);
     v.rows8 = (uint8_t*)v.sums + ((8 * na + 15) / 16) * 16;
+    int* hdr = reinterpret_cast<int*>(s.pin + o_hdr);
+    hdr[0] = n;
+    hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
+    memcpy(s.pin + o_hdr + 64, &v, sizeof(v));   // the image's view, where sort_kp_kernel / pack_desc_kernel find it
+    int r = plain_blit(c->stream, s.pin, s.dev, o_desc / 4);
+    if (r < 0) return r;
+    big_copy(s.pin + o_desc, d, db);
+    const double ta1 = g_tr_on > 0 ? tr_now() : 0;
+    const ImageView* dview = reinterpret_cast<const ImageView*>(s.dev + o_hdr + 64);
+    if ((r = launch_sort_kp(c->stream, dview, 1, n > 0 ? n : 1)) < 0) return r;
+    if (dlen <= VISO_ROW && (r = launch_pack(c->stream, dview, 1, n > 0 ? n : 1, dlen, nullptr, const_cast<int*>(v.bad), extras, r8s, nullptr)) < 0) return r;
+    if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
+    s.n = n; s.dlen = dlen; s.extras = extras; s.r8s = r8s;
+    s.bad_host = dlen > VISO_ROW ? 1 : -1;
+    s.o_desc = o_desc; s.o_hdr = o_hdr;
     s.v = v;
     s.stamp = ++pc->clock;
     s.valid = true;
@@ -419,7 +438,7 @@ static bool tri_equal(const viso_param& a, const viso_param& b) {   // the field
     return memcmp(&a.base, &b.base, 8) == 0 && memcmp(&a.f, &b.f, 8) == 0 && memcmp(&a.cu, &b.cu, 8) == 0 && memcmp(&a.cv, &b.cv, 8) == 0;
 }
 
-struct FrameHead { MatchProblem p[PF_PROBS]; ImageView miss[2]; TriItem tri; SolverItem rs; };
+struct FrameHead { MatchProblem p[PF_PROBS]; TriItem tri; SolverItem rs; };
 
 // x_c / Xp_c of src/viso.cpp:1292-1305: columns of x (this frame) and of the previous frame's X picked by match_pcl
 __global__ __launch_bounds__(256) void plain_gather_kernel(const int* __restrict__ rows, const int* __restrict__ cnt, int cap,
@@ -501,6 +520,11 @@ static void frame_retire(PlainCache* pc, PlainFrame& f) {
 
 static const int* frame_rows(const PlainFrame& f, int p) { return reinterpret_cast<const int*>(f.host + (f.o_sorted[p] - f.o_misc)); }
 
+#define PLAIN_RERUN 2
+static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it, bool hit_q, bool hit_t, int n1, int n2, int dlen,
+                     const viso_match_params* mp, int variant, int extras, int r8s, int32_t* out_match, int* out_n,
+                     bool force_general, double* tt);
+
 // match_desc, reference src/viso.cpp:669-726.
 extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n2,
                                const float* d1, const float* d2, int dlen,
@@ -561,6 +585,29 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         if (cur.valid && prv.valid && ((iq == cur.L && it == prv.L && pc->slot[it].stamp == prv.sL) ||
                                        (iq == cur.R && it == prv.R && pc->slot[it].stamp == prv.sR))) pc->tm_pattern = true;
     }
+    for (int pass = 0; pass < 2; ++pass) {   // second pass: an image nobody expected turned out not to fit the u16 rows
+        r = match_run(c, pc, pp, iq, it, hit_q, hit_t, n1, n2, dlen, mp, variant, extras, r8s, out_match, out_n, pass == 1, tt);
+        if (r != PLAIN_RERUN) break;
+    }
+    if (r < 0) return r;
+    if (g_tr_on) {
+        tt[6] = tr_now();
+        const int k = (hit_q ? 0 : 1) + (hit_t ? 0 : 1);
+        for (int j = 0; j < 6; ++j) g_tr_us[k][j] += tt[j + 1] - tt[j];
+        g_tr_n[k] += 1;
+    }
+    return VISO_OK;
+}
+
+static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it, bool hit_q, bool hit_t, int n1, int n2, int dlen,
+                     const viso_match_params* mp, int variant, int extras, int r8s, int32_t* out_match, int* out_n,
+                     bool force_general, double* tt) {
+    hipStream_t s = c->stream;
+    int r;
+    (void)n2; (void)hit_q; (void)hit_t;
+    const bool stereo_call = mp->enforce_epipolar != 0;
+    const int saved_cur = pc->cur;
+    const unsigned long long saved_no = pc->frame_no;
     // ---- which frame object takes the call, and which problems ride along
     PlainFrame* f = &pc->frame[2];
     int np = 1;
@@ -607,11 +654,21 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     // [8] tiles match_stereo_kernel declines (BatchMatchArgs::bad[1])  [16 + 4p] matches of problem p, [18 + 4p] its scored pairs (u64)
     char* sc = f->dev + f->o_end;
     int2* dovf = reinterpret_cast<int2*>(sc + PF_PROBS * (al256(sizeof(int2) * C) + al256(sizeof(int) * C) + al256(sizeof(int) * (C / 64 + 1))));
-    bool all_good = true;
-    int n_miss = 0, cap_miss = 1;
+    // The general (float / double) kernels are for images whose descriptors do not fit the u16 rows.  Whether a NEW image
+    // does is known only after its pack kernel has run; once a few launches in a row have seen none, new images are expected
+    // to fit and the three general kernels are left out of the launch (15 us of the chain).  If the expectation fails
+    // -- the images' own flags come back with the results -- sort_matches_kernel has emitted EMPTY lists for the problems
+    // concerned (flagged_empty) and the call is repeated with the general kernels: same results, later.
+    bool any_bad = false, any_unknown = false;
     for (int p = 0; p < np; ++p) {
         PlainSlot &a = pc->slot[f->tq[p]], &b = pc->slot[f->tt[p]];
-        if (a.bad_host != 0 || b.bad_host != 0) all_good = false;
+        if (a.bad_host == 1 || b.bad_host == 1) any_bad = true;
+        if (a.bad_host < 0 || b.bad_host < 0) any_unknown = true;
+    }
+    const bool trust = pc->good_streak >= 2 && !force_general;
+    const bool need_general = any_bad || (any_unknown && !trust) || dlen > VISO_ROW;
+    for (int p = 0; p < np; ++p) {
+        PlainSlot &a = pc->slot[f->tq[p]], &b = pc->slot[f->tt[p]];
         MatchProblem P{};
         P.q = a.v; P.t = b.v;
         char* ps = sc + p * (al256(sizeof(int2) * C) + al256(sizeof(int) * C) + al256(sizeof(int) * (C / 64 + 1)));
@@ -624,10 +681,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         P.ovf = dovf; P.ovf_cnt = dmisc + 6;
         H->p[p] = P;
     }
-    // a resident image whose flag the host has not seen yet may be flagged: say so, the kernels look at the image's own flag
-    if ((hit_q && sq.bad_host != 0) || (hit_t && st.bad_host != 0) || dlen > VISO_ROW || (np == 3 && !all_good)) hmisc[7] = 1;
-    if (!hit_q) { H->miss[n_miss++] = sq.v; cap_miss = n1 > cap_miss ? n1 : cap_miss; }
-    if (!hit_t && it != iq) { H->miss[n_miss++] = st.v; cap_miss = n2 > cap_miss ? n2 : cap_miss; }
+    if (need_general) hmisc[7] = 1;   // the general kernels' early-exit hint; they look at every image's own flag
     if (spec_x) {
         TriItem T{};
         T.kp1 = sq.v.kp; T.kp2 = st.v.kp; T.match = reinterpret_cast<const int*>(f->dev + f->o_sorted[0]); T.m_cnt = dmisc + 16;
@@ -660,19 +714,14 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     pp.mark(1);
     if (g_tr_on) tt[3] = tr_now();
     const MatchProblem* dprob = reinterpret_cast<const MatchProblem*>(f->dev);
-    const ImageView* dmiss = reinterpret_cast<const ImageView*>(f->dev + offsetof(FrameHead, miss));
-    if (n_miss) {
-        if ((r = launch_sort_kp(s, dmiss, n_miss, cap_miss)) < 0) return r;
-        if (dlen <= VISO_ROW && (r = launch_pack(s, dmiss, n_miss, cap_miss, dlen, nullptr, dmisc + 7, extras, r8s, nullptr)) < 0) return r;
-    }
     MatchParamsDev mpd[2];
     fill_match_params(&mpd[0], mp);
     if (np == 3) fill_match_params(&mpd[1], &pc->tm); else mpd[1] = mpd[0];
-    const int general_possible = !all_good;
+    const int general_possible = need_general ? 1 : 0;
     const int kinds = np == 3 ? VISO_KIND_ALL : mpd[0].epi ? VISO_KIND_STEREO : VISO_KIND_TEMPORAL;
     if ((r = launch_match_timed(s, dprob, np, cap, dlen, mpd, dmisc + 7, nullptr, nullptr, 0, variant, dovf, dmisc + 6, r8s,
                                 general_possible, kinds)) < 0) return r;
-    if ((r = launch_sort(s, dprob, np, cap)) < 0) return r;
+    if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1)) < 0) return r;
     if (spec_x) {
         SolverParamsDev sp;
         fill_solver_params(&sp, &pc->tri_p);
@@ -689,7 +738,13 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
             oa.r[nr].cnt = cnt; oa.r[nr].row_words = row_words; oa.r[nr].max_rows = max_rows;
             ++nr;
         };
-        region(f->o_misc, nullptr, 64, 1);
+        region(f->o_misc, nullptr, 40, 1);
+        {   // the two images' own flags: words 40, 41 of the mirror
+            oa.r[nr].src = reinterpret_cast<const uint32_t*>(sq.v.bad); oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host) + 40;
+            oa.r[nr].cnt = nullptr; oa.r[nr].row_words = 1; oa.r[nr].max_rows = 1; ++nr;
+            oa.r[nr].src = reinterpret_cast<const uint32_t*>(st.v.bad); oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host) + 41;
+            oa.r[nr].cnt = nullptr; oa.r[nr].row_words = 1; oa.r[nr].max_rows = 1; ++nr;
+        }
         for (int p = 0; p < np; ++p) region(f->o_sorted[p], dmisc + 16 + 4 * p, 3, f->nq[p]);
         if (spec_x) {
             for (int k = 0; k < 4; ++k) region(f->o_x + sizeof(double) * C * k, dmisc + 16, 2, n1);
@@ -727,7 +782,7 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
             ob.r[nr].cnt = cnt; ob.r[nr].row_words = row_words; ob.r[nr].max_rows = max_rows;
             ++nr;
         };
-        region(f->o_misc + 128, nullptr, 16, 1);                         // misc[32..47]: the join's row count
+        region(f->o_misc + 128, nullptr, 8, 1);                          // misc[32..39]: the join's row count
         region(f->o_circ, dmisc + 32, 6, cap);
         for (int k = 0; k < 4; ++k) region(f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
         for (int k = 0; k < 3; ++k) region(f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
@@ -749,18 +804,24 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
         if (m < 0 || m > f->nq[p]) { frame_reset(*f); viso_set_error("viso_match_desc: device returned %d matches for %d queries", m, f->nq[p]); return VISO_ERR_HIP; }
         f->m[p] = m;
     }
-    if (omisc[7] == 0)   // no image of this launch is flagged: all of them fit the u16 rows
-        for (int p = 0; p < np; ++p) { pc->slot[f->tq[p]].bad_host = 0; pc->slot[f->tt[p]].bad_host = 0; }
+    sq.bad_host = omisc[40] != 0; st.bad_host = omisc[41] != 0;   // the images' own flags, as their pack kernels left them
+    if (sq.bad_host || st.bad_host) {
+        pc->good_streak = 0;
+        if (!need_general) {   // unexpected: the launch had no kernel for them.  Everything it produced is dropped, the call repeated
+            HIP_TRY(hipStreamSynchronize(s));
+            f->pending_B = false;
+            frame_reset(*f);
+            pc->cur = saved_cur; pc->frame_no = saved_no;
+            pc->general_reruns += 1;
+            return PLAIN_RERUN;
+        }
+    } else {
+        pc->good_streak += 1;
+    }
     const int m = f->m[0];
     if (m > 0) memcpy(out_match, frame_rows(*f, 0), sizeof(int) * 3 * (size_t)m);
     f->valid = stereo_call && pc->speculate;
     f->have_xX = spec_x; f->tri_p = pc->tri_p;
-    if (g_tr_on) {
-        tt[6] = tr_now();
-        const int k = (hit_q ? 0 : 1) + (hit_t ? 0 : 1);
-        for (int j = 0; j < 6; ++j) g_tr_us[k][j] += tt[j + 1] - tt[j];
-        g_tr_n[k] += 1;
-    }
     *out_n = m;
     return VISO_OK;
 }
