@@ -247,6 +247,8 @@ def main():
                          "per frame to paint; 512 like the other legs: +16 %% / +6 %%)")
     ap.add_argument("--e2e-streams", type=int, default=5,
                     help="batches in flight for the end-to-end leg (each adds a RANSAC stream of its own: 5 measured +1.3 %% over 3; 0 = --streams)")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the per-call drop-in leg (the plain C-ABI, one reference function per call)")
+    ap.add_argument("--drop-in-frames", type=int, default=256, help="frame pairs of the per-call drop-in leg")
     ap.add_argument("--ab-variants", default="", help="matcher variants timed by --ab (default: all of the build)")
     ap.add_argument("--ab", action="store_true", help="also time the other matcher variants, interleaved, same process")
     args = ap.parse_args()
@@ -610,6 +612,70 @@ def main():
                                    "what": "viso_batch_upload (pageable host memory, 2 frames) + viso_batch_run + viso_batch_get_poses of a "
                                            "1-pair batch, wall time per call sequence; the oracle needs ~35 ms for the same frame on one core"}
 
+    # ---- the LITERAL drop-in path: the reference's loop calling the plain C-ABI one function per call ----------
+    # (viso::sequence_odometry_per_call, libviso_amd/host: src/viso.cpp:1205-1327 with match_desc x3, collect_matches,
+    # triangulate_rectified, match_circle, ransac_minimize_reproj per frame, host pointers in, host results out, the
+    # copyTo carry-over of :1208-1222 -- what an unchanged kitti.cpp gets from adapters/libviso_hip.patch).  One frame at a
+    # time, synchronous: a latency figure per GPU, not a throughput one.
+    drop = None
+    if not args.no_e2e and not args.no_drop_in:
+        from libviso_amd import drop_in
+        nd = min(nf, args.drop_in_frames + 1)
+        dk, dd, dn = seq["kp"][:nd], seq["desc"][:nd], seq["n"][:nd]
+        sync_all()
+
+        def loop(cache=True, speculate=True, profile=False, want_matches=False):
+            drop_in.plain_cache(cache)
+            drop_in.plain_speculate(speculate)
+            drop_in.run(dk[:12], dd[:12], dn[:12], seq["F"], seq["param"], seed=1, first_frame=rank * args.frames)   # warm-up, pattern learnt afresh below
+            if profile:
+                drop_in.plain_profile(True)
+            o = drop_in.run(dk, dd, dn, seq["F"], seq["param"], seed=1, first_frame=rank * args.frames, want_matches=want_matches)
+            rows = None
+            if profile:
+                drop_in.plain_profile(False)
+                rows = drop_in.plain_profile_rows()
+            return o, rows
+
+        def per_call(o):
+            return {k: {"calls": c, "us_per_call": us / c, "us_per_frame": us / (o["frames"] - 1)} for k, (c, us) in o["calls"].items()}
+        o_best = None
+        fps_runs = []
+        for _ in range(3):
+            o, _r = loop()
+            fps_runs.append((o["frames"] - 1) / o["loop_s"])
+            if o_best is None or o["loop_s"] < o_best["loop_s"]:
+                o_best = o
+        o_dir, _r = loop(speculate=False)
+        _o, rows_dir = loop(speculate=False, profile=True)
+        o_nc, _r = loop(cache=False, speculate=False)
+        o_chk, _r = loop(want_matches=True)
+        drop_in.plain_cache(True)
+        drop_in.plain_speculate(True)
+        st_plain = drop_in.plain_stats()
+        tr_b, ok_b, inl_b = batch.poses()
+        same = bool(np.array_equal(o_chk["ok"], ok_b[:nd]) and np.array_equal(o_chk["n_inl"][ok_b[:nd] == 1], inl_b[:nd][ok_b[:nd] == 1])
+                    and all(np.array_equal(o_chk["matches"][w][t], batch.matches(w, t)) for w in range(3) for t in range(1 if w else 0, min(nd, 24))))
+        tr_err = float(np.abs(o_chk["tr"][ok_b[:nd] == 1] - tr_b[:nd][ok_b[:nd] == 1]).max()) if ok_b[:nd].any() else None
+        drop = {"fps": float(np.median(fps_runs)), "fps_runs": fps_runs, "frames": int(o_best["frames"]), "unit": "frames/s (one process, one GPU, one frame at a time)",
+                "ms_per_frame": o_best["loop_s"] / (o_best["frames"] - 1) * 1e3,
+                "workload": "configs[2] frames through viso::sequence_odometry_per_call (C++): per frame match_desc x3, collect_matches, "
+                            "triangulate_rectified, match_circle, ransac_minimize_reproj on the plain (host-pointer) C-ABI, in the order of "
+                            "src/viso.cpp:1240-1313, with the copyTo carry-over of :1208-1222; pageable host buffers in, host results out",
+                "per_call_wall": per_call(o_best),
+                "carry_over_us_per_frame": o_best["carry_s"] / (o_best["frames"] - 1) * 1e6,
+                "every_call_direct": {"fps": (o_dir["frames"] - 1) / o_dir["loop_s"], "per_call_wall": per_call(o_dir),
+                                      "per_call_gpu_us": {k: {kk: (vv / v["calls"] if kk != "calls" else vv) for kk, vv in v.items()} for k, v in rows_dir.items()},
+                                      "note": "viso_plain_speculate(0): every call does its own work (image cache on); per_call_gpu_us = hipEvent "
+                                              "brackets of the phases (viso_plain_profile): h2d = inputs, kernel, d2h = results, wait = host blocked, host = the call"},
+                "every_call_direct_no_image_cache": {"fps": (o_nc["frames"] - 1) / o_nc["loop_s"], "per_call_wall": per_call(o_nc)},
+                "equals_batch_family": same, "max_abs_tr_diff_vs_batch_family": tr_err,
+                "plain_family_stats": st_plain,
+                "bound": "one frame = one unavoidable round trip (the stereo call: 2 x 0.98 MB of descriptors from pageable memory into a pinned "
+                         "shadow, then pulled over PCIe by the pack kernel) + a dependent chain of ~20 small kernels (sort, pack, 3 match_desc problems, "
+                         "sorts, join, RANSAC/GN) of ~350 us on an otherwise idle GPU; the later calls of the frame compare their arguments with what "
+                         "the stereo call assumed (memcmp) and return"}
+
     # ---- streaming: every step consumes fresh host frames (pinned, asynchronous, stream ordered) -------------
     # sequence_odometry reads new images every frame (src/viso.cpp:1205-1231); the resident figures above never
     # touch PCIe.  Two different host sequences (the batch's and its time reversal: other pairs, other poses)
@@ -773,6 +839,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "drop_in_per_call": drop,
             "collective": collective,
             "streaming": streaming,
             "end_to_end_from_images": e2e_img,

@@ -227,6 +227,29 @@ typedef struct viso_plain_times {
     int64_t calls;
     double host_us, h2d_us, kernel_us, d2h_us, wait_us;
 } viso_plain_times;
+/* What the plain family does behind one function per call (libviso_amd/csrc/plain.hip; DESIGN.md "the drop-in path"):
+ *   image cache    match_desc recognises an image it has been given before -- the loop passes every (keypoints,
+ *                  descriptors) set three times, under changing addresses (`d1.copyTo(d1_prev)`, src/viso.cpp:1213) -- by
+ *                  comparing its bytes with a pinned host shadow (memcmp: exact), and then neither uploads nor sorts nor
+ *                  packs it again.  viso_plain_cache(0) / $VISO_PLAIN_CACHE=0: every image uploaded again.
+ *   frames         the stereo call of a frame (enforce_epipolar != 0) also runs what the loop asks for next: the two
+ *                  temporal match_desc problems against the previous stereo call's images, collect_matches /
+ *                  triangulate_rectified of its own matches, match_circle of the four lists, the gather of :1292-1305
+ *                  and ransac_minimize_reproj with the parameters and stream key of the previous frame's call (key
+ *                  advanced by its last step).  A later call is answered from those results ONLY if its arguments are
+ *                  byte for byte what was assumed (the functions are pure: same results as the direct path, which any
+ *                  other argument takes).  Guessing starts after the call sequence has been seen once and stops when a
+ *                  guess goes unused.  viso_plain_speculate(0) / $VISO_PLAIN_SPECULATE=0: every call direct.
+ * Both only change when the work is done, never a result (tests/test_gpu_drop_in.py runs every combination).  The
+ * speculation statistics: served[0..3] = calls answered from a frame (temporal match_desc, collect_matches,
+ * triangulate_rectified + match_circle, ransac_minimize_reproj), wasted[0..3] = results computed ahead and never asked for. */
+int viso_plain_cache(int enable);
+int viso_plain_cache_stats(int64_t* hits, int64_t* misses);
+int64_t viso_plain_general_reruns(void);   /* calls repeated because an image unexpectedly did not fit the u16 rows */
+int viso_plain_speculate(int enable);
+int viso_plain_speculate_stats(int64_t served_wasted[8]);
+/* $VISO_PLAIN_TRACE=1: host microseconds of viso_match_desc by phase; this prints and zeroes them (stderr). */
+void viso_plain_trace_dump(void);
 int viso_plain_profile(int enable);                        /* 1: zero the sums and start; 0: stop */
 int viso_plain_profile_get(int fn, viso_plain_times* out); /* fn: VISO_PLAIN_* */
 const char* viso_plain_profile_name(int fn);

@@ -298,6 +298,14 @@ extern "C" int viso_plain_speculate_stats(int64_t out[8]) {
     return VISO_OK;
 }
 
+// launches that left the general kernels out and had to be repeated with them (an image that does not fit the u16 rows
+// where none was expected)
+extern "C" int64_t viso_plain_general_reruns(void) {
+    PlainLock lk;
+    viso_ctx* c = viso_default_ctx();
+    return c && c->plain ? c->plain->general_reruns : 0;
+}
+
 extern "C" int viso_plain_cache_stats(int64_t* hits, int64_t* misses) {
     PlainLock lk;
     viso_ctx* c = viso_default_ctx();

@@ -82,3 +82,30 @@ def run(kp, desc, n, F, param, seed=0, first_frame=0, want_matches=False):
     if want_matches:
         out["matches"] = [[m[w, t, :mn[w, t]].copy() for t in range(nf)] for w in range(3)]
     return out
+
+
+def plain_cache(enable):
+    """viso_plain_cache: the plain family's image cache on / off (off: every image uploaded, sorted and packed again)."""
+    r = load().viso_plain_cache(1 if enable else 0)
+    if r != 1:
+        raise RuntimeError(f"viso_plain_cache failed with {r}")
+
+
+def plain_speculate(enable):
+    """viso_plain_speculate: a frame's stereo call also runs what the loop asks for next (on), or every call direct (off)."""
+    r = load().viso_plain_speculate(1 if enable else 0)
+    if r != 1:
+        raise RuntimeError(f"viso_plain_speculate failed with {r}")
+
+
+def plain_stats():
+    """dict(hits, misses, served [4], wasted [4], general_reruns) of the plain family's cache / frames."""
+    L = load()
+    L.viso_plain_cache_stats.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.viso_plain_general_reruns.restype = C.c_int64
+    h, m = C.c_int64(0), C.c_int64(0)
+    L.viso_plain_cache_stats(C.byref(h), C.byref(m))
+    st = (C.c_int64 * 8)()
+    L.viso_plain_speculate_stats(st)
+    return {"hits": h.value, "misses": m.value, "served": list(st)[:4], "wasted": list(st)[4:],
+            "general_reruns": int(L.viso_plain_general_reruns())}

@@ -1,0 +1,221 @@
+"""The literal drop-in flow: the reference's sequence_odometry loop (src/viso.cpp:1205-1327) calling the plain C-ABI one
+function at a time, in C++ (`viso::sequence_odometry_per_call` through libviso_host.so).  It must give what the batch
+family and the oracle give on the same frames, whatever the plain family does behind the calls (image cache,
+computing a frame's later calls ahead): those only move work, never a result -- every combination is run."""
+import numpy as np
+import pytest
+
+import libviso_amd
+from libviso_amd import drop_in, synth
+from libviso_amd.abi import MatchParams
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5
+
+
+def rel_fro(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def seq():
+    return synth.make_sequence(77, 14, n_kp=500, width=620, height=188, ragged=True)
+
+
+@pytest.fixture(autouse=True)
+def _defaults_back():
+    yield
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(True)
+
+
+def batch_results(seq):
+    nf, cap = seq["kp"].shape[0], seq["kp"].shape[2]
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, nf, cap)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.set_params(st, tm, seq["param"], seed=5, first_frame=100)
+    b.run()
+    tr, ok, n_inl = b.poses()
+    m = [[b.matches(w, t) for t in range(nf)] for w in range(3)]
+    circ = [b.circle(t)[0] if t else np.zeros((0, 4), np.int32) for t in range(nf)]
+    b.close(); ctx.close()
+    return tr, ok, n_inl, m, circ
+
+
+@pytest.mark.parametrize("cache,speculate", [(True, True), (True, False), (False, False), (False, True)])
+def test_per_call_loop_equals_batch_family(viso, seq, cache, speculate):
+    drop_in.plain_cache(cache)
+    drop_in.plain_speculate(speculate)
+    before = drop_in.plain_stats()
+    o = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=5, first_frame=100, want_matches=True)
+    after = drop_in.plain_stats()
+    tr, ok, n_inl, m, circ = batch_results(seq)
+    nf = seq["kp"].shape[0]
+    assert o["frames"] == nf
+    for t in range(nf):
+        assert np.array_equal(o["matches"][0][t], m[0][t]), f"stereo matches of frame {t}"
+        if t:
+            assert np.array_equal(o["matches"][1][t], m[1][t]), f"temporal-left matches of frame {t}"
+            assert np.array_equal(o["matches"][2][t], m[2][t]), f"temporal-right matches of frame {t}"
+            assert o["n_circle"][t] == len(circ[t])
+    assert np.array_equal(o["ok"], ok) and ok[1:].sum() >= nf - 3
+    assert np.array_equal(o["n_inl"][ok == 1], n_inl[ok == 1])
+    for t in range(1, nf):
+        if ok[t]:
+            assert rel_fro(libviso_amd.tr2mat(o["tr"][t]), libviso_amd.tr2mat(tr[t])) < POSE_TOL
+    served = [a - b for a, b in zip(after["served"], before["served"])]
+    if speculate and cache:     # the loop is recognised within a few frames, then every later call comes from the frame
+        assert served[0] >= 2 * (nf - 6) and served[1] >= nf - 4 and served[3] >= nf - 8, served
+    if not speculate:
+        assert served == [0, 0, 0, 0]
+    if cache:                   # every image crosses PCIe once
+        assert after["misses"] - before["misses"] == 2 * nf
+
+
+def test_per_call_loop_equals_oracle(viso, oracle, seq):
+    o = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=5, first_frame=100, want_matches=True)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=5, first_frame=100)
+    assert np.array_equal(o["ok"], want["ok"]) and np.array_equal(o["n_inl"], want["n_inl"])
+    for t in range(1, seq["kp"].shape[0]):
+        if want["ok"][t]:
+            assert rel_fro(libviso_amd.tr2mat(o["tr"][t]), oracle.tr2mat(want["tr"][t])) < POSE_TOL
+        n1, p1 = seq["n"][t, 0], seq["n"][t - 1, 0]
+        m_cpu = oracle.match_desc(seq["kp"][t, 0, :n1], seq["kp"][t - 1, 0, :p1], seq["desc"][t, 0, :n1], seq["desc"][t - 1, 0, :p1], tm)
+        assert np.array_equal(o["matches"][1][t], m_cpu)
+
+
+def _loop_frame(seq, t, st, tm, state, seed=5):
+    """One iteration of the reference's loop body through the Python wrappers of the plain family; returns its products."""
+    nL, nR = seq["n"][t]
+    kp1, kp2 = seq["kp"][t, 0, :nL].copy(), seq["kp"][t, 1, :nR].copy()
+    d1, d2 = seq["desc"][t, 0, :nL].copy(), seq["desc"][t, 1, :nR].copy()
+    lr = libviso_amd.match_desc(kp1, kp2, d1, d2, st)
+    x = libviso_amd.collect_matches(kp1, kp2, lr)
+    X = libviso_amd.triangulate_rectified(x, seq["param"])
+    out = {"kp1": kp1, "kp2": kp2, "d1": d1, "d2": d2, "lr": lr, "x": x, "X": X}
+    if state is not None:
+        m11 = libviso_amd.match_desc(kp1, state["kp1"].copy(), d1, state["d1"].copy(), tm)
+        m22 = libviso_amd.match_desc(kp2, state["kp2"].copy(), d2, state["d2"].copy(), tm)
+        _, circ, pcl, n = libviso_amd.match_circle(lr, state["lr"], m11, m22)
+        out.update(m11=m11, m22=m22, circ=circ, pcl=pcl)
+        if n >= 3:
+            x_c, Xp_c = np.ascontiguousarray(x[:, pcl[:, 0]]), np.ascontiguousarray(state["X"][:, pcl[:, 1]])
+            out["rs"] = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=seed, frame=t)
+            out.update(x_c=x_c, Xp_c=Xp_c)
+    return out
+
+
+def test_calls_that_are_not_the_loops_take_the_direct_path(viso, oracle, seq):
+    """After the loop has been recognised, calls whose arguments differ from what a frame computed ahead -- one descriptor,
+    one match row, another parameter, another stream key -- must get THEIR results (the oracle's), not the frame's."""
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(True)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    state = None
+    for t in range(8):
+        state = _loop_frame(seq, t, st, tm, state)
+    s0 = drop_in.plain_stats()
+    assert s0["served"][0] > 0 and s0["served"][1] > 0 and s0["served"][3] > 0, s0   # the loop IS being answered from frames
+    prev = state
+    t = 8
+    nL, nR = seq["n"][t]
+    kp1, kp2 = seq["kp"][t, 0, :nL].copy(), seq["kp"][t, 1, :nR].copy()
+    d1, d2 = seq["desc"][t, 0, :nL].copy(), seq["desc"][t, 1, :nR].copy()
+    lr = libviso_amd.match_desc(kp1, kp2, d1, d2, st)            # opens the frame, computes everything ahead
+    assert np.array_equal(lr, oracle.match_desc(kp1, kp2, d1, d2, st))
+    # collect_matches with two rows of the list exchanged
+    lr2 = lr.copy(); lr2[[0, 1]] = lr2[[1, 0]]
+    assert np.array_equal(libviso_amd.collect_matches(kp1, kp2, lr2), oracle.collect_matches(kp1, kp2, lr2))
+    x = libviso_amd.collect_matches(kp1, kp2, lr)
+    assert np.array_equal(x, oracle.collect_matches(kp1, kp2, lr))
+    # triangulate_rectified with another baseline, and with one coordinate moved
+    p2 = type(seq["param"]).from_buffer_copy(seq["param"]); p2.base = seq["param"].base * 1.25
+    assert np.array_equal(libviso_amd.triangulate_rectified(x, p2), oracle.triangulate_rectified(x, p2))
+    x2 = x.copy(); x2[0, 3] += 1.0
+    assert np.array_equal(libviso_amd.triangulate_rectified(x2, seq["param"]), oracle.triangulate_rectified(x2, seq["param"]))
+    X = libviso_amd.triangulate_rectified(x, seq["param"])
+    assert np.array_equal(X, oracle.triangulate_rectified(x, seq["param"]))
+    # temporal call with one descriptor element changed / another ratio
+    d1b = d1.copy(); d1b[5, 7] += 3
+    assert np.array_equal(libviso_amd.match_desc(kp1, prev["kp1"], d1b, prev["d1"], tm), oracle.match_desc(kp1, prev["kp1"], d1b, prev["d1"], tm))
+    tm2 = MatchParams.temporal(); tm2.ratio_2nd_best = 0.8
+    assert np.array_equal(libviso_amd.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm2), oracle.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm2))
+    m11 = libviso_amd.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm)
+    m22 = libviso_amd.match_desc(kp2, prev["kp2"], d2, prev["d2"], tm)
+    assert np.array_equal(m11, oracle.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm))
+    assert np.array_equal(m22, oracle.match_desc(kp2, prev["kp2"], d2, prev["d2"], tm))
+    # match_circle with a row of match22 removed
+    m22b = m22[1:].copy()
+    _, c_a, p_a, n_a = libviso_amd.match_circle(lr, prev["lr"], m11, m22b)
+    _, c_o, p_o, _ = oracle.match_circle(lr, prev["lr"], m11, m22b)
+    assert n_a == len(c_o) and np.array_equal(c_a, c_o) and np.array_equal(p_a, p_o)
+    _, circ, pcl, n = libviso_amd.match_circle(lr, prev["lr"], m11, m22)
+    _, c_o, p_o, _ = oracle.match_circle(lr, prev["lr"], m11, m22)
+    assert n == len(c_o) and np.array_equal(circ, c_o) and np.array_equal(pcl, p_o)
+    assert n >= 3
+    x_c, Xp_c = np.ascontiguousarray(x[:, pcl[:, 0]]), np.ascontiguousarray(prev["X"][:, pcl[:, 1]])
+    # RANSAC with another stream key, another seed, one observation moved, another threshold
+    for kw, xc in (({"seed": 5, "frame": t + 40}, x_c), ({"seed": 6, "frame": t}, x_c)):
+        r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xp_c, xc, seq["param"], **kw)
+        r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xp_c, xc, seq["param"], **kw)
+        assert r_a == r_o and np.array_equal(inl_a, inl_o)
+        if r_o:
+            assert rel_fro(libviso_amd.tr2mat(tr_a), oracle.tr2mat(tr_o)) < POSE_TOL
+    xcb = x_c.copy(); xcb[1, 2] += 0.5
+    p3 = type(seq["param"]).from_buffer_copy(seq["param"]); p3.inlier_threshold = 1.5
+    for prm, xc in ((seq["param"], xcb), (p3, x_c)):
+        r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xp_c, xc, prm, seed=5, frame=t)
+        r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xp_c, xc, prm, seed=5, frame=t)
+        assert r_a == r_o and np.array_equal(inl_a, inl_o)
+    r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=5, frame=t)
+    r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=5, frame=t)
+    assert r_a == r_o and np.array_equal(inl_a, inl_o)
+
+
+def test_an_image_that_does_not_fit_the_u16_rows_where_none_was_expected(viso, oracle, seq):
+    """Integer-valued images for a while (the launches leave the general kernels out), then fractional descriptors: the
+    call is repeated with the general kernels and gives the oracle's matches."""
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(True)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    state = None
+    for t in range(5):
+        state = _loop_frame(seq, t, st, tm, state)
+    before = drop_in.plain_stats()["general_reruns"]
+    t = 5
+    nL, nR = seq["n"][t]
+    kp1, kp2 = seq["kp"][t, 0, :nL].copy(), seq["kp"][t, 1, :nR].copy()
+    d1, d2 = seq["desc"][t, 0, :nL].copy(), seq["desc"][t, 1, :nR].copy()
+    d2[3, 4] += 0.5                                              # one fractional value in the right image
+    lr = libviso_amd.match_desc(kp1, kp2, d1, d2, st)
+    assert np.array_equal(lr, oracle.match_desc(kp1, kp2, d1, d2, st))
+    assert drop_in.plain_stats()["general_reruns"] == before + 1
+    m11 = libviso_amd.match_desc(kp1, state["kp1"], d1, state["d1"], tm)
+    m22 = libviso_amd.match_desc(kp2, state["kp2"], d2, state["d2"], tm)
+    assert np.array_equal(m11, oracle.match_desc(kp1, state["kp1"], d1, state["d1"], tm))
+    assert np.array_equal(m22, oracle.match_desc(kp2, state["kp2"], d2, state["d2"], tm))
+    # and the loop goes on with integer images
+    state = None
+    for t in range(6, 12):
+        state = _loop_frame(seq, t, st, tm, state)
+        if t > 6:
+            want = oracle.match_desc(state["kp1"], seq["kp"][t - 1, 0, :seq["n"][t - 1, 0]], state["d1"], seq["desc"][t - 1, 0, :seq["n"][t - 1, 0]], tm)
+            assert np.array_equal(state["m11"], want)
+
+
+def test_frames_of_changing_size_and_empty_images(viso, oracle):
+    """Keypoint counts that change from frame to frame (the frame's blocks are re-laid out), an image without keypoints."""
+    s = synth.make_sequence(3, 9, n_kp=300, width=500, height=200, ragged=True)
+    s["n"][4, 1] = 0                                              # frame 4: no keypoints in the right image
+    s["n"][6, 0] = 40
+    st, tm = MatchParams.stereo(s["F"]), MatchParams.temporal()
+    o = drop_in.run(s["kp"], s["desc"], s["n"], s["F"], s["param"], seed=2, want_matches=True)
+    want = oracle.sequence(s["kp"], s["desc"], s["n"], st, tm, s["param"], seed=2)
+    assert np.array_equal(o["ok"], want["ok"]) and np.array_equal(o["n_inl"], want["n_inl"])
+    for t in range(9):
+        nL, nR = s["n"][t]
+        assert np.array_equal(o["matches"][0][t], oracle.match_desc(s["kp"][t, 0, :nL], s["kp"][t, 1, :nR], s["desc"][t, 0, :nL], s["desc"][t, 1, :nR], st))
