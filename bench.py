@@ -64,7 +64,7 @@ CLK_GHZ = 2.4                  # max clock
 VALU_CYCLES_FULL = 2
 VALU_CYCLES_SAD = 4
 L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 GATHER_KERNELS = ("match_union_kernel", "match_union8_kernel")   # rows gathered from the XCD's L2 by index
 
 
@@ -100,6 +100,20 @@ def b_min_bytes(n, m_out, dlen=121, elem=4):
         pL, pR = int(n[t - 1, 0]), int(n[t - 1, 1])
         temporal += (8 + row) * (nL + pL) + 12 * int(m_out[1, t]) + (8 + row) * (nR + pR) + 12 * int(m_out[2, t])
     return stereo, temporal
+
+
+def b_min_bytes_union8(n, m_out):
+    """What match_union8_kernel (matcher variant 6) MUST read per temporal call: keypoints and 8-bit planes of both images
+    ((8 + 128) B per keypoint), every query's own u16 row (256 B) and the u16 rows of the two candidates per query that are
+    scored exactly -- at most every target row once from HBM (256 B x min(2 N1, N2)) -- plus the 12-B result rows.
+    Sum over the temporal calls of the batch."""
+    nf = n.shape[0]
+    tot = 0
+    for t in range(1, nf):
+        for side, w in ((0, 1), (1, 2)):
+            n1, n2 = int(n[t, side]), int(n[t - 1, side])
+            tot += (8 + 128) * (n1 + n2) + 256 * n1 + 256 * min(2 * n1, n2) + 12 * int(m_out[w, t])
+    return tot
 
 
 def workload_name(args):
@@ -247,6 +261,7 @@ def main():
                          "per frame to paint; 512 like the other legs: +16 %% / +6 %%)")
     ap.add_argument("--e2e-streams", type=int, default=5,
                     help="batches in flight for the end-to-end leg (each adds a RANSAC stream of its own: 5 measured +1.3 %% over 3; 0 = --streams)")
+    ap.add_argument("--no-i16", action="store_true", help="skip the resident int16-rows matcher leg")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the per-call drop-in leg (the plain C-ABI, one reference function per call)")
     ap.add_argument("--drop-in-frames", type=int, default=256, help="frame pairs of the per-call drop-in leg")
     ap.add_argument("--ab-variants", default="", help="matcher variants timed by --ab (default: all of the build)")
@@ -311,7 +326,10 @@ def main():
 
     variant = args.matcher if args.matcher is not None else libviso_amd.DEFAULT_MATCHER
     nf = args.frames + 1                      # B pairs need B+1 frames (one-frame halo)
+    t_syn = time.perf_counter()
     seq = synth.make_sequence(1000 + rank, nf, n_kp=args.kp, width=args.width, height=args.height, cluster_frac=args.clustered)
+    # a first multi-GPU run that looks hung is usually here: every rank paints its own synthetic data on the CPU first
+    print(f"bench.py: rank {rank}/{world}: {nf} synthetic feature frames generated in {time.perf_counter() - t_syn:.1f} s", file=sys.stderr, flush=True)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
     # S independent batches per GPU, each on its own context / HIP stream: consecutive steps go to
     # different streams, so one batch's latency-bound stages (sorts, RANSAC) overlap the next one's matcher
@@ -427,6 +445,29 @@ def main():
     fps = frames_total / dt
     fps_spread = spread(dts_m, frames_total)
 
+    # ---- the same step with the descriptors resident as int16 rows (viso_batch_upload_i16: the lossless boundary format) --
+    # the f32 headline pays 0.3 ms of every 1.0 ms step for the f32 -> u16 + u8 repack of the reference's CV_32F rows: the
+    # boundary's cost, not the matcher's; this is the matcher step without it
+    res_i16 = None
+    if not args.no_i16:
+        d16 = np.ascontiguousarray(seq["desc"].astype(np.int16))
+        b16 = []
+        for c, _ in lanes[:n_streams]:
+            b = libviso_amd.Batch(c, nf, args.kp)
+            b.upload_i16(seq["kp"], d16, seq["n"])
+            b.set_params(st, tm, seq["param"], seed=1, first_frame=rank * args.frames)
+            b16.append(b)
+        dts16r = timed_regions(lambda b: b.run_matcher(), args.steps, n_streams, objs=b16)
+        sc16, mo16 = b16[0].counters()
+        res_i16 = {"fps": frames_total / float(np.median(dts16r)), "ms_per_step": float(np.median(dts16r)) / args.steps * 1e3,
+                   "fps_spread": spread(dts16r, frames_total),
+                   "workload": "the configs[1] step with the descriptors uploaded once as N x 121 int16 (viso_batch_upload_i16) instead of "
+                               "CV_32F: pack_desc_i16_kernel reads half the bytes; same matches",
+                   "same_counters_as_f32": bool(np.array_equal(sc16, batch.counters()[0]) and np.array_equal(mo16, batch.counters()[1]))}
+        for b in b16:
+            b.close()
+        del d16
+
     scored, m_out = batch.counters()
     n_overflow = batch.overflow_count()
     balg_stereo, balg_temporal = b_alg_bytes(seq["n"], scored, m_out)
@@ -443,6 +484,7 @@ def main():
     # v_sad_u8 / v_sad_hi_u8 wave-instruction (64 lanes x 4 elements) scores TWO pairs, and only the two best candidates
     # of a query are scored again on the u16 rows.  All of them are half-rate opcodes (one per 4 cycles per SIMD)
     u8_kernel = kname == "match_union8_kernel"
+    bmin_k = b_min_bytes_union8(seq["n"], m_out) if u8_kernel else bmin16_t
     sad_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_SAD * (2 if u8_kernel else 1)
     valu_peak = N_SIMD * CLK_GHZ * 1e9 / VALU_CYCLES_FULL
     ceilings["sad_valu"] = {"achieved": pairs / t_k, "peak": sad_peak, "unit": "scored pairs/s",
@@ -537,8 +579,13 @@ def main():
                                 "note": "SURVEY 8(d) B_alg (every scored pair counted as a fresh 484-B f32 row) / kernel time: an "
                                         "effective figure served by L2/LDS, not comparable with the HBM peak"},
         "compulsory_bytes": {"per_launch_f32_boundary": bmin32_t, "per_launch_u16_rows": bmin16_t,
+                             "per_launch_this_kernel": bmin_k,
+                             "per_launch_this_kernel_what": ("match_union8_kernel: planes + keypoints of both images, every query's u16 row, the u16 rows of the two "
+                                                             "exactly scored candidates per query (at most every target row once), result rows" if u8_kernel
+                                                             else "the u16 rows + keypoints of both images, result rows"),
+                             "traffic_over_compulsory": (pmc["hbm_bytes"] / bmin_k) if pmc["hbm_bytes"] else None,
                              "per_step_all_calls_f32_boundary": bmin32_s + bmin32_t,
-                             "hbm_frac_if_only_compulsory_u16": bmin16_t / t_k / 1e9 / HBM_PEAK_GBS},
+                             "hbm_frac_if_only_compulsory": bmin_k / t_k / 1e9 / HBM_PEAK_GBS},
         "algorithmic_bytes_per_step_all_calls": balg_stereo + balg_temporal,
     }
 
@@ -739,7 +786,9 @@ def main():
         for _, b in lanes:   # the resident legs below expect the original sequence
             b.upload(seq["kp"], seq["desc"], seq["n"])
         # image-in: uint8 images + keypoints cross PCIe, descriptors are extracted on the device
+        t_syn = time.perf_counter()
         iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
+        print(f"bench.py: rank {rank}/{world}: {nfi} synthetic stereo images painted in {time.perf_counter() - t_syn:.1f} s (CPU, ~35 ms per frame)", file=sys.stderr, flush=True)
         ibs, ihosts = [], []
         for c, _ in lanes[:n_streams]:
             ib = libviso_amd.Batch(c, nfi, args.kp)
@@ -774,7 +823,9 @@ def main():
     e2e_img = None
     if not args.no_images:
         if iseq is None:
+            t_syn = time.perf_counter()
             iseq = synth.make_image_sequence(2000 + rank, nfi, n_kp=args.kp, width=args.width, height=args.height)
+            print(f"bench.py: rank {rank}/{world}: {nfi} synthetic stereo images painted in {time.perf_counter() - t_syn:.1f} s (CPU, ~35 ms per frame)", file=sys.stderr, flush=True)
         isteps = max(n_pipe, args.steps // 2)
         ibs = []
         for c, _ in pipeline_lanes():   # one image batch per stream, same synthetic frames in each
@@ -838,6 +889,7 @@ def main():
                                       f"the legs that run the whole pipeline (end_to_end, end_to_end_from_images): {n_pipe}"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "resident_i16": res_i16,
             "end_to_end": e2e,
             "drop_in_per_call": drop,
             "collective": collective,

@@ -349,8 +349,9 @@ int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl)
 /* Per-hypothesis state of the last run's RANSAC stage (diagnostics / tests): tr_h [n_frames][ransac_iter][6],
  * ok_h, cnt_h [n_frames][ransac_iter] (support sizes; frame 0 unused), *n_undecided = hypotheses that needed the
  * wave-per-hypothesis kernel.  Any pointer may be NULL.  ransac_iter is the one given to viso_batch_set_params;
- * viso_batch_get_hypotheses2 takes the capacity of the caller's arrays (in hypotheses per frame) and returns
- * VISO_ERR_ARG instead of writing past them. */
+ * viso_batch_get_hypotheses2 takes the capacity of the caller's arrays (in hypotheses per frame): the arrays are
+ * [n_frames][iters_capacity] (x 6 for tr_h) and every frame's row is written at THAT stride (entries beyond ransac_iter
+ * are left alone); VISO_ERR_ARG when iters_capacity < ransac_iter. */
 int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided);
 int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, double* tr_h, int32_t* ok_h, int32_t* cnt_h,
                                int32_t* n_undecided);

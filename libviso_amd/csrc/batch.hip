@@ -748,7 +748,20 @@ extern "C" int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, dou
         viso_set_error("viso_batch_get_hypotheses2: arrays hold %d hypotheses per frame, the batch has %d", iters_capacity, b ? b->iters : 0);
         return VISO_ERR_ARG;
     }
-    return viso_batch_get_hypotheses(b, tr_h, ok_h, cnt_h, n_undecided);
+    const int iters = b->iters > 0 ? b->iters : 1;
+    if (iters_capacity == iters) return viso_batch_get_hypotheses(b, tr_h, ok_h, cnt_h, n_undecided);
+    // the caller's rows are longer than the batch's: frame by frame, at the caller's stride
+    if (!b->tr_h) { viso_set_error("viso_batch_get_hypotheses2: no run yet"); return VISO_ERR_ARG; }
+    { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
+    const size_t nf = (size_t)b->nf;
+    if (tr_h) HIP_TRY(hipMemcpy2D(tr_h, sizeof(double) * 6 * (size_t)iters_capacity, b->tr_h, sizeof(double) * 6 * (size_t)iters,
+                                  sizeof(double) * 6 * (size_t)iters, nf, hipMemcpyDeviceToHost));
+    if (ok_h) HIP_TRY(hipMemcpy2D(ok_h, sizeof(int) * (size_t)iters_capacity, b->ok_h, sizeof(int) * (size_t)iters, sizeof(int) * (size_t)iters, nf,
+                                  hipMemcpyDeviceToHost));
+    if (cnt_h) HIP_TRY(hipMemcpy2D(cnt_h, sizeof(int) * (size_t)iters_capacity, b->cnt_h, sizeof(int) * (size_t)iters, sizeof(int) * (size_t)iters, nf,
+                                   hipMemcpyDeviceToHost));
+    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq, sizeof(int), hipMemcpyDeviceToHost));
+    return VISO_OK;
 }
 
 extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided) {

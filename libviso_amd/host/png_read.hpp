@@ -359,12 +359,14 @@ inline bool read_png_gray_with(const std::string& file_name, int& rows, int& col
     }
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!w || !h || depth != 8 || !ch || interlace || w > 65535 || h > 65535 || (size_t)w * h > PNG_MAX_PIXELS) return false;
+    // the destination is asked for BEFORE anything is sized from the (untrusted) header: a caller that knows the geometry
+    // (read_png_gray_to) refuses another one here, before up to 256 MB are allocated and inflated for nothing
+    uint8_t* dst = provide((int)h, (int)w);
+    if (!dst) return false;
     const size_t stride = (size_t)w * ch, raw_size = (size_t)h * (stride + 1);
     std::vector<uint8_t> raw(raw_size + 8);
     size_t produced = 0;
     if (!inflate(f.data() + zbeg, zlen, raw.data(), raw_size, &produced) || produced < raw_size) return false;
-    uint8_t* dst = provide((int)h, (int)w);
-    if (!dst) return false;
     std::vector<uint8_t> zero(stride, 0), rowbuf;
     if (ch == 1) {   // straight into the destination
         for (uint32_t y = 0; y < h; ++y) {
@@ -396,9 +398,16 @@ inline bool read_png_gray(const std::string& file_name, int& rows, int& cols, st
 }
 
 // The same into caller memory of a known geometry (a pinned upload buffer): fails when the file's size differs.
-inline bool read_png_gray_to(const std::string& file_name, int rows, int cols, uint8_t* dst) {
+// *other_geometry (may be null) = the file is a readable PNG header of ANOTHER size: a different failure from "cannot be
+// opened / decoded" (the end of a sequence, src/viso.h:94-96) for callers that must tell the two apart.
+inline bool read_png_gray_to(const std::string& file_name, int rows, int cols, uint8_t* dst, bool* other_geometry = nullptr) {
     int r = 0, c = 0;
-    return read_png_gray_with(file_name, r, c, [&](int fr, int fc) { return fr == rows && fc == cols ? dst : nullptr; });
+    if (other_geometry) *other_geometry = false;
+    return read_png_gray_with(file_name, r, c, [&](int fr, int fc) {
+        if (fr == rows && fc == cols) return dst;
+        if (other_geometry) *other_geometry = true;
+        return static_cast<uint8_t*>(nullptr);
+    });
 }
 
 }  // namespace viso

@@ -235,6 +235,9 @@ public:
     // One image of frame `index` (side 0 = left) into caller memory of a known geometry (a pinned upload buffer);
     // false if it cannot be read or has another size.
     bool read_to(int index, int side, int rows, int cols, uint8_t* dst) const;
+    // The same with the reason of a failure: 1 = read, 0 = cannot be opened / decoded (the generator's end of stream,
+    // src/viso.h:94-96), 2 = decodes, but with another geometry than rows x cols.
+    int read_into(int index, int side, int rows, int cols, uint8_t* dst) const;
     int index() const { return m_index; }
     int end() const { return m_end; }
     void seek(int index) { m_index = index; }

@@ -610,15 +610,23 @@ bool StereoImageGenerator::read(int index, Image& left, Image& right) const {
     return !right.empty();
 }
 
-bool StereoImageGenerator::read_to(int index, int side, int rows, int cols, uint8_t* dst) const {
+int StereoImageGenerator::read_into(int index, int side, int rows, int cols, uint8_t* dst) const {
     const std::string name = format_mask(side ? m_mask.second : m_mask.first, index);
     const size_t n = name.size();
-    if (n >= 4 && (name.compare(n - 4, 4, ".png") == 0 || name.compare(n - 4, 4, ".PNG") == 0))
-        return read_png_gray_to(name, rows, cols, dst);
+    if (n >= 4 && (name.compare(n - 4, 4, ".png") == 0 || name.compare(n - 4, 4, ".PNG") == 0)) {
+        bool other = false;
+        if (read_png_gray_to(name, rows, cols, dst, &other)) return 1;
+        return other ? 2 : 0;
+    }
     Image im = imread_pgm(name);
-    if (im.empty() || im.rows != rows || im.cols != cols) return false;
+    if (im.empty()) return 0;
+    if (im.rows != rows || im.cols != cols) return 2;
     std::memcpy(dst, im.data.data(), (size_t)rows * cols);
-    return true;
+    return 1;
+}
+
+bool StereoImageGenerator::read_to(int index, int side, int rows, int cols, uint8_t* dst) const {
+    return read_into(index, side, rows, cols, dst) == 1;
 }
 
 StereoImageGenerator::result_type StereoImageGenerator::operator()() {
@@ -753,12 +761,22 @@ OdometryResult sequence_odometry(const Matd& P1, const Matd& P2, StereoImageGene
                 uint8_t* dst = pin + ((size_t)(j + 1) * 2 + side) * per;
                 uint8_t* flag = &ok_flag[(size_t)j * 2 + side];
                 const int index = first_index + global0 + 1 + j;
-                pool.submit([&images, index, side, rows, cols, dst, flag] { *flag = images.read_to(index, side, rows, cols, dst) ? 1 : 0; });
+                pool.submit([&images, index, side, rows, cols, dst, flag] {
+                    // a worker must not let an exception escape (std::terminate): a file that cannot be decoded -- whatever the
+                    // decoder ran into, bad_alloc on a corrupt header included -- is an unreadable image
+                    try { *flag = (uint8_t)images.read_into(index, side, rows, cols, dst); } catch (...) { *flag = 0; }
+                });
             }
         pool.wait_all();
         out.stats.decode_wait_s += since(t0);
         int got = 0;
-        while (got < want && ok_flag[(size_t)got * 2] && ok_flag[(size_t)got * 2 + 1]) ++got;
+        while (got < want && ok_flag[(size_t)got * 2] == 1 && ok_flag[(size_t)got * 2 + 1] == 1) ++got;
+        // The first frame that is not usable ends the sequence, as the reference's generator does for an unreadable pair
+        // (src/viso.h:94-96) -- unless it DOES decode, with another size: that is not an end of stream but an input error,
+        // and it is reported as one (the chunks in flight are drained by the pipeline's destructor)
+        if (got < want && (ok_flag[(size_t)got * 2] == 2 || ok_flag[(size_t)got * 2 + 1] == 2))
+            throw std::invalid_argument("sequence_odometry: image size changes inside a sequence (frame " +
+                                        std::to_string(first_index + global0 + 1 + got) + ")");
         if (got < want || first_index + global0 + got >= images.end()) eos = true;
         images.seek(first_index + global0 + got + (got < want ? 2 : 1));   // where operator() would stand now
         frames_read += got;

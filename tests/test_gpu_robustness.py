@@ -39,6 +39,53 @@ def test_exit_with_live_handles_keeps_the_python_exit_code():
     assert "leak on purpose" in r.stderr and "terminate called" not in r.stderr
 
 
+@pytest.mark.parametrize("order", ["alive_at_exit", "stream_first", "context_first"])
+def test_context_on_a_callers_stream(order):
+    """viso_ctx_create(device, stream) BORROWS the caller's stream.  A context (and a batch) on such a stream must survive
+    every teardown order a caller can produce: everything still alive at interpreter exit; the stream destroyed before
+    the context (viso_ctx_destroy then REPORTS the dead handle, it does not crash); the context first.  Round 4 left a
+    probe that exited with a live context on a CU-masked stream of its own and died in __cxa_finalize under rocprofv3
+    (gpurun_out/cum.txt): the probe is gone, the teardown orders are pinned here."""
+    code = textwrap.dedent("""
+        import ctypes as C, sys
+        sys.path.insert(0, %r)
+        import torch
+        import libviso_amd
+        from libviso_amd import synth
+        from libviso_amd.abi import MatchParams
+        order = %r
+        import libviso_amd as _l; _l.load()
+        path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+        hip = C.CDLL(path)                  # the HIP runtime this process already holds (torch's): the same handle, no second copy
+        stream = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(stream)) == 0
+        seq = synth.make_sequence(1, 3, n_kp=300, width=400, height=200)
+        ctx = libviso_amd.Context(0, stream=stream)
+        b = libviso_amd.Batch(ctx, 3, 300)
+        b.upload(seq["kp"], seq["desc"], seq["n"])
+        b.set_params(MatchParams.stereo(seq["F"]), MatchParams.temporal(), seq["param"], seed=1)
+        b.run()
+        tr, ok, n_inl = b.poses()
+        assert ok[1:].all()
+        L = libviso_amd.load()
+        if order == "stream_first":
+            b.close()
+            assert hip.hipStreamDestroy(stream) == 0
+            r = L.viso_ctx_destroy(C.c_void_p(ctx.h))     # a dead stream: reported (VISO_ERR_HIP) or tolerated, never a crash
+            assert r in (1, -2), r
+            ctx.h = None
+        elif order == "context_first":
+            b.close(); ctx.close()
+            assert hip.hipStreamDestroy(stream) == 0
+        else:
+            keep = [b, ctx, stream]          # all alive at interpreter exit
+        print("done", order)
+    """ % (ROOT, order))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and ("done " + order) in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "terminate called" not in r.stderr and "Segmentation" not in r.stderr
+
+
 def test_destroy_reports_instead_of_swallowing(viso):
     ctx = libviso_amd.Context(0)
     b = libviso_amd.Batch(ctx, 2, 64)
@@ -145,4 +192,27 @@ def test_synchronous_upload_waits_for_a_run_in_flight(viso):
         b.run()
         got = b.poses()
         assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    b.close(); ctx.close()
+
+
+def test_hypotheses_getter_with_a_wider_capacity(viso):
+    """viso_batch_get_hypotheses2 with arrays of [n_frames][capacity > ransac_iter]: every frame's row at the caller's stride
+    (the first version forwarded to the tight getter and put frame 1's row where frame 0's padding belonged)."""
+    import ctypes as C
+    from libviso_amd.abi import f64p, i32p, ptr
+    seq = synth.make_sequence(4, 4, n_kp=300, width=400, height=200)
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 4, 300)
+    b.upload(seq["kp"], seq["desc"], seq["n"])
+    b.set_params(MatchParams.stereo(seq["F"]), MatchParams.temporal(), seq["param"], seed=3)
+    b.run()
+    tr_h, ok_h, cnt_h, nu = b.hypotheses()
+    iters, cap = tr_h.shape[1], tr_h.shape[1] + 14
+    viso.viso_batch_get_hypotheses2.argtypes = [C.c_void_p, C.c_int, f64p, i32p, i32p, i32p]
+    tr2 = np.full((4, cap, 6), -7.0); ok2 = np.full((4, cap), -7, np.int32); cnt2 = np.full((4, cap), -7, np.int32)
+    nu2 = np.zeros(1, np.int32)
+    assert viso.viso_batch_get_hypotheses2(b.h, cap, ptr(tr2, C.c_double), ptr(ok2, C.c_int32), ptr(cnt2, C.c_int32), ptr(nu2, C.c_int32)) == 1
+    assert np.array_equal(tr2[:, :iters], tr_h) and np.array_equal(ok2[:, :iters], ok_h) and np.array_equal(cnt2[:, :iters], cnt_h)
+    assert (tr2[:, iters:] == -7).all() and (ok2[:, iters:] == -7).all() and (cnt2[:, iters:] == -7).all() and nu2[0] == nu
+    assert viso.viso_batch_get_hypotheses2(b.h, iters - 1, ptr(tr2, C.c_double), ptr(ok2, C.c_int32), ptr(cnt2, C.c_int32), None) == -1
     b.close(); ctx.close()

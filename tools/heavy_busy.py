@@ -4,7 +4,8 @@ import collections
 import csv
 import sys
 
-HEAVY = ("match_union_kernel", "match_prune_kernel", "pack_desc", "match_stereo_kernel", "extract_pack", "harris")
+HEAVY = ("match_union",  # match_union_kernel and match_union8_kernel (the default since round 4)
+         "match_prune_kernel", "pack_desc", "match_stereo_kernel", "extract_pack", "harris")
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -30,7 +31,7 @@ def union(iv):
 
 wall = max(r[1] for r in sel) - sel[0][0]
 heavy = [(s, e) for s, e, k, _ in sel if k.startswith(HEAVY)]
-n_steps = sum(1 for _, _, k, _ in sel if k.startswith(("match_union_kernel", "match_prune_kernel")))
+n_steps = sum(1 for _, _, k, _ in sel if k.startswith(("match_union", "match_prune_kernel")))
 print(f"window {wall / 1e6:.3f} ms, {n_steps} steps -> {wall / 1e3 / max(n_steps, 1):.1f} us per step")
 print(f"  >= 1 heavy kernel running: {100 * union(heavy) / wall:.1f} % of the wall time; any kernel: {100 * union([(s, e) for s, e, _, _ in sel]) / wall:.1f} %")
 dur = collections.defaultdict(list)

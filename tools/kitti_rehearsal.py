@@ -9,7 +9,9 @@ and runs it through every runner:
     viso_kitti --gpus W --same-device           W forked ranks on the one device  (W = 6: the box allows 6 GPU processes)
     python -m libviso_amd.kitti_shard --gpus 1 --backend nccl --force-collective   the torch.distributed runner through RCCL
 
-and checks that the pose files are byte-identical.  Every rank prints where its wall time went (PNG decode on the worker
+and checks that the pose files are byte-identical -- and that they are RIGHT: every 50th frame pair and every pair the
+runner reports as unsolved goes through the CPU oracle from the PNG files (tests/rehearsal_check.py), the unsolved ones
+tabulated by the exit of the reference's loop body they take.  Every rank prints where its wall time went (PNG decode on the worker
 threads / upload / GPU); the report goes to stdout and to --out.
 
 The frames come from independent synthetic blocks of 71 frames (generated in parallel): consecutive frames inside a
@@ -77,9 +79,10 @@ def main():
     ap.add_argument("--ranks", type=int, default=6, help="forked ranks on the one device (the box allows 6 GPU processes)")
     ap.add_argument("--cpus", type=int, default=min(16, len(os.sched_getaffinity(0))), help="host threads to use in total")
     ap.add_argument("--home", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "viso_kitti_rehearsal"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_kitti_rehearsal.txt"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_kitti_rehearsal.txt"))
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--skip-rccl", action="store_true")
+    ap.add_argument("--check-every", type=int, default=50, help="every n-th pair (and every unsolved one) goes through the CPU oracle")
     args = ap.parse_args()
     lines = []
 
@@ -105,6 +108,12 @@ def main():
     same = open(pose("one"), "rb").read() == open(pose(f"fork{args.ranks}"), "rb").read()
     log(f"pose files of 1 process and of {args.ranks} forked ranks byte-identical: {same} ({len(open(pose('one')).read().splitlines())} lines)")
     ok = same
+    # the oracle on a sample of the pairs and on every pair the runner reports as unsolved (tests/rehearsal_check.py: the
+    # part of the rehearsal that touches oracle/ is test infrastructure and lives under tests/); CPU only
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rehearsal_check.py"), args.home, "00", f"fork{args.ranks}", str(args.ranks),
+                        "--every", str(args.check_every), "--procs", str(args.cpus)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    log(f"$ python tests/rehearsal_check.py ... fork{args.ranks} {args.ranks} --every {args.check_every}\n[exit {r.returncode}]\n{r.stdout}{r.stderr[-3000:] if r.returncode else ''}")
+    ok = ok and r.returncode == 0
     if not args.skip_rccl:
         run([sys.executable, "-m", "libviso_amd.kitti_shard", "rccl1", "00", "--gpus", "1", "--backend", "nccl", "--force-collective",
              "--decode-threads", str(args.cpus)], env, log)

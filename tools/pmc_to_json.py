@@ -22,9 +22,13 @@ def per_kernel(d, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 main = sys.argv[3] if len(sys.argv) > 3 else "match_union_kernel"
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --streams 1 "
+# the command / workload the passes were taken on: the callers that are not tools/profile_round.sh say so (VISO_PMC_COMMAND,
+# VISO_PMC_WORKLOAD: tools/image_profile.sh) -- round 4's image file carried the matcher profile's strings
+out = {"command": os.environ.get("VISO_PMC_COMMAND") or
+                  "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --streams 1 "
                   "--steps 4 --warmup 1 --no-cpu --no-e2e --no-streaming (two separate passes, tools/profile_round.sh)",
-       "workload": f"configs[1], {os.environ.get('VISO_PMC_FRAMES', '512')} frame pairs/batch, 2000 kp/image (bench.py defaults)",
+       "workload": os.environ.get("VISO_PMC_WORKLOAD") or
+                   f"configs[1], {os.environ.get('VISO_PMC_FRAMES', '512')} frame pairs/batch, 2000 kp/image (bench.py defaults)",
        "kernel_source_sha256": kernel_source_sha(),
        "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reads exactly 1/2 of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE exact",
        "other_kernels": {}}
