@@ -58,7 +58,7 @@ def _check(job):
     for j, fr in enumerate((t - 1, t)):
         for side in (0, 1):
             img = _gray(os.path.join(base, f"image_{side}", "%06d.png" % fr))
-            k, _ = O.detect_harris_binned(img, 1200, 24, 5, 0.04)
+            k, _ = O.detect_harris_binned(img, 1200, 24, 5, O.HARRIS_K)
             n[j, side] = len(k)
             kp[j, side, :len(k)] = k
             desc[j, side, :len(k)] = O.extract_descriptors(img, k, 5)
