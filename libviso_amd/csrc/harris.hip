@@ -113,6 +113,131 @@ __device__ __forceinline__ float wave_shl1(float v) {
 
 // Wave `band` of the workgroup walks output rows [y0, y1) of the tile (relative to ty0); sink(y, lx - 1, R, valid) is
 // called by EVERY lane for every row, in row order; valid = the lane owns an output column (0 <= lx - 1 < tw).
+//
+// The walk keeps three sliding windows per lane: the last five rows of the two row passes (H, G) and the last three
+// box row sums (ra, rb, rc).  Sliding them by moves cost 22 of the ~85 vector instructions of a row (round 4).  They
+// are RINGS now: the steady-state rows run in blocks of 15 (= lcm(5, 3)) fully unrolled rows in which every window slot
+// is a compile-time register, the new row overwrites the oldest slot, and after 15 rows every ring is back in its
+// canonical order (slot 0 = oldest) -- the order the rolled code of the warm-up rows and of the remainder expects.  A
+// KITTI bin is 75 rows: five blocks, no remainder.  The five pixel bytes of a row come as one dword + one byte and are
+// converted by v_cvt_f32_ubyte0..3 straight from the dword (no shifts).
+struct HarrisRow {   // one lane's state of the walk
+    float H[5], G[5];                                  // rows q-4 .. q of the two row passes (canonical order between blocks)
+    float ra[3], rb[3], rc[3];                         // box row sums of cov rows r-2 .. r
+    uint32_t nw; uint32_t nb4;                         // the NEXT row's five bytes: p0..p3 packed, p4
+};
+
+// HS / RS: ring slot the new row-pass row / the new row sums go to (the oldest of the window); in the rolled code both
+// are the last slot after an explicit shift (HS = 4, RS = 2, shift = true)
+#ifndef HW_BLOCK
+#define HW_BLOCK 15                 // unrolled rows per block: 15 (both rings) or 5 (H / G rings, the row sums shift: 386 against 379 us)
+#endif
+// (Measured and dropped, round 5: a second instantiation for tiles that touch no image edge -- no ring column, no cov row
+// to reflect, no row below the image: three uniform branches less per row -- 378 us either way.)
+template <int HS, int RS, bool SHIFT, bool FULL, class Sink, bool SHIFT_R = SHIFT>
+__device__ __forceinline__ bool harris_row(HarrisRow& w, const unsigned char* s_img, int q, int y0, int y1, int rows, int ty0,
+                                           int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
+                                           float t0, float t1, float t2, Sink& sink) {
+    // (float)((dword >> 8 n) & 255) is what the backend selects v_cvt_f32_ubyte<n> for
+    const float p0 = (float)(w.nw & 255u), p1 = (float)((w.nw >> 8) & 255u), p2 = (float)((w.nw >> 16) & 255u),
+                p3 = (float)(w.nw >> 24), p4 = (float)(w.nb4 & 255u);
+    {   // the five bytes of the NEXT row are asked for before this row's arithmetic (the LDS round trip at the top of every
+        // row was exposed: the walk is one dependent chain per row)
+        const unsigned char* p = s_img + (min(q + 1, y1 + 2) + 3) * HW_PITCH + lxc;
+        uint32_t v; __builtin_memcpy(&v, p, 4);
+        w.nw = v; w.nb4 = p[4];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SHIFT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w.H[i] = w.H[i + 1]; w.G[i] = w.G[i + 1]; }
+    }
+    // RowFilter: k0*S0, += k1*S1, ... left to right.  Derivative taps -1,-2,0,2,1: small integers, exact in any order
+    w.H[HS] = (p4 - p0) + 2.f * (p3 - p1);
+    float g = t0 * p0;
+    g += t1 * p1; g += t2 * p2; g += t1 * p3; g += t0 * p4;
+    w.G[HS] = g;
+#define HROW(i) ((HS + 1 + (i)) % 5)                    /* slot of row q - 4 + i */
+    const int r = q - 2;                               // cov row now complete (needs rows r-2 .. r+2 = q-4 .. q)
+    if (!FULL && r < y0 - 1) return true;              // uniform: still warming up
+    // SymmColumnFilter, symmetric: f0*S0 + delta, += f1*(S1 + S-1), += f2*(S2 + S-2)
+    float dx = t2 * w.H[HROW(2)] + 0.f;
+    dx += t1 * (w.H[HROW(3)] + w.H[HROW(1)]);
+    dx += t0 * (w.H[HROW(4)] + w.H[HROW(0)]);
+    // SymmColumnFilter, anti-symmetric (taps 0, 2, 1): delta, += 2*(S1 - S-1), += 1*(S2 - S-2)
+    float dy = 0.f;
+    dy += 2.f * (w.G[HROW(3)] - w.G[HROW(1)]);
+    dy += 1.f * (w.G[HROW(4)] - w.G[HROW(0)]);
+#undef HROW
+    float ca = dx * dx, cb = dx * dy, cc = dy * dy;
+    if (ring_tile) {                                   // uniform: this tile touches the left or right image edge
+        // a lane whose cov column lies outside the image takes the cov of the reflected column (BORDER_REFLECT_101 of the
+        // cov IMAGE, not of the source)
+        const float ua = __shfl(ca, ring_src), ub = __shfl(cb, ring_src), uc = __shfl(cc, ring_src);
+        if (ring_src != lx) { ca = ua; cb = ub; cc = uc; }
+    }
+    // box filter, row sums: (S[x-1] + S[x]) + S[x+1]; the neighbours by DPP wave shifts
+    float sa, sb, sc;
+    {   // six v_add_f32 with a DPP operand (left to the compiler: six DPP moves and three packed adds).  One asm block
+        // behind an s_nop 1: a register written by the previous two vector instructions must not be a DPP source, and
+        // the compiler's hazard recognizer does not look inside inline asm; inside the block every DPP source is older
+        float ta, tb, tc;
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "v_add_f32_dpp %1, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "v_add_f32_dpp %2, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "v_add_f32_dpp %3, %6, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "v_add_f32_dpp %4, %7, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "v_add_f32_dpp %5, %8, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+            : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(sa), "=&v"(sb), "=&v"(sc) : "v"(ca), "v"(cb), "v"(cc));
+    }
+    if (SHIFT_R) {
+        w.ra[0] = w.ra[1]; w.ra[1] = w.ra[2];
+        w.rb[0] = w.rb[1]; w.rb[1] = w.rb[2];
+        w.rc[0] = w.rc[1]; w.rc[1] = w.rc[2];
+    }
+    w.ra[RS] = sa; w.rb[RS] = sb; w.rc[RS] = sc;
+#define RROW(i) ((RS + 1 + (i)) % 3)                    /* slot of row sums r - 2 + i */
+    const int y = r - 1;                               // output row now complete (needs row sums y-1 .. y+1 = r-2 .. r)
+    if (!FULL && y < y0) return true;                  // uniform
+    const int gy = ty0 + y;
+    if (gy >= rows) return false;                      // uniform: rows below the image are nobody's
+    float a0 = w.ra[RROW(0)], a1 = w.ra[RROW(1)], a2 = w.ra[RROW(2)];
+    float b0 = w.rb[RROW(0)], b1 = w.rb[RROW(1)], b2 = w.rb[RROW(2)];
+    float c0 = w.rc[RROW(0)], c1 = w.rc[RROW(1)], c2 = w.rc[RROW(2)];
+    // BORDER_REFLECT_101 of the cov image in y: row -1 is row 1, row `rows` is row rows - 2 (the image's first and last
+    // row only; as real branches -- the empty asm keeps the compiler from turning them into selects on every row of
+    // every tile.  The sums of rows outside the image are never stored: only this row's operands change)
+    if (gy == 0 || gy == rows - 1) {                   // uniform
+        asm volatile("" ::: "memory");
+        if (rows > 1) {
+            if (gy == 0) { a0 = a2; b0 = b2; c0 = c2; }
+            if (gy == rows - 1) { a2 = a0; b2 = b0; c2 = c0; }
+        } else { a0 = a1; b0 = b1; c0 = c1; a2 = a1; b2 = b1; c2 = c1; }
+    }
+#undef RROW
+    // column sums: (rs[y-1] + rs[y]) + rs[y+1]
+    const float a = (a0 + a1) + a2, b = (b0 + b1) + b2, c = (c0 + c1) + c2;
+    const float m1 = a * c, m2 = b * b;
+    const float m3 = m1 - m2;
+    const float tr = a + c;
+    const float R = (float)((double)m3 - k * (double)tr * (double)tr);
+    sink(y, lx - 1, R, lx >= 1 && lx <= tw && gx < cols);   // every lane calls (wave-wide operations inside are fine)
+    return true;
+}
+
+template <int U, class Sink>
+__device__ __forceinline__ bool harris_block15(HarrisRow& w, const unsigned char* s_img, int q, int y0, int y1, int rows, int ty0,
+                                               int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
+                                               float t0, float t1, float t2, Sink& sink) {
+    if constexpr (U < HW_BLOCK) {
+        if (!harris_row<U % 5, HW_BLOCK == 15 ? U % 3 : 2, false, true, Sink, HW_BLOCK != 15>(w, s_img, q + U, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return false;
+        return harris_block15<U + 1>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink);
+    } else {
+        return true;
+    }
+}
+
 template <class Sink>
 __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
                                                  int tw, int y0, int y1, double k, Sink sink) {
@@ -122,94 +247,29 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
     const int lxc = col_used ? lx : 0;                 // idle lanes read a valid address
     const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
     const float t0 = 1.f * scale, t1 = 4.f * scale, t2 = 6.f * scale;   // tap_i = fl32(s_i * fl32(scale)), symmetric
-    // a lane whose cov column lies outside the image takes the cov of the reflected column (BORDER_REFLECT_101 of the
-    // cov IMAGE, not of the source: the derivative of a mirrored image has the other sign): gx = -1 <- gx = 1, gx = cols
-    // <- gx = cols - 2 (lanes two up / two down; one for a one-column image)
+    // gx = -1 <- gx = 1, gx = cols <- gx = cols - 2 (lanes two up / two down; one for a one-column image)
     const bool ring_tile = tx0 == 0 || tx0 + tw == cols;
     const int ring_src = (gx == -1 || gx == cols) ? lx + (h_reflect101(gx, cols) - gx) : lx;
-    float H[5], G[5];                                  // rows q-4 .. q of the two row passes
-    float ra[3], rb[3], rc[3];                         // box row sums of cov rows r-2 .. r
+    HarrisRow w;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { H[i] = 0.f; G[i] = 0.f; }
+    for (int i = 0; i < 5; ++i) { w.H[i] = 0.f; w.G[i] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ra[i] = 0.f; rb[i] = 0.f; rc[i] = 0.f; }
-    // the five bytes of the NEXT row are asked for before this row's arithmetic (the LDS round trip at the top of every
-    // row was exposed: the walk is one dependent chain per row)
-    unsigned char nb0, nb1, nb2, nb3, nb4;
+    for (int i = 0; i < 3; ++i) { w.ra[i] = 0.f; w.rb[i] = 0.f; w.rc[i] = 0.f; }
     {
         const unsigned char* p = s_img + (y0 - 3 + 3) * HW_PITCH + lxc;
-        nb0 = p[0]; nb1 = p[1]; nb2 = p[2]; nb3 = p[3]; nb4 = p[4];
+        uint32_t v; __builtin_memcpy(&v, p, 4);
+        w.nw = v; w.nb4 = p[4];
     }
-    for (int q = y0 - 3; q < y1 + 3; ++q) {            // row-pass row q (relative to ty0) = LDS row q + 3
-        const float p0 = (float)nb0, p1 = (float)nb1, p2 = (float)nb2, p3 = (float)nb3, p4 = (float)nb4;
-        {
-            const unsigned char* p = s_img + (min(q + 1, y1 + 2) + 3) * HW_PITCH + lxc;
-            nb0 = p[0]; nb1 = p[1]; nb2 = p[2]; nb3 = p[3]; nb4 = p[4];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { H[i] = H[i + 1]; G[i] = G[i + 1]; }
-        // RowFilter: k0*S0, += k1*S1, ... left to right.  Derivative taps -1,-2,0,2,1: small integers, exact in any order
-        H[4] = (p4 - p0) + 2.f * (p3 - p1);
-        float g = t0 * p0;
-        g += t1 * p1; g += t2 * p2; g += t1 * p3; g += t0 * p4;
-        G[4] = g;
-        const int r = q - 2;                           // cov row now complete (needs rows r-2 .. r+2 = q-4 .. q)
-        if (r < y0 - 1) continue;                      // uniform: still warming up
-        // SymmColumnFilter, symmetric: f0*S0 + delta, += f1*(S1 + S-1), += f2*(S2 + S-2)
-        float dx = t2 * H[2] + 0.f;
-        dx += t1 * (H[3] + H[1]);
-        dx += t0 * (H[4] + H[0]);
-        // SymmColumnFilter, anti-symmetric (taps 0, 2, 1): delta, += 2*(S1 - S-1), += 1*(S2 - S-2)
-        float dy = 0.f;
-        dy += 2.f * (G[3] - G[1]);
-        dy += 1.f * (G[4] - G[0]);
-        float ca = dx * dx, cb = dx * dy, cc = dy * dy;
-        if (ring_tile) {                               // uniform: this tile touches the left or right image edge
-            const float ua = __shfl(ca, ring_src), ub = __shfl(cb, ring_src), uc = __shfl(cc, ring_src);
-            if (ring_src != lx) { ca = ua; cb = ub; cc = uc; }
-        }
-        // box filter, row sums: (S[x-1] + S[x]) + S[x+1]; the neighbours by DPP wave shifts (one instruction each, folded
-        // into the adds by the compiler; a ds_bpermute shuffle costs four)
-        float sa, sb, sc;
-        {   // six v_add_f32 with a DPP operand (left to the compiler: six DPP moves and three packed adds).  One asm block
-            // behind an s_nop 1: a register written by the previous two vector instructions must not be a DPP source, and
-            // the compiler's hazard recognizer does not look inside inline asm; inside the block every DPP source is older
-            float ta, tb, tc;
-            asm("s_nop 1\n\t"
-                "v_add_f32_dpp %0, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %1, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %2, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %3, %6, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %4, %7, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %5, %8, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(sa), "=&v"(sb), "=&v"(sc) : "v"(ca), "v"(cb), "v"(cc));
-        }
-        ra[0] = ra[1]; ra[1] = ra[2]; ra[2] = sa;
-        rb[0] = rb[1]; rb[1] = rb[2]; rb[2] = sb;
-        rc[0] = rc[1]; rc[1] = rc[2]; rc[2] = sc;
-        const int y = r - 1;                           // output row now complete (needs row sums y-1 .. y+1 = r-2 .. r)
-        if (y < y0) continue;                          // uniform
-        const int gy = ty0 + y;
-        if (gy >= rows) break;                         // uniform: rows below the image are nobody's
-        // BORDER_REFLECT_101 of the cov image in y: row -1 is row 1, row `rows` is row rows - 2
-        // (the image's first and last row only; as real branches — the empty asm keeps the compiler from turning them
-        // into selects on every row of every tile.  The overwritten sums belong to rows outside the image: dead)
-        if (gy == 0 || gy == rows - 1) {                   // uniform
-            asm volatile("" ::: "memory");
-            if (rows > 1) {
-                if (gy == 0) { ra[0] = ra[2]; rb[0] = rb[2]; rc[0] = rc[2]; }
-                if (gy == rows - 1) { ra[2] = ra[0]; rb[2] = rb[0]; rc[2] = rc[0]; }
-            } else { ra[0] = ra[1]; rb[0] = rb[1]; rc[0] = rc[1]; ra[2] = ra[1]; rb[2] = rb[1]; rc[2] = rc[1]; }
-        }
-        // column sums: (rs[y-1] + rs[y]) + rs[y+1]
-        const float a = (ra[0] + ra[1]) + ra[2], b = (rb[0] + rb[1]) + rb[2], c = (rc[0] + rc[1]) + rc[2];
-        const float m1 = a * c, m2 = b * b;
-        const float m3 = m1 - m2;
-        const float tr = a + c;
-        const float R = (float)((double)m3 - k * (double)tr * (double)tr);
-        sink(y, lx - 1, R, lx >= 1 && lx <= tw && gx < cols);   // every lane calls (wave-wide operations inside are fine)
-    }
+    int q = y0 - 3;                                    // row-pass row q (relative to ty0) = LDS row q + 3
+    // warm-up: four rows that only feed the row passes, two that also produce row sums (rolled code, shifting windows)
+    for (; q < y0 + 3 && q < y1 + 3; ++q)
+        if (!harris_row<4, 2, true, false>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+    // steady state: blocks of 15 unrolled rows on rings
+    for (; q + HW_BLOCK <= y1 + 3; q += HW_BLOCK)
+        if (!harris_block15<0>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+    // remainder (tiles whose height is not a multiple of 15)
+    for (; q < y1 + 3; ++q)
+        if (!harris_row<4, 2, true, true>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
 }
 
 // ---- cv::cornerHarris as an image (plain API, and bins too large for the fused detector) -----------------------
@@ -423,13 +483,18 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
 // pass, and neither the response image nor the bin's responses ever exist in memory.  Per image the HBM traffic is the
 // uint8 pixels in (+ halo re-reads from L2) and the corners out.
 #define HD_CAND 256   // candidate keys per wave; a row appends at most HW_MAXW
-__device__ __forceinline__ int harris_keep_best(unsigned long long* list, int n, int per, unsigned long long& tau) {
-    // the `per` largest of list[0..n) to list[0..per) (descending), tau = the smallest kept (0 if fewer than `per`)
+// The `per` largest of list[0..n) stay in list[0..kept) (descending if `sorted`), tau = the smallest kept (0 if fewer than `per`).
+// Called when the wave's candidate list is nearly full (a few times per bin) and once at the end of the bin.
+//
+// Round 4 picked the maximum `per` times (wave-wide 64-bit max, then removing it: ~55 vector instructions per pick, ~600
+// per call: a fifth of the kernel's instructions).  Now the per-th largest HIGH word (|response| bits) is found bit by
+// bit from the top -- 31 steps of four compares whose ballots are counted on the scalar unit -- and everything at or
+// above it is compacted: ~190 vector instructions.  Keys that share the threshold's high word are decided by their low
+// words (push order): when more of them exist than places are left, the old pick-by-pick loop runs (rare: equal
+// |response| bits).  The walk only tests the high word of tau, so the set kept here is the exact top `per`.
+struct HarrisKept { unsigned long long tau; int n; };
+__device__ __forceinline__ HarrisKept harris_keep_best_picks(unsigned long long (&mine)[HD_CAND / 64], unsigned long long* list, int per) {
     const int lane = threadIdx.x & 63;
-    unsigned long long mine[HD_CAND / 64];
-#pragma unroll
-    for (int u = 0; u < HD_CAND / 64; ++u) mine[u] = (lane + 64 * u < n) ? list[lane + 64 * u] : 0ull;
-    __builtin_amdgcn_wave_barrier();
     int kept = 0;
     unsigned long long last = 0;
     for (int round = 0; round < per; ++round) {
@@ -445,8 +510,73 @@ __device__ __forceinline__ int harris_keep_best(unsigned long long* list, int n,
         ++kept;
     }
     __builtin_amdgcn_wave_barrier();
-    tau = kept == per ? last : 0ull;
-    return kept;
+    HarrisKept out;
+    out.tau = kept == per ? last : 0ull;
+    out.n = kept;
+    return out;
+}
+
+__device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list, int n, int per, bool sorted) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long mine[HD_CAND / 64];
+#pragma unroll
+    for (int u = 0; u < HD_CAND / 64; ++u) mine[u] = (lane + 64 * u < n) ? list[lane + 64 * u] : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    HarrisKept out;
+    if (n <= per && !sorted) {                              // uniform: nothing to drop, nothing to order
+        out.n = n;
+        out.tau = 0ull;
+        if (n == per) {                                     // the smallest key is the threshold
+            unsigned long long mn = mine[0] ? mine[0] : ~0ull;
+            mn = ~wave_max_u64(~mn);
+            out.tau = mn;
+        }
+        return out;
+    }
+    uint32_t hi[HD_CAND / 64];
+#pragma unroll
+    for (int u = 0; u < HD_CAND / 64; ++u) hi[u] = (uint32_t)(mine[u] >> 32);
+    // T = the per-th largest high word (0 when fewer than `per` keys exist): greatest T with #(hi >= T) >= per
+    uint32_t T = 0;
+    for (int bit = 30; bit >= 0; --bit) {                   // |response| bits: the sign bit is clear
+        const uint32_t cand = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < HD_CAND / 64; ++u) cnt += __popcll(__ballot(hi[u] >= cand));
+        if (cnt >= per) T = cand;                           // uniform
+    }
+    int greater = 0, ties = 0;
+#pragma unroll
+    for (int u = 0; u < HD_CAND / 64; ++u) {
+        greater += __popcll(__ballot(hi[u] > T && mine[u] != 0ull));
+        ties += __popcll(__ballot(hi[u] == T && mine[u] != 0ull));
+    }
+    if (T != 0 && greater + ties > per) return harris_keep_best_picks(mine, list, per);   // uniform: the low words decide among the ties
+    // compaction of everything at or above T (T == 0: fewer than `per` keys, all stay)
+    int base = 0;
+#pragma unroll
+    for (int u = 0; u < HD_CAND / 64; ++u) {
+        const bool take = mine[u] != 0ull && hi[u] >= T;
+        const unsigned long long m = __ballot(take);
+        const int at = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (take) list[at] = mine[u];
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    out.n = base;
+    out.tau = base == per ? ((unsigned long long)T << 32) : 0ull;   // the walk tests the high word only
+    if (sorted && base > 1) {                               // descending: every key to the place its rank says (base <= HD_MAXPER <= 64)
+        const unsigned long long key = lane < base ? list[lane] : 0ull;
+        int rank = 0;
+        for (int j = 0; j < base; ++j) {
+            const unsigned long long kj = __shfl(key, j);
+            rank += kj > key ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < base) list[rank] = key;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return out;
 }
 
 __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, const uint8_t* __restrict__ images, double k) {
@@ -481,12 +611,13 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
             n += __popcll(m);
             if (n > HD_CAND - 64) {                        // uniform: the next row might not fit
                 __builtin_amdgcn_wave_barrier();
-                n = harris_keep_best(list, n, per, tau);
+                const HarrisKept kb = harris_keep_best(list, n, per, false);
+                n = kb.n; tau = kb.tau;
             }
         }
     });
     __builtin_amdgcn_wave_barrier();
-    n = harris_keep_best(list, n, per, tau);
+    { const HarrisKept kb = harris_keep_best(list, n, per, true); n = kb.n; tau = kb.tau; }
     const BinEmit emit{a, ((size_t)img * nbins + bin) * a.per, tx0, ty0};
     for (int i = 0; i < n; ++i) emit(i, list[i]);
     if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
