@@ -3,7 +3,7 @@
 # Harris] -> descriptors -> matcher -> solver; the program directly behind `--`)
 TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-Q="--streams 1 --e2e-streams 1 --no-cpu --no-streaming --no-e2e --steps 12 --warmup 2 --min-region-seconds 0"
+Q="--streams 1 --e2e-streams 1 --no-cpu --no-streaming --no-e2e --no-i16 --steps 12 --warmup 2 --min-region-seconds 0"
 rocprofv3 --kernel-trace --stats -d gpurun_out/img_stats -o s --output-format csv -- python3 bench.py $Q > gpurun_out/img_stats_bench.json 2>gpurun_out/img_stats.err &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/img_fetch -o p --output-format csv -- python3 bench.py $Q > /dev/null 2>gpurun_out/img_fetch.err &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/img_write -o p --output-format csv -- python3 bench.py $Q > /dev/null 2>gpurun_out/img_write.err &&

@@ -3,10 +3,10 @@
 #   2. kernel-trace stats of the same workload with ONE stream: per-kernel averages that fit inside the step
 #   3./4. the two HBM-traffic counter passes (separate runs, one stream)
 # then: python3 tools/pmc_to_json.py gpurun_out/prof_fetch gpurun_out/prof_write <kernel> > profiles/<round>_pmc_hbm.json
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-Q="--no-cpu --no-e2e --no-streaming --no-images"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o s --output-format csv -- python3 bench.py --no-cpu --no-streaming --no-images > gpurun_out/prof_stats_bench.json 2>gpurun_out/prof_stats.err &&
+Q="--no-cpu --no-e2e --no-streaming --no-images --no-i16"   # matcher step only (--no-e2e also leaves the drop-in leg out)
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o s --output-format csv -- python3 bench.py --no-cpu --no-streaming --no-images --no-i16 --no-drop-in > gpurun_out/prof_stats_bench.json 2>gpurun_out/prof_stats.err &&
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats1 -o s --output-format csv -- python3 bench.py --streams 1 $Q > gpurun_out/prof_stats1_bench.json 2>gpurun_out/prof_stats1.err &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 --min-region-seconds 0 $Q > /dev/null 2>gpurun_out/prof_fetch.err &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o p --output-format csv -- python3 bench.py --streams 1 --steps 4 --warmup 1 --min-region-seconds 0 $Q > /dev/null 2>gpurun_out/prof_write.err &&

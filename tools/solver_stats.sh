@@ -2,4 +2,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONPATH=.
 rocprofv3 --kernel-trace --stats -d gpurun_out/solverstats -o s --output-format csv -- python3 tools/host_issue_cost.py ${1:-512} 0 1 > gpurun_out/solverstats.txt 2>&1
-head -22 gpurun_out/solverstats/s_kernel_stats.csv | cut -c1-100
+python3 tools/kstats_table.py gpurun_out/solverstats/s_kernel_stats.csv 22
