@@ -38,4 +38,4 @@ def test_counter_files_name_their_own_command():
     import json
     for p in glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_images.json")):
         d = json.load(open(p))
-        assert "image" in d["workload"] and "--no-e2e --steps 12" in d["command"], p
+        assert "image" in d["workload"] and "--no-e2e" in d["command"] and "--steps 12" in d["command"] and "image_profile" in d["command"], p
