@@ -219,3 +219,77 @@ def test_frames_of_changing_size_and_empty_images(viso, oracle):
     for t in range(9):
         nL, nR = s["n"][t]
         assert np.array_equal(o["matches"][0][t], oracle.match_desc(s["kp"][t, 0, :nL], s["kp"][t, 1, :nR], s["desc"][t, 0, :nL], s["desc"][t, 1, :nR], st))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_shuffled_and_perturbed_call_sequences_always_get_their_own_results(viso, oracle, seed):
+    """The frame logic guesses which call comes next; this feeds it sequences that are ALMOST the loop's -- calls left out,
+    repeated, out of order, with perturbed arguments, scene cuts, frames of other sizes -- and checks every single result
+    against the oracle.  Whatever was computed ahead may only be handed out for byte-identical arguments."""
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(True)
+    rng = np.random.default_rng(seed)
+    seqs = [synth.make_sequence(40 + seed, 26, n_kp=360, width=500, height=180, ragged=True),
+            synth.make_sequence(90 + seed, 26, n_kp=300, width=500, height=180)]
+    F, prm = seqs[0]["F"], seqs[0]["param"]
+    st, tm = MatchParams.stereo(F), MatchParams.temporal()
+    prev = None
+    which = 0
+    for t in range(26):
+        if rng.random() < 0.12:
+            which ^= 1                                         # scene cut: the other sequence's frame t
+        s = seqs[which]
+        nL, nR = s["n"][t]
+        kp1, kp2 = s["kp"][t, 0, :nL].copy(), s["kp"][t, 1, :nR].copy()
+        d1, d2 = s["desc"][t, 0, :nL].copy(), s["desc"][t, 1, :nR].copy()
+        if rng.random() < 0.1 and prev is not None:            # a temporal call BEFORE the frame's stereo call
+            got = libviso_amd.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm)
+            assert np.array_equal(got, oracle.match_desc(kp1, prev["kp1"], d1, prev["d1"], tm))
+        lr = libviso_amd.match_desc(kp1, kp2, d1, d2, st)
+        assert np.array_equal(lr, oracle.match_desc(kp1, kp2, d1, d2, st)), t
+        cur = {"kp1": kp1, "kp2": kp2, "d1": d1, "d2": d2, "lr": lr}
+        lr_used = lr
+        if rng.random() < 0.2 and len(lr) > 4:                 # collect on a shortened list
+            lr_used = lr[:-2].copy()
+        if rng.random() < 0.85:
+            x = libviso_amd.collect_matches(kp1, kp2, lr_used)
+            assert np.array_equal(x, oracle.collect_matches(kp1, kp2, lr_used)), t
+        else:
+            x = oracle.collect_matches(kp1, kp2, lr_used)       # the call left out
+        p = prm
+        if rng.random() < 0.15:
+            p = type(prm).from_buffer_copy(prm); p.f = prm.f * 1.01
+        X = libviso_amd.triangulate_rectified(x, p)
+        assert np.array_equal(X, oracle.triangulate_rectified(x, p)), t
+        if rng.random() < 0.2:                                  # and once more
+            assert np.array_equal(libviso_amd.triangulate_rectified(x, prm), oracle.triangulate_rectified(x, prm)), t
+        cur["X"] = oracle.triangulate_rectified(oracle.collect_matches(kp1, kp2, lr), prm)
+        if prev is not None:
+            order = [0, 1] if rng.random() < 0.8 else [1, 0]     # right before left
+            res = {}
+            for w in order:
+                a, b = (("kp1", "d1") if w == 0 else ("kp2", "d2"))
+                q_kp, q_d = cur[a], cur[b]
+                if rng.random() < 0.1:
+                    q_d = q_d.copy(); q_d[rng.integers(len(q_d)), rng.integers(121)] += 2
+                res[w] = libviso_amd.match_desc(q_kp, prev[a], q_d, prev[b], tm)
+                assert np.array_equal(res[w], oracle.match_desc(q_kp, prev[a], q_d, prev[b], tm)), (t, w)
+            m11, m22 = res[0], res[1]
+            lrp = prev["lr"]
+            if rng.random() < 0.15 and len(lrp) > 3:
+                lrp = lrp[1:].copy()
+            _, circ, pcl, n = libviso_amd.match_circle(lr, lrp, m11, m22)
+            _, c_o, p_o, n_o = oracle.match_circle(lr, lrp, m11, m22)
+            assert n == n_o and np.array_equal(circ, c_o) and np.array_equal(pcl, p_o), t
+            if n >= 3 and lrp is prev["lr"] and lr_used is lr:
+                x_full = oracle.collect_matches(kp1, kp2, lr)
+                x_c, Xp_c = np.ascontiguousarray(x_full[:, pcl[:, 0]]), np.ascontiguousarray(prev["X"][:, pcl[:, 1]])
+                frame = t if rng.random() < 0.85 else t + 7
+                r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, prm, seed=9, frame=frame)
+                r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xp_c, x_c, prm, seed=9, frame=frame)
+                assert r_a == r_o and np.array_equal(inl_a, inl_o), t
+                if r_o:
+                    assert rel_fro(libviso_amd.tr2mat(tr_a), oracle.tr2mat(tr_o)) < POSE_TOL
+        prev = cur
+    st_ = drop_in.plain_stats()
+    assert st_["served"][0] + st_["served"][1] > 0              # the frame logic did take part
