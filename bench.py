@@ -6,7 +6,12 @@ already resident in HBM: by default BASELINE.json configs[1] (1241x376,
 ~2k features/frame, SAD matcher only = pack + 3 match_desc per frame incl. the
 final sort).  The same JSON line also carries
 
+  resident_i16 the same matcher step with the descriptors resident as int16 rows
+               (the step without the f32 -> u16 + u8 repack of the CV_32F boundary)
   end_to_end   configs[2]: matcher + circle join + RANSAC/Gauss-Newton
+  drop_in_per_call  the LITERAL drop-in path: the reference's sequence_odometry
+               loop calling the plain C-ABI one function per call, one frame
+               at a time, host pointers in and out (C++ loop, libviso_host.so)
   streaming    every step consumes FRESH host frames through pinned asynchronous
                uploads (feature-in and image-in): the PCIe-inclusive rate
   roofline     the dominant kernel against the ceilings that can bound it, each

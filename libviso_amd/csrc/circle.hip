@@ -40,24 +40,6 @@ __device__ __forceinline__ int circle_row(const CircleArgs& a, int i, int off) {
     return n;
 }
 
-__device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* scratch) {
-    // 256 threads = 4 waves; scratch: 8 ints of LDS
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) scratch[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += scratch[w];
-    *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-    __syncthreads();
-    return base + incl - v;
-}
-
 // ------------------------------------------------------------------ plain family: tables when the keys allow it
 // viso_match_circle for the lists match_desc produces: at most one row per query index in match11 (key [0]), match_lr_prev
 // (key [0]) and match22 (key [0]), so every hop of the reference's nested loops (:215-240) hits at most one row and the
