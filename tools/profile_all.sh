@@ -11,6 +11,7 @@ bash tools/image_profile.sh $TAG > gpurun_out/${TAG}_image_profile.log 2>&1 && e
 bash tools/ransac_alone.sh 512 > gpurun_out/${TAG}_ransac_alone.txt 2>gpurun_out/${TAG}_ransac_alone.err && echo "ransac_alone ok" &&
 bash tools/image_alone.sh > gpurun_out/${TAG}_image_kernels_alone.txt 2>gpurun_out/${TAG}_image_alone.err && echo "image_alone ok" &&
 python3 tools/dropin_probe.py 257 2000 > gpurun_out/${TAG}_drop_in.txt 2>&1 && echo "drop_in ok" &&
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/dropin_stats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/dropin_probe.py 257 2000 > $GRAFT_REPO_ROOT/gpurun_out/dropin_stats.txt 2>&1) && cp gpurun_out/dropin_stats/s_kernel_stats.csv gpurun_out/${TAG}_kernel_stats_drop_in.csv && echo "drop_in stats ok" &&
 ./tools/h2d_probe > gpurun_out/${TAG}_h2d_probe.txt 2>&1 && echo "h2d_probe ok" &&
 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err && echo "bench default ok" &&
 python3 bench.py --force-collective --no-cpu --no-streaming --no-images > gpurun_out/${TAG}_bench_rccl_1rank.json 2> gpurun_out/${TAG}_bench_rccl.err && echo "bench rccl ok" &&
