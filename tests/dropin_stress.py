@@ -1,0 +1,27 @@
+"""One-off stress of the per-call loop (GPU box): 240 frames whose keypoint counts jump between 0 and 1400 (frame blocks and\nimage slots re-laid out again and again), every cache / speculation mode, ok / inlier counts / poses against the oracle.\nTest infrastructure (imports oracle/): lives under tests/; not collected by pytest.  python tests/dropin_stress.py"""
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+import libviso_amd
+from libviso_amd import synth, drop_in
+from libviso_amd.abi import MatchParams
+from oracle import pyoracle as O
+rng = np.random.default_rng(5)
+nf = 240
+s = synth.make_sequence(321, nf, n_kp=1400, width=900, height=300, ragged=True)
+# wild size changes: shrink some frames a lot, empty a few
+for t in range(nf):
+    r = rng.random()
+    if r < 0.1: s["n"][t] = rng.integers(3, 60, 2)
+    elif r < 0.2: s["n"][t] = rng.integers(60, 400, 2)
+    elif r < 0.22: s["n"][t, rng.integers(2)] = 0
+st, tm = MatchParams.stereo(s["F"]), MatchParams.temporal()
+for mode in ((True, True), (False, True), (True, False)):
+    drop_in.plain_cache(mode[0]); drop_in.plain_speculate(mode[1])
+    o = drop_in.run(s["kp"], s["desc"], s["n"], s["F"], s["param"], seed=4, first_frame=10)
+    if mode == (True, True):
+        want = O.sequence(s["kp"], s["desc"], s["n"], st, tm, s["param"], seed=4, first_frame=10)
+    assert np.array_equal(o["ok"], want["ok"]), mode
+    assert np.array_equal(o["n_inl"], want["n_inl"]), mode
+    err = np.abs(o["tr"][want["ok"] == 1] - want["tr"][want["ok"] == 1]).max()
+    print(mode, "ok", int(o["ok"].sum()), "of", nf, "max |tr - oracle|", err, drop_in.plain_stats())
+print("stress ok")
