@@ -173,6 +173,8 @@ struct PlainFrame {
     int n_circ;                            // rows of the join (host, once B has been waited for)
     viso_param rs_p; uint64_t rs_seed, rs_frame;
     hipEvent_t evA;                        // behind the first part's copy-out
+    hipEvent_t evJ;                        // behind the join's copy-out (match_circle waits for this one only; the RANSAC stage runs on)
+    bool pending_J;
 };
 struct PlainCache {
     PlainSlot slot[PLAIN_SLOTS];
@@ -191,6 +193,7 @@ struct PlainCache {
     unsigned long long frame_no, circ_seen_no; int circ_seen_cnt;
     bool rs_known, rs_pattern, rs_delta_stable;   // ransac's param / seed seen; the call fitted; the stream key advances regularly
     viso_param rs_p; uint64_t rs_seed, rs_last_frame, rs_delta;
+    hipStream_t side; hipEvent_t side_ev;  // a call's SECOND new image is brought in on a stream of its own, beside the first
     int good_streak;                       // launches in a row whose images all fitted the u16 rows
     long long general_reruns;
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
@@ -252,10 +255,13 @@ void plain_cache_free(viso_ctx* c) {
         if (c->plain->slot[i].pin) (void)hipHostFree(c->plain->slot[i].pin);
         if (c->plain->slot[i].dev) (void)hipFree(c->plain->slot[i].dev);
     }
+    if (c->plain->side) { (void)hipStreamSynchronize(c->plain->side); (void)hipStreamDestroy(c->plain->side); }
+    if (c->plain->side_ev) (void)hipEventDestroy(c->plain->side_ev);
     for (int i = 0; i < 3; ++i) {
         if (c->plain->frame[i].host) (void)hipHostFree(c->plain->frame[i].host);
         if (c->plain->frame[i].dev) (void)hipFree(c->plain->frame[i].dev);
         if (c->plain->frame[i].evA) (void)hipEventDestroy(c->plain->frame[i].evA);
+        if (c->plain->frame[i].evJ) (void)hipEventDestroy(c->plain->frame[i].evJ);
     }
     free(c->plain);
     c->plain = nullptr;
@@ -270,7 +276,7 @@ extern "C" int viso_plain_cache(int enable) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     pc->enabled = enable != 0;
     for (int i = 0; i < PLAIN_SLOTS; ++i) pc->slot[i].valid = false;
-    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; }
+    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; pc->frame[i].pending_J = false; }
     return VISO_OK;
 }
 
@@ -282,7 +288,7 @@ extern "C" int viso_plain_speculate(int enable) {
     if (!pc) { viso_set_error("viso_plain_speculate: out of memory"); return VISO_ERR_NOMEM; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     pc->speculate = enable != 0;
-    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; }
+    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; pc->frame[i].pending_J = false; }
     pc->tm_pattern = pc->x_pattern = pc->circ_pattern = pc->rs_pattern = pc->rs_delta_stable = false;
     return VISO_OK;
 }
@@ -340,7 +346,7 @@ extern "C" void viso_plain_trace_dump(void) {
 // The slot that holds (kp, d) -- found by comparing bytes, or filled now: shadow copy, ONE upload of kp | desc | hdr.
 // `keep` is a slot that must not be evicted (the call's other image), -1 for none.
 static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const float* d, int n, int dlen, int extras, int r8s,
-                         int keep, bool* hit) {
+                         int keep, bool* hit, hipStream_t stream) {
     const size_t kb = sizeof(float2) * (size_t)n, db = sizeof(float) * (size_t)n * dlen;
     *hit = false;
     if (pc->enabled)
@@ -408,13 +414,13 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     hdr[0] = n;
     hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
     memcpy(s.pin + o_hdr + 64, &v, sizeof(v));   // the image's view, where sort_kp_kernel / pack_desc_kernel find it
-    int r = plain_blit(c->stream, s.pin, s.dev, o_desc / 4);
+    int r = plain_blit(stream, s.pin, s.dev, o_desc / 4);
     if (r < 0) return r;
     big_copy(s.pin + o_desc, d, db);
     const double ta1 = g_tr_on > 0 ? tr_now() : 0;
     const ImageView* dview = reinterpret_cast<const ImageView*>(s.dev + o_hdr + 64);
-    if ((r = launch_sort_kp(c->stream, dview, 1, n > 0 ? n : 1)) < 0) return r;
-    if (dlen <= VISO_ROW && (r = launch_pack(c->stream, dview, 1, n > 0 ? n : 1, dlen, nullptr, const_cast<int*>(v.bad), extras, r8s, nullptr)) < 0) return r;
+    if ((r = launch_sort_kp(stream, dview, 1, n > 0 ? n : 1)) < 0) return r;
+    if (dlen <= VISO_ROW && (r = launch_pack(stream, dview, 1, n > 0 ? n : 1, dlen, nullptr, const_cast<int*>(v.bad), extras, r8s, nullptr)) < 0) return r;
     if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
     s.n = n; s.dlen = dlen; s.extras = extras; s.r8s = r8s;
     s.bad_host = dlen > VISO_ROW ? 1 : -1;
@@ -494,6 +500,7 @@ static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
         f.host_bytes = want;
     }
     if (!f.evA) HIP_TRY(hipEventCreateWithFlags(&f.evA, hipEventDisableTiming));
+    if (!f.evJ) HIP_TRY(hipEventCreateWithFlags(&f.evJ, hipEventDisableTiming));
     f.cap = cap;
     return VISO_OK;
 }
@@ -507,10 +514,18 @@ static void frame_reset(PlainFrame& f) {
 }
 
 // the second part of a frame's chain has finished: its counters are in the mirror
+static int frame_wait_J(PlainFrame& f) {   // the join (and the gathered columns) are in the mirror
+    if (!f.pending_J) return VISO_OK;
+    HIP_TRY(hipEventSynchronize(f.evJ));
+    f.pending_J = false;
+    const int* om = reinterpret_cast<const int*>(f.host);
+    f.n_circ = om[32];
+    return VISO_OK;
+}
 static int frame_wait_B(viso_ctx* c, PlainFrame& f) {
     if (!f.pending_B) return VISO_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    f.pending_B = false;
+    f.pending_B = false; f.pending_J = false;
     const int* om = reinterpret_cast<const int*>(f.host);
     f.n_circ = om[32];
     return VISO_OK;
@@ -566,11 +581,27 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     if (g_tr_on < 0) { const char* e = getenv("VISO_PLAIN_TRACE"); g_tr_on = e && *e == '1'; }
     double tt[7] = {0, 0, 0, 0, 0, 0, 0};
     if (g_tr_on) tt[0] = tr_now();
-    const int iq = plain_acquire(c, pc, kp1, d1, n1, dlen, extras, r8s, -1, &hit_q);
+    const int iq = plain_acquire(c, pc, kp1, d1, n1, dlen, extras, r8s, -1, &hit_q, s);
     if (iq < 0) return iq;
     if (g_tr_on) tt[1] = tr_now();
-    const int it = plain_acquire(c, pc, kp2, d2, n2, dlen, extras, r8s, iq, &hit_t);
+    // When the first image had to be brought in, a second new one goes through a stream of its own: copy kernel, sort_kp_kernel
+    // and pack_desc_kernel of the two images are independent chains (50 us each, the pack kernels pulling their rows over
+    // PCIe), and the first is already running while the host copies the second into its shadow.  The context's stream waits
+    // for the side stream's event before the matcher; nothing else ever runs there, and every call ends behind that wait.
+    hipStream_t s2 = s;
+    if (!hit_q) {
+        if (!pc->side) {
+            HIP_TRY(hipStreamCreateWithFlags(&pc->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&pc->side_ev, hipEventDisableTiming));
+        }
+        s2 = pc->side;
+    }
+    const int it = plain_acquire(c, pc, kp2, d2, n2, dlen, extras, r8s, iq, &hit_t, s2);
     if (it < 0) return it;
+    if (s2 != s && !hit_t) {
+        HIP_TRY(hipEventRecord(pc->side_ev, s2));
+        HIP_TRY(hipStreamWaitEvent(s, pc->side_ev, 0));
+    }
     if (g_tr_on) tt[2] = tr_now();
     const bool stereo_call = mp->enforce_epipolar != 0;
     // ---- a temporal call the frame's stereo call has already answered?
@@ -778,10 +809,6 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
                            reinterpret_cast<const double*>(prv.dev + prv.o_X), prv.cap > 0 ? prv.cap : 1,
                            reinterpret_cast<double*>(f->dev + f->o_xc), reinterpret_cast<double*>(f->dev + f->o_Xpc), (int)C);
         HIP_TRY(hipGetLastError());
-        SolverParamsDev sp;
-        fill_solver_params(&sp, &f->rs_p);
-        if ((r = launch_ransac(s, reinterpret_cast<const SolverItem*>(f->dev + offsetof(FrameHead, rs)), 1, f->rs_p.ransac_iter, f->rs_seed, sp,
-                               rs_queue, c->gn_split ? c->gn_split : 1, cap)) < 0) return r;
         OutArgs ob{};
         int nr = 0;
         auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
@@ -790,16 +817,26 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
             ob.r[nr].cnt = cnt; ob.r[nr].row_words = row_words; ob.r[nr].max_rows = max_rows;
             ++nr;
         };
+        // the join and the gathered columns go out first, behind an event of their own: match_circle returns as soon as they are
+        // there, the RANSAC stage runs on behind the caller's gather loop
         region(f->o_misc + 128, nullptr, 8, 1);                          // misc[32..39]: the join's row count
         region(f->o_circ, dmisc + 32, 6, cap);
         for (int k = 0; k < 4; ++k) region(f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
         for (int k = 0; k < 3; ++k) region(f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
-        region(f->o_rs, nullptr, 32, 1);
-        region(f->o_rs + 128, reinterpret_cast<const int*>(f->dev + f->o_rs) + 2, 1, cap);
         const unsigned gx = (unsigned)((6 * C + 1023) / 1024);
         hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, ob);
         HIP_TRY(hipGetLastError());
-        f->have_B = true; f->pending_B = true;
+        HIP_TRY(hipEventRecord(f->evJ, s));
+        SolverParamsDev sp;
+        fill_solver_params(&sp, &f->rs_p);
+        if ((r = launch_ransac(s, reinterpret_cast<const SolverItem*>(f->dev + offsetof(FrameHead, rs)), 1, f->rs_p.ransac_iter, f->rs_seed, sp,
+                               rs_queue, c->gn_split ? c->gn_split : 1, cap)) < 0) return r;
+        nr = 0;
+        region(f->o_rs, nullptr, 32, 1);
+        region(f->o_rs + 128, reinterpret_cast<const int*>(f->dev + f->o_rs) + 2, 1, cap);
+        hipLaunchKernelGGL(plain_out_kernel, dim3((unsigned)((C + 1023) / 1024 ? (C + 1023) / 1024 : 1), nr), dim3(256), 0, s, ob);
+        HIP_TRY(hipGetLastError());
+        f->have_B = true; f->pending_B = true; f->pending_J = true;
     }
     if (g_tr_on) tt[4] = tr_now();
     pp.wait_begin();
@@ -817,7 +854,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         pc->good_streak = 0;
         if (!need_general) {   // unexpected: the launch had no kernel for them.  Everything it produced is dropped, the call repeated
             HIP_TRY(hipStreamSynchronize(s));
-            f->pending_B = false;
+            f->pending_B = false; f->pending_J = false;
             frame_reset(*f);
             pc->cur = saved_cur; pc->frame_no = saved_no;
             pc->general_reruns += 1;
@@ -890,7 +927,7 @@ int plain_try_circle(viso_ctx* c, const int32_t* lr, int n_lr, const int32_t* lr
     if (f.have[1] && f.have[2] && !full) return 0;
     pc->circ_pattern = true;   // the loop's call: the stereo lists of this frame and the last
     if (!f.have_B || !full) return 0;
-    if (frame_wait_B(c, f) < 0) return 0;
+    if (frame_wait_J(f) < 0) return 0;
     const int cnt = f.n_circ;
     if (cnt < 0 || cnt > f.cap) return 0;
     const int w = cnt < cap ? cnt : cap;
