@@ -28,6 +28,7 @@
 // No intermediate image (Dx, Dy, cov, row sums) ever exists in memory; per output pixel the walk costs ~75 vector
 // instructions plus 6 / rows_per_band of warm-up.
 #define HW_MAXW 62                  // tile width limit: tw + 2 ring columns = one wave
+#define HW_DIRECT_MAXW 58         // widest bin the LDS-free walk takes: tw + 6 pixel columns on 64 lanes
 #define HW_PITCH 72                 // LDS row pitch of the uint8 tile (tw + 6 <= 68 used)
 #define HW_THREADS 256
 
@@ -124,7 +125,18 @@ __device__ __forceinline__ float wave_shl1(float v) {
 struct HarrisRow {   // one lane's state of the walk
     float H[5], G[5];                                  // rows q-4 .. q of the two row passes (canonical order between blocks)
     float ra[3], rb[3], rc[3];                         // box row sums of cov rows r-2 .. r
-    uint32_t nw; uint32_t nb4;                         // the NEXT row's five bytes: p0..p3 packed, p4
+    uint32_t nw; uint32_t nb4;                         // LDS source: the NEXT row's five bytes (p0..p3 packed, p4);
+                                                       // direct source: this lane's pixel of rows q and q + 1
+};
+// Where a row's pixels come from.  LDS source (s_img != null): the tile was loaded into LDS first, lane lx reads the five
+// bytes of its cov column.  DIRECT source (round 5, tiles of up to 58 columns): no tile in LDS at all -- lane l owns PIXEL
+// column tx0 - 3 + l, loads its one byte per row straight from the image (one 64-byte request per wave and row, two rows
+// ahead) and gets its four neighbours by wave shifts of the converted value: no tile-load phase, no LDS per wave beyond the
+// candidate list (8 instead of 5 waves per SIMD), one conversion per row instead of five.  Same arithmetic on the same
+// values: the cov column of lane l is pixel column tx0 - 3 + l, i.e. logical lane lx = l - 2 of the LDS layout.
+struct HarrisSrc {
+    const unsigned char* s_img;   // LDS tile, or null
+    __amdgpu_buffer_rsrc_t rsrc; int pcol;   // direct: the image as a raw buffer (rows * cols bytes), this lane's (reflected) pixel column
 };
 
 // HS / RS: ring slot the new row-pass row / the new row sums go to (the oldest of the window); in the rolled code both
@@ -134,16 +146,28 @@ struct HarrisRow {   // one lane's state of the walk
 #endif
 // (Measured and dropped, round 5: a second instantiation for tiles that touch no image edge -- no ring column, no cov row
 // to reflect, no row below the image: three uniform branches less per row -- 378 us either way.)
-template <int HS, int RS, bool SHIFT, bool FULL, class Sink, bool SHIFT_R = SHIFT>
-__device__ __forceinline__ bool harris_row(HarrisRow& w, const unsigned char* s_img, int q, int y0, int y1, int rows, int ty0,
+template <int HS, int RS, bool SHIFT, bool FULL, class Sink, bool SHIFT_R = SHIFT, bool DIRECT = false>
+__device__ __forceinline__ bool harris_row(HarrisRow& w, const HarrisSrc& src, int q, int y0, int y1, int rows, int ty0,
                                            int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
                                            float t0, float t1, float t2, Sink& sink) {
-    // (float)((dword >> 8 n) & 255) is what the backend selects v_cvt_f32_ubyte<n> for
-    const float p0 = (float)(w.nw & 255u), p1 = (float)((w.nw >> 8) & 255u), p2 = (float)((w.nw >> 16) & 255u),
-                p3 = (float)(w.nw >> 24), p4 = (float)(w.nb4 & 255u);
-    {   // the five bytes of the NEXT row are asked for before this row's arithmetic (the LDS round trip at the top of every
+    float p0, p1, p2, p3, p4;
+    if (DIRECT) {
+        p2 = (float)(w.nw & 255u);
+        w.nw = w.nb4;
+        {   // the pixel of row q + 2 is asked for before this row's arithmetic
+            const int gy = h_reflect101(ty0 + min(q + 2, y1 + 2), rows);
+            w.nb4 = __builtin_amdgcn_raw_buffer_load_b8(src.rsrc, src.pcol, gy * cols, 0);   // the row's offset rides in an SGPR: no address arithmetic
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p1 = wave_shr1(p2); p0 = wave_shr1(p1);            // lane l <- lane l - 1: the pixel one / two columns to the left
+        p3 = wave_shl1(p2); p4 = wave_shl1(p3);
+    } else {
+        // (float)((dword >> 8 n) & 255) is what the backend selects v_cvt_f32_ubyte<n> for
+        p0 = (float)(w.nw & 255u); p1 = (float)((w.nw >> 8) & 255u); p2 = (float)((w.nw >> 16) & 255u);
+        p3 = (float)(w.nw >> 24); p4 = (float)(w.nb4 & 255u);
+        // the five bytes of the NEXT row are asked for before this row's arithmetic (the LDS round trip at the top of every
         // row was exposed: the walk is one dependent chain per row)
-        const unsigned char* p = s_img + (min(q + 1, y1 + 2) + 3) * HW_PITCH + lxc;
+        const unsigned char* p = src.s_img + (min(q + 1, y1 + 2) + 3) * HW_PITCH + lxc;
         uint32_t v; __builtin_memcpy(&v, p, 4);
         w.nw = v; w.nb4 = p[4];
         __builtin_amdgcn_sched_barrier(0);
@@ -173,8 +197,8 @@ __device__ __forceinline__ bool harris_row(HarrisRow& w, const unsigned char* s_
     if (ring_tile) {                                   // uniform: this tile touches the left or right image edge
         // a lane whose cov column lies outside the image takes the cov of the reflected column (BORDER_REFLECT_101 of the
         // cov IMAGE, not of the source)
-        const float ua = __shfl(ca, ring_src), ub = __shfl(cb, ring_src), uc = __shfl(cc, ring_src);
-        if (ring_src != lx) { ca = ua; cb = ub; cc = uc; }
+        const float ua = __shfl(ca, ring_src), ub = __shfl(cb, ring_src), uc = __shfl(cc, ring_src);   // ring_src: a PHYSICAL lane
+        if (ring_src != (int)(threadIdx.x & 63)) { ca = ua; cb = ub; cc = uc; }
     }
     // box filter, row sums: (S[x-1] + S[x]) + S[x+1]; the neighbours by DPP wave shifts
     float sa, sb, sc;
@@ -226,36 +250,44 @@ __device__ __forceinline__ bool harris_row(HarrisRow& w, const unsigned char* s_
     return true;
 }
 
-template <int U, class Sink>
-__device__ __forceinline__ bool harris_block15(HarrisRow& w, const unsigned char* s_img, int q, int y0, int y1, int rows, int ty0,
+template <int U, bool DIRECT, class Sink>
+__device__ __forceinline__ bool harris_block15(HarrisRow& w, const HarrisSrc& s_img, int q, int y0, int y1, int rows, int ty0,
                                                int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
                                                float t0, float t1, float t2, Sink& sink) {
     if constexpr (U < HW_BLOCK) {
-        if (!harris_row<U % 5, HW_BLOCK == 15 ? U % 3 : 2, false, true, Sink, HW_BLOCK != 15>(w, s_img, q + U, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return false;
-        return harris_block15<U + 1>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink);
+        if (!harris_row<U % 5, HW_BLOCK == 15 ? U % 3 : 2, false, true, Sink, HW_BLOCK != 15, DIRECT>(w, s_img, q + U, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return false;
+        return harris_block15<U + 1, DIRECT>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink);
     } else {
         return true;
     }
 }
 
-template <class Sink>
-__device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
-                                                 int tw, int y0, int y1, double k, Sink sink) {
-    const int lx = threadIdx.x & 63;
+template <bool DIRECT, class Sink>
+__device__ __forceinline__ void harris_walk_band_impl(const unsigned char* s_img, const uint8_t* im, int rows, int cols, int tx0, int ty0,
+                                                      int tw, int y0, int y1, double k, Sink sink) {
+    const int lane = threadIdx.x & 63;
+    const int lx = DIRECT ? lane - 2 : lane;           // logical lane: cov column tx0 - 1 + lx
     const int gx = tx0 - 1 + lx;                       // this lane's cov column
-    const bool col_used = lx < tw + 2;
+    const bool col_used = lx >= 0 && lx < tw + 2;
     const int lxc = col_used ? lx : 0;                 // idle lanes read a valid address
     const float scale = (float)(1.0 / (16.0 * 3.0 * 255.0));
     const float t0 = 1.f * scale, t1 = 4.f * scale, t2 = 6.f * scale;   // tap_i = fl32(s_i * fl32(scale)), symmetric
     // gx = -1 <- gx = 1, gx = cols <- gx = cols - 2 (lanes two up / two down; one for a one-column image)
     const bool ring_tile = tx0 == 0 || tx0 + tw == cols;
-    const int ring_src = (gx == -1 || gx == cols) ? lx + (h_reflect101(gx, cols) - gx) : lx;
+    const int ring_src = (gx == -1 || gx == cols) ? lane + (h_reflect101(gx, cols) - gx) : lane;   // a physical lane
+    HarrisSrc src;
+    src.s_img = s_img;
+    if (DIRECT) src.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)im, 0, rows * cols, 0x00020000);
+    src.pcol = DIRECT ? h_reflect101(min(tx0 - 3 + lane, tx0 + tw + 2), cols) : 0;   // lanes past the tile's halo repeat its last column
     HarrisRow w;
 #pragma unroll
     for (int i = 0; i < 5; ++i) { w.H[i] = 0.f; w.G[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { w.ra[i] = 0.f; w.rb[i] = 0.f; w.rc[i] = 0.f; }
-    {
+    if (DIRECT) {
+        w.nw = __builtin_amdgcn_raw_buffer_load_b8(src.rsrc, src.pcol, h_reflect101(ty0 + y0 - 3, rows) * cols, 0);
+        w.nb4 = __builtin_amdgcn_raw_buffer_load_b8(src.rsrc, src.pcol, h_reflect101(ty0 + min(y0 - 2, y1 + 2), rows) * cols, 0);
+    } else {
         const unsigned char* p = s_img + (y0 - 3 + 3) * HW_PITCH + lxc;
         uint32_t v; __builtin_memcpy(&v, p, 4);
         w.nw = v; w.nb4 = p[4];
@@ -263,13 +295,18 @@ __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int
     int q = y0 - 3;                                    // row-pass row q (relative to ty0) = LDS row q + 3
     // warm-up: four rows that only feed the row passes, two that also produce row sums (rolled code, shifting windows)
     for (; q < y0 + 3 && q < y1 + 3; ++q)
-        if (!harris_row<4, 2, true, false>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_row<4, 2, true, false, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
     // steady state: blocks of 15 unrolled rows on rings
     for (; q + HW_BLOCK <= y1 + 3; q += HW_BLOCK)
-        if (!harris_block15<0>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_block15<0, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
     // remainder (tiles whose height is not a multiple of 15)
     for (; q < y1 + 3; ++q)
-        if (!harris_row<4, 2, true, true>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_row<4, 2, true, true, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+}
+template <class Sink>
+__device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
+                                                 int tw, int y0, int y1, double k, Sink sink) {
+    harris_walk_band_impl<false>(s_img, nullptr, rows, cols, tx0, ty0, tw, y0, y1, k, sink);
 }
 
 // ---- cv::cornerHarris as an image (plain API, and bins too large for the fused detector) -----------------------
@@ -579,6 +616,8 @@ __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list,
     return out;
 }
 
+// DIRECT: bins of up to HW_DIRECT_MAXW columns walk the image itself (HarrisSrc), the LDS holds candidate lists only
+template <bool DIRECT>
 __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, const uint8_t* __restrict__ images, double k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char h_smem[];
     const int nbins = a.nbinx * a.nbiny;
@@ -589,14 +628,17 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
     const int tx0 = (bin / a.nbiny) * a.stridex, ty0 = (bin % a.nbiny) * a.stridey;
     const int tw = a.stridex, th = a.stridey;              // bins never reach past the image: stride * nbin <= size
     const int per = a.per;
-    const size_t tile_bytes = ((size_t)(th + 6) * HW_PITCH + 15) & ~(size_t)15;
+    const size_t tile_bytes = DIRECT ? 0 : ((size_t)(th + 6) * HW_PITCH + 15) & ~(size_t)15;
     unsigned char* s_img = h_smem + (size_t)wave * (tile_bytes + HD_CAND * sizeof(unsigned long long));
     unsigned long long* list = reinterpret_cast<unsigned long long*>(s_img + tile_bytes);
-    harris_load_tile<1>(images + (size_t)img * a.rows * a.cols, a.rows, a.cols, tx0, ty0, tw, th, s_img);
-    __builtin_amdgcn_wave_barrier();
+    const uint8_t* im = images + (size_t)img * a.rows * a.cols;
+    if (!DIRECT) {
+        harris_load_tile<1>(im, a.rows, a.cols, tx0, ty0, tw, th, s_img);
+        __builtin_amdgcn_wave_barrier();
+    }
     unsigned long long tau = 0;
     int n = 0;
-    harris_walk_band(s_img, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool valid) {
+    harris_walk_band_impl<DIRECT>(s_img, im, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool valid) {
         // a candidate is everything above tau; the test is on the key's HIGH word (|response| bits) alone: the few pixels
         // that tie tau's high word come along and lose in harris_keep_best, and the 64-bit key (push position of the
         // reference's scan: x outer, y inner, :953-955) is only built for the lanes that store one
@@ -661,7 +703,7 @@ int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int 
 size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per) {
     const int sx = cols / nbinx, sy = rows / nbiny;
     if (sx <= 0 || sy <= 0 || sx > HW_MAXW || per > HD_MAXPER) return 0;
-    const size_t tile = ((size_t)(sy + 6) * HW_PITCH + 15) & ~(size_t)15;
+    const size_t tile = sx <= HW_DIRECT_MAXW ? 0 : ((size_t)(sy + 6) * HW_PITCH + 15) & ~(size_t)15;
     const size_t b = (HW_THREADS / 64) * (tile + HD_CAND * sizeof(unsigned long long));   // per wave: its bin's pixels + candidate keys
     return b <= 64 * 1024 ? b : 0;
 }
@@ -679,9 +721,14 @@ int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int ro
     const int nbins = nbinx * nbiny;
     const size_t lds = harris_fused_lds(rows, cols, nbinx, nbiny, a.per);
     if (!lds) { viso_set_error("harris: bin geometry does not fit the fused detector"); return VISO_ERR_UNSUPPORTED; }
-    if (lds > 32 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(harris_detect_kernel, dim3((unsigned)(((long long)n_img * nbins + HW_THREADS / 64 - 1) / (HW_THREADS / 64))), dim3(HW_THREADS), lds, s, a, images, k);
+    const dim3 grid((unsigned)(((long long)n_img * nbins + HW_THREADS / 64 - 1) / (HW_THREADS / 64)));
+    if (a.stridex <= HW_DIRECT_MAXW) {
+        hipLaunchKernelGGL(harris_detect_kernel<true>, grid, dim3(HW_THREADS), lds, s, a, images, k);
+    } else {
+        if (lds > 32 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(harris_detect_kernel<false>, grid, dim3(HW_THREADS), lds, s, a, images, k);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(harris_compact_kernel, dim3(n_img), dim3(256), sizeof(int) * (size_t)(nbins + 1), s, a, kp_out,
                        resp_out, n_out, cap, kp_stride);

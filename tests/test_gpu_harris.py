@@ -32,6 +32,32 @@ def test_detect_binned_bit_exact(viso, oracle):
     assert len(libviso_amd.detect_harris_binned(flat, 120, 6, 2)[0]) == 0 == len(oracle.detect_harris_binned(flat, 120, 6, 2)[0])
 
 
+# bin widths either side of the detector's two pixel sources (direct image walk up to 58 columns, LDS tile for 59..62),
+# bins that touch both image borders at once, bins a few rows / columns small, images narrower than a wave
+@pytest.mark.parametrize("shape,bx,by,per", [
+    ((376, 1241), 21, 5, 10),     # 59 columns: LDS tile
+    ((376, 1241), 20, 4, 12),     # 62 columns: LDS tile, the widest
+    ((376, 1241), 22, 5, 10),     # 56 columns
+    ((100, 58), 1, 2, 16),        # 58 columns: the widest direct bin, left and right border in one tile
+    ((64, 116), 2, 1, 20),
+    ((50, 40), 1, 1, 30),
+    ((30, 7), 1, 1, 5),
+    ((90, 200), 25, 3, 4),        # 8 columns
+    ((30, 64), 2, 10, 3),         # 3 rows per bin
+    ((33, 61), 1, 11, 2),         # 61 columns, both borders, LDS tile
+    ((47, 130), 3, 3, 32),        # per at the fused detector's cap
+    ((47, 130), 3, 3, 33),        # ... and past it (response image + per-bin selection)
+])
+def test_detect_binned_geometries_bit_exact(viso, oracle, shape, bx, by, per):
+    nf = per * bx * by
+    for seed in (3, 4, 5):
+        img = synth.make_images(seed, shape[0], shape[1])
+        k0, r0 = oracle.detect_harris_binned(img, nf, bx, by)
+        k1, r1 = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        assert np.array_equal(k0, k1) and np.array_equal(r0, r1)
+        assert len(k0) > 0
+
+
 def test_image_to_pose_pipeline(viso, oracle):
     seq = synth.make_image_sequence(9, 4, n_kp=1500)
     nf = 4
