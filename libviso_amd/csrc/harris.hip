@@ -149,13 +149,15 @@ struct HarrisSrc {
 template <int HS, int RS, bool SHIFT, bool FULL, class Sink, bool SHIFT_R = SHIFT, bool DIRECT = false>
 __device__ __forceinline__ bool harris_row(HarrisRow& w, const HarrisSrc& src, int q, int y0, int y1, int rows, int ty0,
                                            int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
-                                           float t0, float t1, float t2, Sink& sink) {
+                                           float t0, float t1, float t2, unsigned long long vmask, Sink& sink) {
     float p0, p1, p2, p3, p4;
     if (DIRECT) {
         p2 = (float)(w.nw & 255u);
         w.nw = w.nb4;
         {   // the pixel of row q + 2 is asked for before this row's arithmetic
-            const int gy = h_reflect101(ty0 + min(q + 2, y1 + 2), rows);
+            int gy = ty0 + min(q + 2, y1 + 2);         // at most three rows outside the image
+            if (rows >= 4) { gy = abs(gy); gy = min(gy, 2 * (rows - 1) - gy); }   // uniform: one reflection is enough, three scalar instructions
+            else { asm volatile("" ::: "memory"); gy = h_reflect101(gy, rows); }   // (kept a branch of its own: the empty asm)
             w.nb4 = __builtin_amdgcn_raw_buffer_load_b8(src.rsrc, src.pcol, gy * cols, 0);   // the row's offset rides in an SGPR: no address arithmetic
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -226,37 +228,40 @@ __device__ __forceinline__ bool harris_row(HarrisRow& w, const HarrisSrc& src, i
     if (!FULL && y < y0) return true;                  // uniform
     const int gy = ty0 + y;
     if (gy >= rows) return false;                      // uniform: rows below the image are nobody's
-    float a0 = w.ra[RROW(0)], a1 = w.ra[RROW(1)], a2 = w.ra[RROW(2)];
-    float b0 = w.rb[RROW(0)], b1 = w.rb[RROW(1)], b2 = w.rb[RROW(2)];
-    float c0 = w.rc[RROW(0)], c1 = w.rc[RROW(1)], c2 = w.rc[RROW(2)];
+    const float a0 = w.ra[RROW(0)], a1 = w.ra[RROW(1)], a2 = w.ra[RROW(2)];
+    const float b0 = w.rb[RROW(0)], b1 = w.rb[RROW(1)], b2 = w.rb[RROW(2)];
+    const float c0 = w.rc[RROW(0)], c1 = w.rc[RROW(1)], c2 = w.rc[RROW(2)];
+    float a, b, c;                                     // column sums: (rs[y-1] + rs[y]) + rs[y+1]
     // BORDER_REFLECT_101 of the cov image in y: row -1 is row 1, row `rows` is row rows - 2 (the image's first and last
     // row only; as real branches -- the empty asm keeps the compiler from turning them into selects on every row of
     // every tile.  The sums of rows outside the image are never stored: only this row's operands change)
-    if (gy == 0 || gy == rows - 1) {                   // uniform
+    // (only the sums differ on those rows, computed in a branch of their own: as operand swaps in front of common adds
+    // they cost the other rows three register moves each)
+    if ((unsigned)(gy - 1) >= (unsigned)(rows - 2)) {  // uniform: gy == 0 || gy == rows - 1 (gy < rows here), one compare
         asm volatile("" ::: "memory");
         if (rows > 1) {
-            if (gy == 0) { a0 = a2; b0 = b2; c0 = c2; }
-            if (gy == rows - 1) { a2 = a0; b2 = b0; c2 = c0; }
-        } else { a0 = a1; b0 = b1; c0 = c1; a2 = a1; b2 = b1; c2 = c1; }
-    }
+            // the first row's row -1 is row 1; the last row's row `rows` is row rows - 2 (never both: rows > 1)
+            const float ta = gy == 0 ? a2 : a0, tb = gy == 0 ? b2 : b0, tc = gy == 0 ? c2 : c0;
+            const float ua = gy == rows - 1 ? ta : a2, ub = gy == rows - 1 ? tb : b2, uc = gy == rows - 1 ? tc : c2;
+            a = (ta + a1) + ua; b = (tb + b1) + ub; c = (tc + c1) + uc;
+        } else { a = (a1 + a1) + a1; b = (b1 + b1) + b1; c = (c1 + c1) + c1; }
+    } else { a = (a0 + a1) + a2; b = (b0 + b1) + b2; c = (c0 + c1) + c2; }
 #undef RROW
-    // column sums: (rs[y-1] + rs[y]) + rs[y+1]
-    const float a = (a0 + a1) + a2, b = (b0 + b1) + b2, c = (c0 + c1) + c2;
     const float m1 = a * c, m2 = b * b;
     const float m3 = m1 - m2;
     const float tr = a + c;
     const float R = (float)((double)m3 - k * (double)tr * (double)tr);
-    sink(y, lx - 1, R, lx >= 1 && lx <= tw && gx < cols);   // every lane calls (wave-wide operations inside are fine)
+    sink(y, lx - 1, R, lx >= 1 && lx <= tw && gx < cols, vmask);   // every lane calls (wave-wide operations inside are fine)
     return true;
 }
 
 template <int U, bool DIRECT, class Sink>
 __device__ __forceinline__ bool harris_block15(HarrisRow& w, const HarrisSrc& s_img, int q, int y0, int y1, int rows, int ty0,
                                                int lxc, int lx, int tw, int gx, int cols, bool ring_tile, int ring_src, double k,
-                                               float t0, float t1, float t2, Sink& sink) {
+                                               float t0, float t1, float t2, unsigned long long vmask, Sink& sink) {
     if constexpr (U < HW_BLOCK) {
-        if (!harris_row<U % 5, HW_BLOCK == 15 ? U % 3 : 2, false, true, Sink, HW_BLOCK != 15, DIRECT>(w, s_img, q + U, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return false;
-        return harris_block15<U + 1, DIRECT>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink);
+        if (!harris_row<U % 5, HW_BLOCK == 15 ? U % 3 : 2, false, true, Sink, HW_BLOCK != 15, DIRECT>(w, s_img, q + U, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink)) return false;
+        return harris_block15<U + 1, DIRECT>(w, s_img, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink);
     } else {
         return true;
     }
@@ -275,6 +280,7 @@ __device__ __forceinline__ void harris_walk_band_impl(const unsigned char* s_img
     // gx = -1 <- gx = 1, gx = cols <- gx = cols - 2 (lanes two up / two down; one for a one-column image)
     const bool ring_tile = tx0 == 0 || tx0 + tw == cols;
     const int ring_src = (gx == -1 || gx == cols) ? lane + (h_reflect101(gx, cols) - gx) : lane;   // a physical lane
+    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(lx >= 1 && lx <= tw && gx < cols);   // the lanes that own an output column
     HarrisSrc src;
     src.s_img = s_img;
     if (DIRECT) src.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)im, 0, rows * cols, 0x00020000);
@@ -295,13 +301,13 @@ __device__ __forceinline__ void harris_walk_band_impl(const unsigned char* s_img
     int q = y0 - 3;                                    // row-pass row q (relative to ty0) = LDS row q + 3
     // warm-up: four rows that only feed the row passes, two that also produce row sums (rolled code, shifting windows)
     for (; q < y0 + 3 && q < y1 + 3; ++q)
-        if (!harris_row<4, 2, true, false, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_row<4, 2, true, false, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink)) return;
     // steady state: blocks of 15 unrolled rows on rings
     for (; q + HW_BLOCK <= y1 + 3; q += HW_BLOCK)
-        if (!harris_block15<0, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_block15<0, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink)) return;
     // remainder (tiles whose height is not a multiple of 15)
     for (; q < y1 + 3; ++q)
-        if (!harris_row<4, 2, true, true, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, sink)) return;
+        if (!harris_row<4, 2, true, true, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink)) return;
 }
 template <class Sink>
 __device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(HW_THREADS) void harris_response_kernel(const uint8
     const int y0 = band * rb, y1 = min(th, y0 + rb);
     if (y0 < y1)
         harris_walk_band(s_img, rows, cols, tx0, ty0, tw, y0, y1, k,
-                         [&](int y, int x, float R, bool valid) { if (valid) out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
+                         [&](int y, int x, float R, bool valid, unsigned long long) { if (valid) out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
 }
 
 struct BinArgs {
@@ -637,17 +643,21 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
         __builtin_amdgcn_wave_barrier();
     }
     unsigned long long tau = 0;
+    uint32_t thi = 1;                                      // max(tau's high word, 1): the row test
     int n = 0;
-    harris_walk_band_impl<DIRECT>(s_img, im, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool valid) {
+    harris_walk_band_impl<DIRECT>(s_img, im, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int x, float R, bool, unsigned long long vmask) {
         // a candidate is everything above tau; the test is on the key's HIGH word (|response| bits) alone: the few pixels
         // that tie tau's high word come along and lose in harris_keep_best, and the 64-bit key (push position of the
-        // reference's scan: x outer, y inner, :953-955) is only built for the lanes that store one
-        const float v = fabsf(R);
-        const bool nz = !(fabsf(v - 0.f) <= 1e-6f * fabsf(v));   // isEqual(response, .0f), src/misc.cpp:10-14
-        const uint32_t hi = __float_as_uint(v);
-        const bool take = valid && nz && hi >= (uint32_t)(tau >> 32);
-        const unsigned long long m = __ballot(take);
+        // reference's scan: x outer, y inner, :953-955) is only built for the lanes that store one.
+        // isEqual(response, .0f) (src/misc.cpp:10-14: |v - 0| <= 1e-6 |v|) holds for v == 0 alone -- denormals are kept in
+        // this build, 1e-6 |v| < |v| for every other finite v, a NaN compares false there and is a candidate here -- so
+        // "not equal to zero" is hi >= 1 and rides in the same compare.  The row's whole test is that one compare, its
+        // mask and the mask of the lanes that own a column (scalar); the lane's own bit comes back without a vector
+        // instruction (inverse ballot)
+        const uint32_t hi = __float_as_uint(R) & 0x7fffffffu;
+        const unsigned long long m = vmask & __builtin_amdgcn_ballot_w64(hi >= thi);
         if (m) {                                           // uniform
+            const bool take = __builtin_amdgcn_inverse_ballot_w64(m);
             const int at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (take) list[at] = ((unsigned long long)hi << 32) | (uint32_t)(0xffffffffu - (uint32_t)(x * th + y));
             n += __popcll(m);
@@ -655,6 +665,7 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
                 __builtin_amdgcn_wave_barrier();
                 const HarrisKept kb = harris_keep_best(list, n, per, false);
                 n = kb.n; tau = kb.tau;
+                thi = max((uint32_t)(tau >> 32), 1u);
             }
         }
     });
