@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
 // was <= tau at that time <= the final `per`-th best, so the true top `per` are in the list at the end: exact, no second
 // pass, and neither the response image nor the bin's responses ever exist in memory.  Per image the HBM traffic is the
 // uint8 pixels in (+ halo re-reads from L2) and the corners out.
+#define HD_KEEP 48    // keys a mid-walk harris_keep_best may leave in the list (>= HD_MAXPER; the list refills from there)
 #define HD_CAND 256   // candidate keys per wave; a row appends at most HW_MAXW
 // The `per` largest of list[0..n) stay in list[0..kept) (descending if `sorted`), tau = the smallest kept (0 if fewer than `per`).
 // Called when the wave's candidate list is nearly full (a few times per bin) and once at the end of the bin.
@@ -579,22 +580,24 @@ __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list,
     uint32_t hi[HD_CAND / 64];
 #pragma unroll
     for (int u = 0; u < HD_CAND / 64; ++u) hi[u] = (uint32_t)(mine[u] >> 32);
-    // T = the per-th largest high word (0 when fewer than `per` keys exist): greatest T with #(hi >= T) >= per
+    // T = a high word with #(hi >= T) >= per, built from the top bit down (the greatest such T = the per-th largest high
+    // word when every bit is decided; 0 when fewer than `per` keys exist).  Every prefix is such a T already, so the
+    // descent stops as soon as few enough keys are at or above it: exactly `per` for the final, ordered list (they ARE the
+    // best `per` then); HD_KEEP for a call in the middle of the walk, which only has to make room and hand the walk a
+    // threshold that no key of the final answer falls below -- a third of the steps on the bench's images
     uint32_t T = 0;
-    for (int bit = 30; bit >= 0; --bit) {                   // |response| bits: the sign bit is clear
+    int kept = n;                                           // #(hi >= T): every key's high word is >= 1
+    const int stop = sorted ? per : max(per, HD_KEEP);
+    int bit = 30;                                           // |response| bits: the sign bit is clear
+    for (; bit >= 0 && kept > stop; --bit) {
         const uint32_t cand = T | (1u << bit);
         int cnt = 0;
 #pragma unroll
         for (int u = 0; u < HD_CAND / 64; ++u) cnt += __popcll(__ballot(hi[u] >= cand));
-        if (cnt >= per) T = cand;                           // uniform
+        if (cnt >= per) { T = cand; kept = cnt; }           // uniform
     }
-    int greater = 0, ties = 0;
-#pragma unroll
-    for (int u = 0; u < HD_CAND / 64; ++u) {
-        greater += __popcll(__ballot(hi[u] > T && mine[u] != 0ull));
-        ties += __popcll(__ballot(hi[u] == T && mine[u] != 0ull));
-    }
-    if (T != 0 && greater + ties > per) return harris_keep_best_picks(mine, list, per);   // uniform: the low words decide among the ties
+    // every bit decided and still more than `per` at or above T: keys tie T's high word, the low words decide among them
+    if (bit < 0 && T != 0 && kept > per) return harris_keep_best_picks(mine, list, per);   // uniform
     // compaction of everything at or above T (T == 0: fewer than `per` keys, all stay)
     int base = 0;
 #pragma unroll
@@ -607,8 +610,8 @@ __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list,
     }
     __builtin_amdgcn_wave_barrier();
     out.n = base;
-    out.tau = base == per ? ((unsigned long long)T << 32) : 0ull;   // the walk tests the high word only
-    if (sorted && base > 1) {                               // descending: every key to the place its rank says (base <= HD_MAXPER <= 64)
+    out.tau = base >= per ? ((unsigned long long)T << 32) : 0ull;   // the walk tests the high word only (T == 0: no threshold yet)
+    if (sorted && base > 1) {                               // descending: every key to the place its rank says (base <= per <= HD_MAXPER <= 64)
         const unsigned long long key = lane < base ? list[lane] : 0ull;
         int rank = 0;
         for (int j = 0; j < base; ++j) {
