@@ -309,30 +309,22 @@ __device__ __forceinline__ void harris_walk_band_impl(const unsigned char* s_img
     for (; q < y1 + 3; ++q)
         if (!harris_row<4, 2, true, true, Sink, true, DIRECT>(w, src, q, y0, y1, rows, ty0, lxc, lx, tw, gx, cols, ring_tile, ring_src, k, t0, t1, t2, vmask, sink)) return;
 }
-template <class Sink>
-__device__ __forceinline__ void harris_walk_band(const unsigned char* s_img, int rows, int cols, int tx0, int ty0,
-                                                 int tw, int y0, int y1, double k, Sink sink) {
-    harris_walk_band_impl<false>(s_img, nullptr, rows, cols, tx0, ty0, tw, y0, y1, k, sink);
-}
-
 // ---- cv::cornerHarris as an image (plain API, and bins too large for the fused detector) -----------------------
-#define HR_TW 62
-#define HR_TH 76
+// One wave per (58-column strip, band of `band` rows), walking the image itself (HarrisSrc direct): no LDS, no barrier.
+// The band height is the launcher's choice: tall bands pay the walk's six warm-up rows less often, short ones put more
+// waves on a single image.
+#define HR_TW HW_DIRECT_MAXW
 __global__ __launch_bounds__(HW_THREADS) void harris_response_kernel(const uint8_t* __restrict__ images, int rows,
-                                                                     int cols, double k, float* __restrict__ resp) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_img[(HR_TH + 6) * HW_PITCH];
+                                                                     int cols, double k, float* __restrict__ resp, int band) {
     const int img = blockIdx.z;
-    const int tx0 = blockIdx.x * HR_TW, ty0 = blockIdx.y * HR_TH;
-    const int tw = min(HR_TW, cols - tx0), th = min(HR_TH, rows - ty0);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave uniform: scalar loop control
+    const int tx0 = blockIdx.x * HR_TW, ty0 = (blockIdx.y * (HW_THREADS / 64) + wave) * band;
+    if (ty0 >= rows) return;
+    const int tw = min(HR_TW, cols - tx0), th = min(band, rows - ty0);
     const uint8_t* im = images + (size_t)img * rows * cols;
     float* out = resp + (size_t)img * rows * cols;
-    harris_load_tile<HW_THREADS / 64>(im, rows, cols, tx0, ty0, tw, th, s_img);
-    __syncthreads();
-    const int band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rb = (th + 3) / 4;   // wave uniform: scalar loop control
-    const int y0 = band * rb, y1 = min(th, y0 + rb);
-    if (y0 < y1)
-        harris_walk_band(s_img, rows, cols, tx0, ty0, tw, y0, y1, k,
-                         [&](int y, int x, float R, bool valid, unsigned long long) { if (valid) out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
+    harris_walk_band_impl<true>(nullptr, im, rows, cols, tx0, ty0, tw, 0, th, k,
+                                [&](int y, int x, float R, bool valid, unsigned long long) { if (valid) out[(size_t)(ty0 + y) * cols + tx0 + x] = R; });
 }
 
 struct BinArgs {
@@ -705,8 +697,12 @@ __global__ __launch_bounds__(256) void harris_compact_kernel(BinArgs a, float2* 
 
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp) {
     if (n_img <= 0) return VISO_OK;
-    dim3 grid((cols + HR_TW - 1) / HR_TW, (rows + HR_TH - 1) / HR_TH, n_img);
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(HW_THREADS), 0, s, images, rows, cols, k, resp);
+    // bands of 76 rows once the strips alone fill the GPU's wave slots a few times over, of 19 rows for a few images
+    const int strips = (cols + HR_TW - 1) / HR_TW;
+    int band = (long long)n_img * strips * ((rows + 75) / 76) >= 16384 ? 76 : 19;
+    if (const char* e = getenv("VISO_HARRIS_BAND")) { const int v = atoi(e); if (v >= 1 && v <= 4096) band = v; }   // tuning / tests: results do not depend on it
+    dim3 grid(strips, (rows + band * (HW_THREADS / 64) - 1) / (band * (HW_THREADS / 64)), n_img);
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(HW_THREADS), 0, s, images, rows, cols, k, resp, band);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -21,6 +21,16 @@ def test_harris_response_bit_exact(viso, oracle, shape):
     assert np.abs(a).max() > 0
 
 
+# the response image is walked in bands whose height the launcher picks by the amount of work (and VISO_HARRIS_BAND
+# overrides): every height gives the same image
+@pytest.mark.parametrize("band", ["1", "7", "19", "76", "500"])
+def test_harris_response_band_heights(viso, oracle, band, monkeypatch):
+    monkeypatch.setenv("VISO_HARRIS_BAND", band)
+    for shape in ((37, 131), (200, 59), (3, 3), (2, 70), (1, 9), (90, 1)):
+        img = synth.make_images(11, shape[0], shape[1])
+        assert np.array_equal(libviso_amd.harris_response(img), oracle.harris_response(img)), shape
+
+
 def test_detect_binned_bit_exact(viso, oracle):
     img = synth.make_image_sequence(3, 1, n_kp=1500)["images"][0, 0]          # 376 x 1241
     for nf, bx, by in ((1200, 24, 5), (120, 6, 3), (64, 2, 2)):
