@@ -445,6 +445,9 @@ __device__ __forceinline__ int harris_top_keys(int stridex, int stridey, int P, 
             if (take && at < LIST) list[at] = key;
             cnt += __popcll(m);
         });
+        // the walk's trip count falls with the lane (P need not be a multiple of its stride): the lanes that left early
+        // missed the last appends; lane 0 runs every iteration and has the whole count
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
         __builtin_amdgcn_wave_barrier();
         if (cnt <= LIST) {
             unsigned long long mine[LIST / 64];

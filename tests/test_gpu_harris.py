@@ -68,6 +68,18 @@ def test_detect_binned_geometries_bit_exact(viso, oracle, shape, bx, by, per):
         assert len(k0) > 0
 
 
+# random geometries (tests/harris_fuzz.py).  Seed 1 holds the two cases that found the selection from a response image
+# (more than 32 corners per bin, or bins wider than 62 columns) dropping corners: its second walk appended to the list
+# with a per-lane count, and the lanes whose share of a bin is one pixel shorter never saw the last appends.
+def test_detect_random_geometries(viso, oracle):
+    import harris_fuzz
+    for img, nf, bx, by in harris_fuzz.cases(1, 400):
+        k0, r0 = oracle.detect_harris_binned(img, nf, bx, by)
+        k1, r1 = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        assert np.array_equal(k0, k1) and np.array_equal(r0, r1), harris_fuzz.describe(img, nf, bx, by, k0, k1)
+        assert np.array_equal(libviso_amd.harris_response(img), oracle.harris_response(img)), img.shape
+
+
 def test_image_to_pose_pipeline(viso, oracle):
     seq = synth.make_image_sequence(9, 4, n_kp=1500)
     nf = 4
