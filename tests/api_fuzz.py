@@ -1,0 +1,148 @@
+"""Random and degenerate inputs through the plain C-ABI calls other than match_desc (tests/test_gpu_fuzz.py has that one):
+extract_descriptors, match_circle, collect_matches, triangulate_rectified, get_inliers, minimize_reproj,
+ransac_minimize_reproj -- each against the oracle.  Test infrastructure (imports oracle/): lives under tests/;
+`run(seed, n, L, O)` feeds tests/test_gpu_fuzz.py, as a script (not collected) it runs longer sweeps:
+python3 tests/api_fuzz.py SEED N"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def _close(L, t0, t1, tol=1e-5):
+    """poses as matrices, relative Frobenius distance (the parity tests' POSE_TOL): the device orders some fp64 sums differently"""
+    if not (np.isfinite(t0).all() and np.isfinite(t1).all()):
+        return _same(np.isfinite(t0), np.isfinite(t1))
+    a, b = L.tr2mat(t0), L.tr2mat(t1)
+    return np.linalg.norm(a - b) <= tol * np.linalg.norm(b)
+
+
+def fuzz_extract(rng, L, O):
+    rows, cols = int(rng.integers(1, 90)), int(rng.integers(1, 130))
+    img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    n = int(rng.integers(0, 40))
+    kp = np.stack([rng.uniform(-8, cols + 8, n), rng.uniform(-8, rows + 8, n)], 1).astype(np.float32)
+    if n and rng.integers(0, 2):
+        kp[: n // 2] = np.rint(kp[: n // 2])                       # integer positions, .5 positions (rint: ties to even)
+        kp[n // 2 :: 3] = np.floor(kp[n // 2 :: 3]) + 0.5
+    radius = int(rng.choice([5, 5, 5, 1, 2, 3, 7]))
+    a, b = L.extract_descriptors(img, kp, radius), O.extract_descriptors(img, kp, radius)
+    return _same(a, b), "extract %dx%d n=%d radius=%d" % (rows, cols, n, radius)
+
+
+def _match_list(rng, n, na, nb, dup):
+    """rows (query idx, train idx, dist) like match_desc's output; with `dup` some indices repeat or point out of range"""
+    if n == 0:
+        return np.zeros((0, 3), np.int32)
+    q = rng.permutation(max(na, n))[:n] if not dup else rng.integers(0, max(na, 1), n)
+    t = rng.permutation(max(nb, n))[:n] if not dup else rng.integers(0, max(nb, 1), n)
+    return np.stack([q, t, rng.integers(0, 5000, n)], 1).astype(np.int32)
+
+
+def fuzz_circle(rng, L, O):
+    n1, n2, n3, n4 = (int(rng.integers(0, 60)) for _ in range(4))       # keypoints of left, right, left_prev, right_prev
+    dup = bool(rng.integers(0, 3) == 0)
+    lr = _match_list(rng, int(rng.integers(0, 50)), n1, n2, dup)
+    lrp = _match_list(rng, int(rng.integers(0, 50)), n3, n4, dup)
+    m11 = _match_list(rng, int(rng.integers(0, 50)), n1, n3, dup)
+    m22 = _match_list(rng, int(rng.integers(0, 50)), n2, n4, dup)
+    cap = int(rng.choice([1, 2, 7, 64, 400]))
+    r0, c0, p0, k0 = O.match_circle(lr, lrp, m11, m22, cap)
+    r1, c1, p1, k1 = L.match_circle(lr, lrp, m11, m22, cap)
+    return (r0 == r1 and k0 == k1 and _same(c0, c1) and _same(p0, p1)), "circle sizes %s cap=%d dup=%s (r %d/%d n %d/%d)" % (
+        (len(lr), len(lrp), len(m11), len(m22)), cap, dup, r0, r1, k0, k1)
+
+
+def fuzz_collect_triangulate(rng, L, O, param):
+    na, nb = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+    kp1 = rng.uniform(0, 1241, (na, 2)).astype(np.float32)
+    kp2 = rng.uniform(0, 1241, (nb, 2)).astype(np.float32)
+    n = int(rng.integers(0, 60))
+    m = np.stack([rng.integers(0, na, n), rng.integers(0, nb, n), rng.integers(0, 9999, n)], 1).astype(np.int32) if n else np.zeros((0, 3), np.int32)
+    if n and rng.integers(0, 2):
+        kp2[m[0, 1], 0] = kp1[m[0, 0], 0]                          # zero disparity: a division by zero in the reference
+    x0, x1 = O.collect_matches(kp1, kp2, m), L.collect_matches(kp1, kp2, m)
+    ok = _same(x0, x1)
+    if n:
+        with np.errstate(all="ignore"):
+            ok = ok and _same(O.triangulate_rectified(x0, param), L.triangulate_rectified(x0, param))
+    return ok, "collect/triangulate na=%d nb=%d n=%d" % (na, nb, n)
+
+
+def fuzz_solver(rng, L, O, synth):
+    m = int(rng.choice([3, 4, 5, 8, 20, 65, 130, 300]))
+    X, obs, tr_true, param = synth.make_solver_case(int(rng.integers(1 << 30)), m=m, outlier_frac=float(rng.choice([0.0, 0.25, 0.6])), noise=float(rng.choice([0.0, 0.3, 2.0])))
+    X, obs = X.copy(), obs.copy()
+    kind = int(rng.integers(0, 6))
+    if kind == 1:
+        X[:, : m // 2] = X[:, :1]                                  # repeated points: singular 3-point systems
+        obs[:, : m // 2] = obs[:, :1]
+    elif kind == 2:
+        X[2, rng.integers(0, m)] = 0.0                             # a point in the camera plane
+    elif kind == 3:
+        obs[:, rng.integers(0, m)] = 1e6
+    elif kind == 4:
+        X *= 1e-3
+    tr = tr_true + rng.normal(0, 0.01, 6)
+    # kinds 1 and 4 are ill-posed on purpose (half the points identical; a world a thousand times too small: Gauss-Newton
+    # diverges to rotations of thousands of radians): one ulp in a sum decides where such a solve ends, and the device orders
+    # some fp64 sums differently, so their POSES are not compared -- the calls must return, and get_inliers must agree
+    posed = kind not in (1, 4)
+    ok = True
+    what = "solver m=%d kind=%d" % (m, kind)
+    with np.errstate(all="ignore"):
+        i0, i1 = O.get_inliers(X, obs, tr, param), L.get_inliers(X, obs, tr, param)
+        ok_i = _same(i0[0], i1[0]) and (abs(i0[1] - i1[1]) <= 1e-12 * max(1.0, abs(i0[1])) or (np.isnan(i0[1]) and np.isnan(i1[1])) or i0[1] == i1[1])
+        if not ok_i:
+            what += " | get_inliers: %d / %d inliers, rms %r / %r" % (len(i0[0]), len(i1[0]), i0[1], i1[1])
+        ok = ok and ok_i
+        act = np.sort(rng.permutation(m)[: int(rng.integers(3, m + 1))]).astype(np.int32)
+        r0, t0 = O.minimize_reproj(X, obs, np.zeros(6), param, act)[:2]
+        r1, t1 = L.minimize_reproj(X, obs, np.zeros(6), param, act)
+        # (kind 3's observation at 1e6 is an outlier no RANSAC protects a bare minimize_reproj from: ill-posed there too)
+        ok_m = not posed or kind == 3 or (r0 == r1 and (r0 != 1 or _close(L, t0, t1)))
+        if not ok_m:
+            what += " | minimize_reproj on %d points: %d / %d, tr %s / %s" % (len(act), r0, r1, t0, t1)
+        ok = ok and ok_m
+        seed, frame = int(rng.integers(0, 1000)), int(rng.integers(0, 5000))
+        a, b = O.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame), L.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame)
+        ok_r = not posed or (a[0] == b[0] and (not a[0] or (_close(L, a[1], b[1]) and _same(a[2], b[2]))))
+        if not ok_r:
+            what += " | ransac seed %d frame %d: ok %d / %d, inliers %d / %d, tr %s / %s" % (seed, frame, a[0], b[0], len(a[2]), len(b[2]), a[1], b[1])
+        ok = ok and ok_r
+    return ok, what
+
+
+def run(seed, n, L, O):
+    """n rounds of every target; returns the descriptions of the rounds that differ"""
+    from libviso_amd import synth
+    from libviso_amd.abi import Param
+    rng = np.random.default_rng(seed)
+    param = Param.kitti00()
+    bad = []
+    for _ in range(n):
+        for f in (lambda: fuzz_extract(rng, L, O), lambda: fuzz_circle(rng, L, O),
+                  lambda: fuzz_collect_triangulate(rng, L, O, param), lambda: fuzz_solver(rng, L, O, synth)):
+            ok, what = f()
+            if not ok:
+                bad.append(what)
+    return bad
+
+
+if __name__ == "__main__":
+    import libviso_amd
+    from oracle import pyoracle as O
+    O.lib()
+    libviso_amd.load()
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 100, libviso_amd, O)
+    for b in bad[:40]:
+        print("MISMATCH", b)
+    print("done, mismatches:", len(bad))
+    sys.exit(1 if bad else 0)

@@ -155,3 +155,12 @@ def test_stereo_gate_with_a_tiny_scaled_F(viso, oracle):
             want = oracle.match_desc(kp1, kp2, d1, d2, mp)
             got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
             assert np.array_equal(got, want), (scale, thresh, it, len(kp1), len(kp2))
+
+
+# the other plain calls (tests/api_fuzz.py): descriptor extraction at and beyond the image borders, the circle join on lists
+# with repeated / out-of-range indices and tiny capacities, collect / triangulate with zero disparities, the solver calls on
+# ill-conditioned point sets
+def test_plain_calls_randomised(viso, oracle):
+    import api_fuzz
+    bad = api_fuzz.run(1, 150, libviso_amd, oracle)
+    assert not bad, bad[:5]
