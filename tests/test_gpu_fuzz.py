@@ -164,3 +164,11 @@ def test_plain_calls_randomised(viso, oracle):
     import api_fuzz
     bad = api_fuzz.run(1, 150, libviso_amd, oracle)
     assert not bad, bad[:5]
+
+
+# whole sequences through the batch family (tests/batch_fuzz.py): features in with every matcher variant, ragged / empty /
+# repeated frames, odd capacities; images in with keypoints on the borders; images in with the detector on random bin grids
+def test_batch_family_randomised(viso, oracle):
+    import batch_fuzz
+    bad = batch_fuzz.run(3, 30, libviso_amd, oracle)
+    assert not bad, bad[:5]
