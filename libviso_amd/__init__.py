@@ -409,6 +409,7 @@ class Context:
         self.h = self.L.viso_ctx_create(device, stream)
         if not self.h:
             raise VisoError("viso_ctx_create: " + self.L.viso_last_error().decode())
+        self._batches = weakref.WeakSet()   # closed with the context: a batch destroyed after its context uses freed streams
         _live.add(self)
 
     def synchronize(self):
@@ -418,6 +419,13 @@ class Context:
 
     def close(self):
         if self.h:
+            # its batches first, whatever order the caller (or the garbage collector, after an exception skipped the
+            # caller's close() calls) takes: viso_batch_destroy on a destroyed context aborts inside the HIP runtime
+            for b in list(self._batches):
+                try:
+                    b.close()
+                except Exception:
+                    pass
             h, self.h = self.h, None
             r = self.L.viso_ctx_destroy(h)
             if r != 1:
@@ -441,6 +449,7 @@ class Batch:
         self.h = self.L.viso_batch_create(ctx.h, n_frames, cap, dlen)
         if not self.h:
             raise VisoError("viso_batch_create: " + self.L.viso_last_error().decode())
+        ctx._batches.add(self)
         _live.add(self)
 
     def _chk(self, where, r):

@@ -40,7 +40,9 @@ struct viso_batch {
     // the *_async uploads stage the caller's (pageable, possibly temporary) n array through a small pinned ring:
     // slot k is reusable once the copy that read it has passed (n_pin_ev[k])
     int* n_pin; hipEvent_t n_pin_ev[VISO_NPIN_SLOTS]; bool n_pin_used[VISO_NPIN_SLOTS]; int n_pin_next;
-    double* tr; int *ok, *n_inl, *inl;
+    double* tr; int *ok, *n_inl, *inl;   // tr, ok, n_inl: ONE device block (tr first), mirrored in pinned memory by every run's last kernel
+    unsigned char* pose_pin = nullptr;   // [n_frames] x (6 doubles) | [n_frames] ok | [n_frames] n_inl: what viso_batch_get_poses reads
+    size_t pose_bytes = 0;
     MatchParamsDev mp[2];
     SolverParamsDev sp;
     unsigned long long seed, first_frame;
@@ -112,11 +114,12 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     for (int k = 0; k < VISO_NPIN_SLOTS; ++k) if (b->n_pin_ev[k]) note(hipEventDestroy(b->n_pin_ev[k]));
     if (b->n_pin) note(hipHostFree(b->n_pin));
     if (b->r8pin) note(hipHostFree(b->r8pin));
+    if (b->pose_pin) note(hipHostFree(b->pose_pin));
     if (b->r8ev) note(hipEventDestroy(b->r8ev));
     void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->packed8, b->r8cnt, b->sums, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
-                    b->sitems, b->circ, b->pcl, b->mc, b->tr, b->ok, b->n_inl, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->rot, b->tile_flag, b->qord, b->ovf_q};
+                    b->sitems, b->circ, b->pcl, b->mc, b->tr /* + ok, n_inl */, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->rot, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
     delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -256,7 +259,19 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     A(dalloc(&b->x_c, nf * 4 * c)); A(dalloc(&b->Xp_c, nf * 3 * c));
     A(dalloc(&b->join, nf)); A(dalloc(&b->sitems, nf));
     A(dalloc(&b->circ, nf * c * 4)); A(dalloc(&b->pcl, nf * c * 2)); A(dalloc(&b->mc, nf));
-    A(dalloc(&b->tr, nf * 6)); A(dalloc(&b->ok, nf)); A(dalloc(&b->n_inl, nf)); A(dalloc(&b->inl, nf * c));
+    // poses, flags and inlier counts in one block: one blit into the pinned mirror per run (three blocking copies of a
+    // few bytes were 50 us of a one-pair batch's 0.42 ms)
+    b->pose_bytes = nf * (6 * sizeof(double) + 2 * sizeof(int));
+    { unsigned char* blk = nullptr; A(dalloc(&blk, b->pose_bytes)); b->tr = reinterpret_cast<double*>(blk); }
+    b->ok = r >= 0 ? reinterpret_cast<int*>(b->tr + nf * 6) : nullptr;
+    b->n_inl = r >= 0 ? b->ok + nf : nullptr;
+    A(dalloc(&b->inl, nf * c));
+    if (r >= 0 && hipHostMalloc((void**)&b->pose_pin, b->pose_bytes, hipHostMallocDefault) != hipSuccess) {
+        b->pose_pin = nullptr;
+        viso_set_error("viso_batch_create: hipHostMalloc of the pose mirror failed");
+        r = VISO_ERR_NOMEM;
+    }
+    if (r >= 0) memset(b->pose_pin, 0, b->pose_bytes);
     if (r >= 0 && (hipHostMalloc((void**)&b->r8pin, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess ||
                    hipEventCreateWithFlags(&b->r8ev, hipEventDisableTiming) != hipSuccess)) {
         viso_set_error("viso_batch_create: pinned buffer / event for the planes' statistics failed");
@@ -274,9 +289,7 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
               hipMemset(b->n, 0, nf * 2 * sizeof(int)) == hipSuccess &&
               hipMemset(b->m_cnt, 0, 3 * nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->mc, 0, nf * sizeof(int)) == hipSuccess &&
-              hipMemset(b->tr, 0, nf * 6 * sizeof(double)) == hipSuccess &&
-              hipMemset(b->ok, 0, nf * sizeof(int)) == hipSuccess &&
-              hipMemset(b->n_inl, 0, nf * sizeof(int)) == hipSuccess &&
+              hipMemset(b->tr, 0, b->pose_bytes) == hipSuccess &&
               hipMemset(b->scored, 0, b->zeroed_bytes) == hipSuccess;
     if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_destroy(b); return nullptr; }
     return b;
@@ -444,6 +457,10 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0 ||
             (r = dalloc(&b->hq, k + 1)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0 ||
             (r = dalloc(&b->rot, (size_t)b->nf * viso_rot_bytes(b->iters))) < 0) return r;
+        // frame 0 has no solve: its rows are never written, and viso_batch_get_hypotheses hands them out with the rest
+        HIP_TRY(hipMemset(b->tr_h, 0, sizeof(double) * 6 * k));
+        HIP_TRY(hipMemset(b->ok_h, 0, sizeof(int) * k));
+        HIP_TRY(hipMemset(b->cnt_h, 0, sizeof(int) * k));
     }
     int r = build_solver_items(b);
     if (r < 0) return r;
@@ -668,6 +685,9 @@ static int run_rest(viso_batch* b) {
     // vector<double> tr(6,0), :1312: ransac_refit_kernel writes the zeros itself where no solve succeeds
     if (b->nf > 1) {
         if ((r = launch_ransac(ss, b->sitems, b->nf - 1, b->iters, b->seed, b->sp, b->hq, b->ctx->gn_split, b->cap)) < 0) return r;   // :1313
+        // the run's poses, flags and inlier counts into the pinned mirror (the kernel writes over PCIe; viso_batch_get_poses
+        // waits for the streams and reads host memory)
+        if ((r = plain_blit(ss, b->tr, b->pose_pin, b->pose_bytes / 4)) < 0) return r;
     }
     if (ss != s) {
         HIP_TRY(hipEventRecord(b->ev_ransac, ss));
@@ -722,9 +742,10 @@ extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, 
     if (!slot_ok(b, 0, t)) { viso_set_error("viso_batch_get_pose: bad argument"); return VISO_ERR_ARG; }
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     int o = 0, n = 0;
-    if (tr) HIP_TRY(hipMemcpy(tr, b->tr + (size_t)t * 6, sizeof(double) * 6, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&o, b->ok + t, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&n, b->n_inl + t, sizeof(int), hipMemcpyDeviceToHost));
+    const size_t nf = (size_t)b->nf;
+    if (tr) memcpy(tr, b->pose_pin + sizeof(double) * 6 * (size_t)t, sizeof(double) * 6);
+    memcpy(&o, b->pose_pin + sizeof(double) * 6 * nf + sizeof(int) * (size_t)t, sizeof(int));
+    memcpy(&n, b->pose_pin + sizeof(double) * 6 * nf + sizeof(int) * (nf + (size_t)t), sizeof(int));
     if (n > 0 && inliers) HIP_TRY(hipMemcpy(inliers, b->inl + (size_t)t * b->cap, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     if (ok) *ok = o;
     if (n_inl) *n_inl = n;
@@ -734,9 +755,11 @@ extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, 
 extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl) {
     if (!b) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
-    if (tr) HIP_TRY(hipMemcpy(tr, b->tr, sizeof(double) * 6 * (size_t)b->nf, hipMemcpyDeviceToHost));
-    if (ok) HIP_TRY(hipMemcpy(ok, b->ok, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
-    if (n_inl) HIP_TRY(hipMemcpy(n_inl, b->n_inl, sizeof(int) * (size_t)b->nf, hipMemcpyDeviceToHost));
+    // the pinned mirror of the device block (run_rest's last kernel; zeros before the first run, like the device's)
+    const size_t nf = (size_t)b->nf;
+    if (tr) memcpy(tr, b->pose_pin, sizeof(double) * 6 * nf);
+    if (ok) memcpy(ok, b->pose_pin + sizeof(double) * 6 * nf, sizeof(int) * nf);
+    if (n_inl) memcpy(n_inl, b->pose_pin + sizeof(double) * 6 * nf + sizeof(int) * nf, sizeof(int) * nf);
     return VISO_OK;
 }
 

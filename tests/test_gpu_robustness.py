@@ -195,6 +195,17 @@ def test_synchronous_upload_waits_for_a_run_in_flight(viso):
     b.close(); ctx.close()
 
 
+def test_a_context_closed_first_takes_its_batches_along(viso):
+    """The order an exception or the garbage collector can produce: the context goes first.  Its batches are closed with it
+    (viso_batch_destroy on a destroyed context aborted the process from inside the HIP runtime)."""
+    ctx = libviso_amd.Context(0)
+    b1, b2 = libviso_amd.Batch(ctx, 3, 64), libviso_amd.Batch(ctx, 2, 32)
+    ctx.close()
+    assert b1.h is None and b2.h is None
+    b1.close(); b2.close()      # no-ops
+    del b1, b2, ctx
+
+
 def test_hypotheses_getter_with_a_wider_capacity(viso):
     """viso_batch_get_hypotheses2 with arrays of [n_frames][capacity > ransac_iter]: every frame's row at the caller's stride
     (the first version forwarded to the tight getter and put frame 1's row where frame 0's padding belonged)."""
