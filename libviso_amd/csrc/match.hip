@@ -42,6 +42,7 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 // bucket.  Also: the image's y range (the matchers bucket their windows by y), the number of non-NaN x, and the y
 // order inside every block of 64 consecutive entries (ImageView::qord).
 #define VISO_IMG_THREADS 512
+#define VISO_KP_REGS 4
 
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
                                                                    uint32_t* zero_words, int n_zero, int* r8zero) {
@@ -65,11 +66,27 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     // ---- x extent (x0 = smallest x, x1 = largest non-NaN x: the bucket map), finite y extent, number of non-NaN x
     float xmn = __builtin_huge_valf(), xmx = -__builtin_huge_valf(), ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
     float nvx = 0.f;
-    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
-        const float2 k = I.kp[i];
+    // the kernel walks the keypoints three times (extent, histogram, scatter): a thread's first VISO_KP_REGS of them stay
+    // in registers (all of them up to 2048 keypoints per image), so that only the first walk waits for memory
+    float2 kreg[VISO_KP_REGS];
+#pragma unroll
+    for (int u = 0; u < VISO_KP_REGS; ++u) {
+        const int i = threadIdx.x + u * VISO_IMG_THREADS;
+        kreg[u] = i < n ? I.kp[i] : make_float2(0.f, 0.f);
+    }
+    // visit(i, k) for every keypoint of this thread: the register ones (compile-time slots), then the rest from memory
+    auto walk = [&](auto visit) {
+#pragma unroll
+        for (int u = 0; u < VISO_KP_REGS; ++u) {
+            const int i = threadIdx.x + u * VISO_IMG_THREADS;
+            if (i < n) visit(i, kreg[u]);
+        }
+        for (int i = threadIdx.x + VISO_KP_REGS * VISO_IMG_THREADS; i < n; i += VISO_IMG_THREADS) visit(i, I.kp[i]);
+    };
+    walk([&](int, float2 k) {
         if (k.x == k.x) { xmn = fminf(xmn, k.x); xmx = fmaxf(xmx, k.x); nvx += 1.f; }
         if (fabsf(k.y) < 3.0e38f) { ymn = fminf(ymn, k.y); ymx = fmaxf(ymx, k.y); }
-    }
+    });
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         xmn = fminf(xmn, __shfl_xor(xmn, m)); xmx = fmaxf(xmx, __shfl_xor(xmx, m));
@@ -97,7 +114,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     __syncthreads();
     const float x0 = s_x[0], scale = s_x[1];
     // ---- counting sort by column bucket
-    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) atomicAdd(&s_cnt[bucket_of(I.kp[i].x, x0, scale)], 1);
+    walk([&](int, float2 k) { atomicAdd(&s_cnt[bucket_of(k.x, x0, scale)], 1); });
     __syncthreads();
     if (wv == 0) {   // exclusive scan of the 256 counts: 4 per lane + wave scan
         int c[4], tot = 0;
@@ -116,8 +133,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     }
     __syncthreads();
     const int n64 = (n + 63) & ~63;
-    for (int i = threadIdx.x; i < n; i += VISO_IMG_THREADS) {
-        const float2 k = I.kp[i];
+    walk([&](int i, float2 k) {
         const int p = atomicAdd(&s_cnt[bucket_of(k.x, x0, scale)], 1);   // running offset of the bucket
         I.skp[p] = k;
         I.sidx[p] = i;
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         uint32_t yk = yb ^ ((yb >> 31) ? 0xffffffffu : 0x80000000u);
         if (yk == 0xffffffffu) yk = 0xfffffffeu;   // keep "past n" strictly last
         ykey[p] = yk;
-    }
+    });
     for (int j = n + threadIdx.x; j < n64; j += VISO_IMG_THREADS) ykey[j] = 0xffffffffu;
     __syncthreads();
     // ---- y order inside every block of 64 positions (the matcher kernels score rounds of y-adjacent queries of such
