@@ -536,7 +536,7 @@ static int launch_inlier_count(hipStream_t s, const SolverArgs& a, int max_point
 #define REFIT_WAVES (REFIT_THREADS / 64)
 
 // ordered (ascending index) compaction of the inliers of `tr` into out[];
-// returns the count to every thread.  scratch: >= 8 ints of LDS.
+// returns the count to every thread.  scratch: >= REFIT_WAVES ints of LDS.
 __device__ int block_inliers(const double* tr, const SolverParamsDev& sp, const double* X,
                              const double* obs, int ld, int m, int* out, int* scratch,
                              double* last_err2) {
@@ -571,12 +571,31 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// Sum of a double over the wave, valid in lane 63: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source
+// add 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (gfx9 reduction idiom; the halves of the
+// double move as two 32-bit DPP moves).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    v += dpp_f64<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of every row = the row's sum
+    v += dpp_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = the wave's sum
+    return v;
+}
+
 // minimize_reproj over an arbitrary active list, one workgroup.  Every thread
 // accumulates its points' contribution to the 21+6 sums, the workgroup reduces
 // them (wave shuffles, then a fixed-order sum over the waves in LDS), the first
 // wave solves the 6x6 system with ONE ENTRY PER LANE (lu_lane_step: bit-identical
 // to lu_solve6, see ransac_coop_kernel) and publishes the step.  tr_s: 6 doubles
-// in LDS (in/out).  red: >= 4*27+8 doubles of LDS.  Returns 1/0 to every thread.
+// in LDS (in/out).  red: >= REFIT_WAVES*27+8 doubles of LDS.  Returns 1/0 to every thread.
 // The rotation table is wave uniform: lanes 0..2 take the three sincos, the 36
 // entries live in SCALAR registers while the points are accumulated (round 3
 // kept them, the Jacobian rows, the 27 sums and lane 0's 6x6 matrix in 254
@@ -613,13 +632,12 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
         for (int k = 0; k < 27; ++k) S[k] = 0;
         for (int i = threadIdx.x; i < n; i += REFIT_THREADS)
             accumulate_point_rows(R, sp, X, obs, ld, active[i], i, S);
-        // wave reduction of the 27 sums
+        // wave reduction of the 27 sums: DPP row shifts and row broadcasts, the total in lane 63 (six LDS-crossbar
+        // butterflies per sum were 5.8 us of an iteration: two ds_bpermute and their wait per step)
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            double v = S[k];
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) v += __shfl_xor(v, mk);
-            if (lane == 0) red[wave * 27 + k] = v;
+            const double v = wave_sum_to_lane63(S[k]);
+            if (lane == 63) red[wave * 27 + k] = v;
             if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four chains in flight, not 27: registers
         }
         __syncthreads();
@@ -658,10 +676,10 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
                     for (int j = 0; j < 6; ++j) tr_s[j] = tr[j] + Bs[j];
                 }
             }
-            if (lane == 0) reinterpret_cast<int*>(red + 4 * 27)[0] = status;
+            if (lane == 0) reinterpret_cast<int*>(red + REFIT_WAVES * 27)[0] = status;
         }
         __syncthreads();
-        const int status = reinterpret_cast<int*>(red + 4 * 27)[0];
+        const int status = reinterpret_cast<int*>(red + REFIT_WAVES * 27)[0];
         __syncthreads();
         if (status == 1) return 1;
         if (status == 2) return 0;
@@ -678,15 +696,33 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
         if (threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // vector<double> tr(6,0), :1312 (no memset in front of the stage)
         return;
     }
-    if (threadIdx.x == 0) {
-        int best = -1, best_cnt = 0;
-        for (int h = 0; h < a.iters; ++h)
-            if (S.ok_h[h] && S.cnt_h[h] > best_cnt) { best_cnt = S.cnt_h[h]; best = h; }   // strict >, :1564
-        scratch[4] = best;
-        for (int j = 0; j < 6; ++j) tr_s[j] = best >= 0 ? S.tr_h[6 * best + j] : 0.0;
+    // The hypothesis with the largest support, the FIRST of them among equals (strict >, :1564), none without support:
+    // the maximum of (count << 32 | ~index) over the hypotheses, all threads at once (one thread walking the 200
+    // flags and counts in memory was 7 of this kernel's 54 us on a single frame)
+    {
+        unsigned long long key = 0;
+        for (int h = threadIdx.x; h < a.iters; h += REFIT_THREADS) {
+            const int c = S.ok_h[h] ? S.cnt_h[h] : 0;
+            const unsigned long long kh = c > 0 ? ((unsigned long long)(unsigned)c << 32) | (unsigned)~h : 0ull;
+            key = kh > key ? kh : key;
+        }
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            const unsigned long long o = __shfl_xor(key, mk);
+            key = o > key ? o : key;
+        }
+        unsigned long long* wkey = reinterpret_cast<unsigned long long*>(red);   // red is free until gn_block
+        if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
+        __syncthreads();
+        key = wkey[0];
+#pragma unroll
+        for (int w = 1; w < REFIT_WAVES; ++w) key = wkey[w] > key ? wkey[w] : key;
+        const int best = key ? (int)~(unsigned)key : -1;
+        if (threadIdx.x < 6) tr_s[threadIdx.x] = best >= 0 ? S.tr_h[6 * best + threadIdx.x] : 0.0;
+        if (threadIdx.x == 0) scratch[REFIT_WAVES] = best;
     }
     __syncthreads();
-    const int best = scratch[4];
+    const int best = scratch[REFIT_WAVES];
     __syncthreads();
     if (best < 0) {   // no hypothesis found any support: best_inliers stays empty, :1571
         if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
@@ -720,8 +756,8 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
 // measured and lose: the chain's latency then limits the batches in flight).
 __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs a) {
     __shared__ double tr_s[6];
-    __shared__ double red[4 * 27 + 8];
-    __shared__ int scratch[8];
+    __shared__ double red[REFIT_WAVES * 27 + 8];
+    __shared__ int scratch[REFIT_WAVES + 8];
     __builtin_amdgcn_s_setprio(3);                   // see ransac_hyp_kernel
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         refit_item(a, item, tr_s, red, scratch);
@@ -773,7 +809,7 @@ struct GnArgs {
 
 __global__ __launch_bounds__(REFIT_THREADS) void minimize_reproj_kernel(GnArgs a) {
     __shared__ double tr_s[6];
-    __shared__ double red[4 * 27 + 8];
+    __shared__ double red[REFIT_WAVES * 27 + 8];
     if (threadIdx.x < 6) tr_s[threadIdx.x] = a.tr_in[threadIdx.x];
     __syncthreads();
     const int ok = gn_block(a.X, a.obs, a.ld, a.active, a.n, tr_s, a.sp, red);
@@ -783,7 +819,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void minimize_reproj_kernel(GnArgs a
 }
 
 __global__ __launch_bounds__(REFIT_THREADS) void get_inliers_kernel(GnArgs a) {
-    __shared__ int scratch[8];
+    __shared__ int scratch[REFIT_WAVES + 8];
     __shared__ double last;
     double tr[6];
 #pragma unroll

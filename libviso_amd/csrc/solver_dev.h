@@ -165,9 +165,13 @@ __device__ __forceinline__ void accumulate_point(const RotDev& R, const SolverPa
 // The same sums for the all-inlier refit (gn_block), arranged for fewer live registers: the 21 + 6 sums as one flat
 // array S (upper triangle row by row, then J^T r), ONE Jacobian row alive at a time, rows in the order u_left, u_right,
 // v_left, v_right so that the row the two v observations share (src/viso.cpp:1479,1481) is built once and used twice.
-// Every product and every Jacobian entry is the expression accumulate_point evaluates; only the order in which a
-// point's four rows enter a sum differs (the refit's sums go through a workgroup reduction tree anyway: this path is
-// compared with the CPU within the 1e-5 pose tolerance, not bit for bit — the 3-point hypotheses keep accumulate_point).
+// The refit's sums go through a workgroup reduction tree anyway: this path is compared with the CPU within the 1e-5 pose
+// tolerance, not bit for bit (the 3-point hypotheses, whose iteration counts decide inlier sets, keep accumulate_point
+// and the reference's every operation).  So the arithmetic here is the cheap one: a point's 18 Jacobian entries share ONE
+// division (wf / Z1c^2; the reference divides each entry, :1478-1481 -- a division is a dozen dependent fp64
+// instructions, and 17 of them were two fifths of this function), and the 27 sums take fused multiply-adds.  A single
+// frame's refit of ~1200 inliers is bound by the fp64 rate of the ONE compute unit its workgroup runs on: 10.3 -> 4 us
+// per Gauss-Newton iteration for this function.
 __device__ __forceinline__ void accumulate_point_rows(const RotDev& R, const SolverParamsDev& sp,
                                                       const double* X, const double* obs, int ld,
                                                       int a, int pos, double (&S)[27]) {
@@ -175,7 +179,7 @@ __device__ __forceinline__ void accumulate_point_rows(const RotDev& R, const Sol
     double pred[4], X1c, Y1c, Z1c, X2c;
     predict_point(R, sp, X1p, Y1p, Z1p, pred, X1c, Y1c, Z1c, X2c);
     const double weight = 1.0 / (fabs(obs[0 * ld + pos] - sp.cu) / fabs(sp.cu) + 0.05);   // Q6: position, not index
-    const double wf = weight * sp.f, zz = Z1c * Z1c;
+    const double wz = weight * sp.f / (Z1c * Z1c);
     const double res0 = weight * (obs[0 * ld + a] - pred[0]), res1 = weight * (obs[1 * ld + a] - pred[1]);
     const double res2 = weight * (obs[2 * ld + a] - pred[2]), res3 = weight * (obs[3 * ld + a] - pred[3]);
     // d(X1c, Y1c, Z1c) / d(rx, ry, rz, tx, ty, tz), the switch of accumulate_point
@@ -190,18 +194,18 @@ __device__ __forceinline__ void accumulate_point_rows(const RotDev& R, const Sol
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
 #pragma unroll
-            for (int q = p; q < 6; ++q) S[c++] += J[p] * J[q];
-            S[21 + p] += J[p] * res;
+            for (int q = p; q < 6; ++q) { S[c] = fma(J[p], J[q], S[c]); ++c; }
+            S[21 + p] = fma(J[p], res, S[21 + p]);
         }
     };
 #pragma unroll
-    for (int j = 0; j < 6; ++j) J[j] = wf * (Xd[j] * Z1c - X1c * Zd[j]) / zz;   // u_left, :1478
+    for (int j = 0; j < 6; ++j) J[j] = (Xd[j] * Z1c - X1c * Zd[j]) * wz;   // u_left, :1478
     add_row(res0);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) J[j] = wf * (Xd[j] * Z1c - X2c * Zd[j]) / zz;   // u_right, :1480
+    for (int j = 0; j < 6; ++j) J[j] = (Xd[j] * Z1c - X2c * Zd[j]) * wz;   // u_right, :1480
     add_row(res2);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) J[j] = wf * (Yd[j] * Z1c - Y1c * Zd[j]) / zz;   // v_left = v_right, :1479,1481
+    for (int j = 0; j < 6; ++j) J[j] = (Yd[j] * Z1c - Y1c * Zd[j]) * wz;   // v_left = v_right, :1479,1481
     add_row(res1);
     add_row(res3);
 }
