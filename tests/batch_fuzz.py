@@ -11,6 +11,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 POSE_TOL = 1e-5
 
 
+def _solved_alike(ok, n_inl, want):
+    """the same frames solved, and the same support where a pose was found.  (A frame WITHOUT a pose reports the support
+    of its best failed hypothesis; on a handful of circle matches that can be a 3-point Gauss-Newton run that wanders
+    through rotations of thousands of radians, where one ulp of sincos -- the device's differs from libm's in 3 % of
+    arguments, tools/experiments/sincos_parity.hip -- decides whether it comes back: not compared.)"""
+    ok, w = np.asarray(ok), np.asarray(want["ok"])
+    return np.array_equal(ok, w) and np.array_equal(np.asarray(n_inl)[ok != 0], np.asarray(want["n_inl"])[w != 0])
+
+
 def one(rng, L, O, ctx):
     from libviso_amd import synth
     from libviso_amd.abi import MatchParams
@@ -45,7 +54,7 @@ def one(rng, L, O, ctx):
     finally:
         b.close()
     what = "nf=%d n_kp=%d cap=%d %dx%d kind=%d variant=%d seed=%d first=%d" % (nf, n_kp, cap, width, height, kind, variant, seed, first)
-    if not (np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"])):
+    if not (_solved_alike(ok, n_inl, want)):
         return False, what + " | ok %s / %s, inliers %s / %s" % (want["ok"], ok, want["n_inl"], n_inl)
     if not (np.array_equal(sc, want["scored"]) and np.array_equal(mo, want["m_out"])):
         return False, what + " | scored / matches differ"
@@ -112,12 +121,23 @@ def one_images(rng, L, O, ctx):
                         return False, what + " | keypoints of frame %d side %d differ" % (t, side)
         tr, ok, n_inl = b.poses()
         sc, mo = b.counters()
+        detail = ""
+        if not (_solved_alike(ok, n_inl, want)):
+            # what the solver was given: the join of the device's own match lists, by the oracle's nested loops
+            for t in range(1, nf):
+                r_, circ, pcl, nc = O.match_circle(b.matches(0, t), b.matches(0, t - 1), b.matches(1, t), b.matches(2, t))
+                c1, p1 = b.circle(t)
+                detail += " [frame %d: matches %s, join %d (oracle's loops on the same lists: %d)]" % (t, [len(b.matches(w, t)) for w in range(3)], len(c1), nc)
     finally:
         b.close()
-    if not (np.array_equal(ok, want["ok"]) and np.array_equal(n_inl, want["n_inl"])):
-        return False, what + " | ok %s / %s, inliers %s / %s" % (want["ok"], ok, want["n_inl"], n_inl)
     if not (np.array_equal(sc, want["scored"]) and np.array_equal(mo, want["m_out"])):
-        return False, what + " | scored / matches differ"
+        return False, what + " | scored / matches differ: %s / %s" % (want["m_out"].tolist(), mo.tolist())
+    if not (_solved_alike(ok, n_inl, want)):
+        if os.environ.get("VISO_FUZZ_DUMP"):   # the sequence as the solver stage saw it, for tests/solver_case.py
+            p = s["param"]
+            np.savez(os.environ["VISO_FUZZ_DUMP"], kp=kp, desc=desc, n=n, F=s["F"], seed=seed, first=first,
+                     param=np.frombuffer(bytes(p), np.uint8))
+        return False, what + " | ok %s / %s, inliers %s / %s, seed %d first %d%s" % (want["ok"], ok, want["n_inl"], n_inl, seed, first, detail)
     for t in range(1, nf):
         if ok[t]:
             a, r = L.tr2mat(tr[t]), O.tr2mat(want["tr"][t])
