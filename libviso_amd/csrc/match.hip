@@ -41,8 +41,12 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 // Which entry lands where inside a bucket depends on the atomics' order; results do not.  NaN x goes to the last
 // bucket.  Also: the image's y range (the matchers bucket their windows by y), the number of non-NaN x, and the y
 // order inside every block of 64 consecutive entries (ImageView::qord).
+#ifndef VISO_IMG_THREADS
 #define VISO_IMG_THREADS 512
+#endif
+#ifndef VISO_KP_REGS
 #define VISO_KP_REGS 4
+#endif
 
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
                                                                    uint32_t* zero_words, int n_zero, int* r8zero) {
