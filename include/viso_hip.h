@@ -344,7 +344,8 @@ int viso_batch_get_circle(viso_batch* b, int t, int32_t* circ, int32_t* pcl, int
 int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok,
                         int32_t* inliers, int* n_inl);
 /* All frames at once: tr [n_frames][6], ok [n_frames], n_inl [n_frames]
- * (entry 0 is zero/0: the first frame has no predecessor, :1256-1260). */
+ * (entry 0 is zero/0: the first frame has no predecessor, :1256-1260).  Waits for the batch's streams, then reads a
+ * pinned host mirror that the last kernel of every viso_batch_run / viso_batch_run_images fills: no device copy. */
 int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl);
 /* Per-hypothesis state of the last run's RANSAC stage (diagnostics / tests): tr_h [n_frames][ransac_iter][6],
  * ok_h, cnt_h [n_frames][ransac_iter] (support sizes; frame 0 unused), *n_undecided = hypotheses that needed the
