@@ -199,7 +199,8 @@ int viso_extract_descriptors(const uint8_t* img, int rows, int cols,
 
 /* cv::cornerHarris(img, R, 3, 5, k, BORDER_DEFAULT) restated in OpenCV's evaluation order (scale folded into the float
  * smoothing taps, row pass then column pass with the symmetric grouping, box filter as row sums then column sums; what
- * an algorithm-level restatement cannot pin is listed in oracle/viso_oracle.c); resp: rows x cols float. */
+ * an algorithm-level restatement cannot pin is listed in oracle/viso_oracle.c); resp: rows x cols float.
+ * ($VISO_HARRIS_BAND = rows per wave of the response kernel, 1..4096: a tuning / test aid, the image does not depend on it.) */
 int viso_harris_response(const uint8_t* img, int rows, int cols, double k, float* resp);
 /* HarrisBinnedFeatureDetector::detectImpl, src/viso.cpp:926-975 (reference defaults:
  * n_features 1200, nbinx 24, nbiny 5).  kp: up to n_features x 2 (x,y);
