@@ -77,9 +77,13 @@ typedef struct viso_ctx viso_ctx;
 /* device: HIP device ordinal.  stream: a hipStream_t to run on, or NULL to let
  * the context create its own.  Returns NULL on failure (viso_last_error()). */
 viso_ctx* viso_ctx_create(int device, void* stream);
-/* Waits for the stream, frees the context.  VISO_OK, or VISO_ERR_HIP with the first HIP error met in
- * viso_last_error() (everything that can be freed still is).  Destroy batches first, and destroy both before
- * the process starts exiting: not from static destructors that may run after the HIP runtime's own. */
+/* Waits for the streams, frees the context.  VISO_OK, or VISO_ERR_HIP with the first HIP error met in
+ * viso_last_error() (everything that can be freed still is).  Batches of the context that are still alive are destroyed
+ * with it, FIRST (the library keeps a registry of its live handles): the intended order is batches, then context, but the
+ * other order costs nothing worse than a return code -- a later viso_batch_destroy of such a batch is a no-op (VISO_OK, once),
+ * every other call on it returns VISO_ERR_ARG, and so does anything on a context or batch handle that was destroyed before
+ * or never existed.  Destroy handles before the process starts exiting: not from static destructors that may run after the
+ * HIP runtime's own. */
 int viso_ctx_destroy(viso_ctx* ctx);
 /* hipStream_t the context launches on.  Every context also owns a second stream for the RANSAC
  * stage of its batches (it runs beside the next run's matcher; ordered by events, waited for by
@@ -166,7 +170,11 @@ int viso_get_inliers(const double* X3xM, const double* obs4xM, int m,
 /* ransac_minimize_reproj, src/viso.cpp:1543-1580.  samples: ransac_iter x 3
  * ascending distinct indices (what randomsample(3,m,.) :87-107 yields), or
  * NULL to draw them from viso_ransac_samples(seed, frame, ...).  best_tr is
- * in/out like the reference's.  best_inl: up to m indices. */
+ * in/out like the reference's: it is assigned only when a hypothesis improves the
+ * support (:1564-1568), so the caller's values survive when no hypothesis finds any
+ * (return 0, *n_inl = 0) and for m < 3; with a support of 1..5 it is the best
+ * hypothesis' motion (return 0, :1571), otherwise the refit's (the partly iterated
+ * value when the refit fails, :1572).  best_inl: up to m indices. */
 int viso_ransac_minimize_reproj(const double* X3xM, const double* obs4xM, int m,
                                 double best_tr[6], int32_t* best_inl, int* n_inl,
                                 const viso_param* p, const int32_t* samples,
@@ -269,7 +277,8 @@ const char* viso_plain_profile_name(int fn);
 typedef struct viso_batch viso_batch;
 
 viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, int dlen);
-/* Waits for the context's stream, frees the batch; return value as viso_ctx_destroy. */
+/* Waits for the context's streams, frees the batch; return value as viso_ctx_destroy (VISO_OK also for a batch its context
+ * has already taken along; VISO_ERR_ARG for a handle that is not, or no longer, a batch). */
 int viso_batch_destroy(viso_batch* b);
 
 /* Stream rule for everything below: a batch's kernels run asynchronously on its context's stream.  Every call

@@ -68,6 +68,10 @@ struct viso_batch {
 };
 #define VISO_EVENT_POOL 64
 
+// A handle the library does not know -- null, destroyed, or taken along by viso_ctx_destroy of its context (ctx.hip keeps the
+// registry): every entry point answers VISO_ERR_ARG instead of following a freed pointer.
+static inline bool dead(const viso_batch* b) { return !b || !viso_batch_live(b); }
+
 static int enter(viso_batch* b) {   // every entry point that allocates, copies or launches
     HIP_TRY(hipSetDevice(b->ctx->device));
     return VISO_OK;
@@ -102,6 +106,17 @@ static void free_solver_bufs(viso_batch* b) {
 // viso_ctx_destroy it must run before the HIP runtime starts unloading (not from static destructors).
 extern "C" int viso_batch_destroy(viso_batch* b) {
     if (!b) return VISO_OK;
+    // the registry decides: a live handle is ours to free; one that viso_ctx_destroy of its context already freed is a no-op
+    // (the context left a tombstone for it); anything else -- a second destroy, a pointer that never was a batch -- is an
+    // argument error, never a dereference
+    const int st = viso_batch_unregister(b);
+    if (st == 0) return VISO_OK;
+    if (st < 0) { viso_set_error("viso_batch_destroy: not a live batch handle"); return VISO_ERR_ARG; }
+    return viso_batch_free(b);
+}
+
+// Frees a batch that has left the registry (viso_batch_destroy, or viso_ctx_destroy for the batches still alive on it).
+int viso_batch_free(viso_batch* b) {
     hipError_t first = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     note(hipSetDevice(b->ctx->device));
@@ -211,6 +226,7 @@ static int build_solver_items(viso_batch* b) {
 
 extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, int dlen) {
     if (!ctx || n_frames <= 0 || cap <= 0 || dlen <= 0) { viso_set_error("viso_batch_create: bad argument"); return nullptr; }
+    if (!viso_ctx_live(ctx)) { viso_set_error("viso_batch_create: not a live context handle"); return nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { viso_set_error("hipSetDevice failed"); return nullptr; }
     viso_batch* b = new viso_batch();
     b->ctx = ctx; b->nf = n_frames; b->cap = cap; b->dlen = dlen; b->iters = 0;
@@ -284,20 +300,21 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     }
     for (int k = 0; r >= 0 && k < VISO_NPIN_SLOTS; ++k)
         if (hipEventCreateWithFlags(&b->n_pin_ev[k], hipEventDisableTiming) != hipSuccess) { b->n_pin_ev[k] = nullptr; r = VISO_ERR_HIP; }
-    if (r < 0) { viso_batch_destroy(b); return nullptr; }
+    if (r < 0) { viso_batch_free(b); return nullptr; }
     bool ok = hipMemset(b->zero, 0, 8 * sizeof(int)) == hipSuccess &&
               hipMemset(b->n, 0, nf * 2 * sizeof(int)) == hipSuccess &&
               hipMemset(b->m_cnt, 0, 3 * nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->mc, 0, nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->tr, 0, b->pose_bytes) == hipSuccess &&
               hipMemset(b->scored, 0, b->zeroed_bytes) == hipSuccess;
-    if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_destroy(b); return nullptr; }
+    if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_free(b); return nullptr; }
+    if (!viso_batch_register(ctx, b)) { viso_set_error("viso_batch_create: the context was destroyed meanwhile"); viso_batch_free(b); return nullptr; }
     return b;
 }
 
 extern "C" int viso_batch_upload(viso_batch* b, int f0, int nf, const float* kp, const float* desc,
                                  const int32_t* n) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload: bad argument"); return VISO_ERR_ARG; }
+    if (dead(b) || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload: bad argument"); return VISO_ERR_ARG; }
     for (int i = 0; i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
     if (nf == 0) return VISO_OK;
@@ -347,7 +364,7 @@ static int stage_n_async(viso_batch* b, int f0, int nf, const int32_t* n, hipStr
 // copied through a small pinned slot of the batch, so the caller's n array need not be pinned.
 extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const float* kp, const float* desc,
                                        const int32_t* n) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload_async: bad argument"); return VISO_ERR_ARG; }
+    if (dead(b) || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc || !n))) { viso_set_error("viso_batch_upload_async: bad argument"); return VISO_ERR_ARG; }
     for (int i = 0; i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("viso_batch_upload_async: n[%d]=%d exceeds cap %d", i, n[i], b->cap); return VISO_ERR_ARG; }
     if (nf == 0) return VISO_OK;
@@ -368,7 +385,7 @@ extern "C" int viso_batch_upload_async(viso_batch* b, int f0, int nf, const floa
 // the last upload decides which pack kernel the next run uses.  sync != 0: wait for the copies.
 static int upload_i16_impl(viso_batch* b, int f0, int nf, const float* kp, const int16_t* desc16, const int32_t* n, bool sync,
                            const char* who) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc16 || !n))) { viso_set_error("%s: bad argument", who); return VISO_ERR_ARG; }
+    if (dead(b) || f0 < 0 || nf < 0 || f0 + nf > b->nf || (nf && (!kp || !desc16 || !n))) { viso_set_error("%s: bad argument", who); return VISO_ERR_ARG; }
     if (b->dlen > VISO_ROW) { viso_set_error("%s: int16 descriptors need dlen <= %d", who, VISO_ROW); return VISO_ERR_UNSUPPORTED; }
     for (int i = 0; i < 2 * nf; ++i)
         if (n[i] < 0 || n[i] > b->cap) { viso_set_error("%s: n[%d]=%d exceeds cap %d", who, i, n[i], b->cap); return VISO_ERR_ARG; }
@@ -395,7 +412,7 @@ extern "C" int viso_batch_upload_i16_async(viso_batch* b, int f0, int nf, const 
 
 extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
                                               const float* kp, const int32_t* n) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
+    if (dead(b) || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
         viso_set_error("viso_batch_upload_images_async: bad argument");
         return VISO_ERR_ARG;
     }
@@ -420,13 +437,13 @@ extern "C" int viso_batch_upload_images_async(viso_batch* b, int f0, int nf, con
 
 // Diagnostics: the shift of the 8-bit planes the last run used (matcher variant 6; see VISO_R8_* in csrc/common.h).
 extern "C" int viso_batch_get_row8_shift(viso_batch* b, int* shift) {
-    if (!b || !shift) { viso_set_error("viso_batch_get_row8_shift: bad argument"); return VISO_ERR_ARG; }
+    if (dead(b) || !shift) { viso_set_error("viso_batch_get_row8_shift: bad argument"); return VISO_ERR_ARG; }
     *shift = b->r8last;
     return VISO_OK;
 }
 
 extern "C" int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, void** n) {
-    if (!b) return VISO_ERR_ARG;
+    if (dead(b)) return VISO_ERR_ARG;
     if (kp) *kp = b->kp;
     if (desc) *desc = b->desc;
     if (n) *n = b->n;
@@ -436,7 +453,7 @@ extern "C" int viso_batch_device_ptrs(viso_batch* b, void** kp, void** desc, voi
 extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* stereo,
                                      const viso_match_params* temporal, const viso_param* p,
                                      uint64_t seed, uint64_t first_frame_index) {
-    if (!b || !stereo || !temporal || !p || p->ransac_iter < 0 || stereo->max_neighbors <= 0 || temporal->max_neighbors <= 0) {
+    if (dead(b) || !stereo || !temporal || !p || p->ransac_iter < 0 || stereo->max_neighbors <= 0 || temporal->max_neighbors <= 0) {
         viso_set_error("viso_batch_set_params: bad argument");
         return VISO_ERR_ARG;
     }
@@ -469,13 +486,13 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
 }
 
 extern "C" int viso_batch_kernel_timing(viso_batch* b, int enable) {
-    if (!b) return VISO_ERR_ARG;
+    if (dead(b)) return VISO_ERR_ARG;
     b->timing = enable != 0;
     return VISO_OK;
 }
 
 static int run_matcher_impl(viso_batch* b, bool from_images) {
-    if (!b || !b->params_set) { viso_set_error("viso_batch_run: parameters not set"); return VISO_ERR_ARG; }
+    if (dead(b) || !b->params_set) { viso_set_error("viso_batch_run: parameters not set"); return VISO_ERR_ARG; }
     if (from_images && (!b->images || b->dlen != VISO_DESC_LEN)) {
         viso_set_error("viso_batch_run_images: no images uploaded (or descriptor length is not 121)");
         return VISO_ERR_ARG;
@@ -548,7 +565,7 @@ static int run_matcher_impl(viso_batch* b, bool from_images) {
 // Time stamps of a run: which = 0 before the run's uploads, 1 after them (both on the context's stream); the end of
 // the run is stamped by viso_batch_run* itself once stamping is on (i.e. after the first viso_batch_stamp call).
 extern "C" int viso_batch_stamp(viso_batch* b, int which) {
-    if (!b || which < 0 || which > 1) { viso_set_error("viso_batch_stamp: bad argument"); return VISO_ERR_ARG; }
+    if (dead(b) || which < 0 || which > 1) { viso_set_error("viso_batch_stamp: bad argument"); return VISO_ERR_ARG; }
     int r;
     if ((r = enter(b)) < 0) return r;
     for (int k = 0; k < 3; ++k)
@@ -563,7 +580,7 @@ extern "C" int viso_batch_stamp(viso_batch* b, int which) {
 
 // Waits for the batch; ms[0] = stamp 0 -> stamp 1 (the uploads), ms[1] = stamp 1 -> behind the run's last kernel.
 extern "C" int viso_batch_stamp_ms(viso_batch* b, double ms[2]) {
-    if (!b || !ms || !b->stamps) { viso_set_error("viso_batch_stamp_ms: no stamps taken"); return VISO_ERR_ARG; }
+    if (dead(b) || !ms || !b->stamps) { viso_set_error("viso_batch_stamp_ms: no stamps taken"); return VISO_ERR_ARG; }
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     float a = 0, c = 0;
     HIP_TRY(hipEventElapsedTime(&a, b->ev_stamp[0], b->ev_stamp[1]));
@@ -590,7 +607,7 @@ extern "C" int viso_batch_run_images(viso_batch* b, int matcher_only) {
 
 extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uint8_t* images, int rows, int cols,
                                         const float* kp, const int32_t* n) {
-    if (!b || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
+    if (dead(b) || f0 < 0 || nf < 0 || f0 + nf > b->nf || rows <= 0 || cols <= 0 || (nf && !images) || ((kp == nullptr) != (n == nullptr))) {
         viso_set_error("viso_batch_upload_images: bad argument");
         return VISO_ERR_ARG;
     }
@@ -621,7 +638,7 @@ extern "C" int viso_batch_upload_images(viso_batch* b, int f0, int nf, const uin
 // HarrisBinnedFeatureDetector on every uploaded image (src/viso.cpp:1226-1227): fills the batch's
 // keypoint arrays and counts on the device; viso_batch_run_images then extracts descriptors there too.
 extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int nbiny, double k) {
-    if (!b || !b->images) { viso_set_error("viso_batch_detect: no images uploaded"); return VISO_ERR_ARG; }
+    if (dead(b) || !b->images) { viso_set_error("viso_batch_detect: no images uploaded"); return VISO_ERR_ARG; }
     if (n_features < 0 || nbinx <= 0 || nbiny <= 0 || b->img_cols / nbinx <= 0 || b->img_rows / nbiny <= 0 ||
         (long long)nbinx * nbiny > 16384) {
         viso_set_error("viso_batch_detect: bad bin geometry");
@@ -659,7 +676,7 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
 
 // Keypoints of frame t, image side (after viso_batch_detect or an upload).
 extern "C" int viso_batch_get_keypoints(viso_batch* b, int t, int side, float* kp, int* n_out) {
-    if (!b || t < 0 || t >= b->nf || side < 0 || side > 1 || !n_out) { viso_set_error("viso_batch_get_keypoints: bad argument"); return VISO_ERR_ARG; }
+    if (dead(b) || t < 0 || t >= b->nf || side < 0 || side > 1 || !n_out) { viso_set_error("viso_batch_get_keypoints: bad argument"); return VISO_ERR_ARG; }
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     int n = 0;
     HIP_TRY(hipMemcpy(&n, b->n + (size_t)t * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
@@ -698,7 +715,7 @@ static int run_rest(viso_batch* b) {
 }
 
 extern "C" int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* n_launches) {
-    if (!b) return VISO_ERR_ARG;
+    if (dead(b)) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     double tot = b->ev_ms_sum;
     int n = b->ev_n;
@@ -714,7 +731,7 @@ extern "C" int viso_batch_kernel_ms(viso_batch* b, double* matcher_ms_avg, int* 
     return VISO_OK;
 }
 
-static bool slot_ok(viso_batch* b, int which, int t) { return b && which >= 0 && which < 3 && t >= 0 && t < b->nf; }
+static bool slot_ok(viso_batch* b, int which, int t) { return !dead(b) && which >= 0 && which < 3 && t >= 0 && t < b->nf; }
 
 extern "C" int viso_batch_get_matches(viso_batch* b, int which, int t, int32_t* out_match, int* out_n) {
     if (!slot_ok(b, which, t) || !out_n) { viso_set_error("viso_batch_get_matches: bad argument"); return VISO_ERR_ARG; }
@@ -753,7 +770,7 @@ extern "C" int viso_batch_get_pose(viso_batch* b, int t, double tr[6], int* ok, 
 }
 
 extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int32_t* n_inl) {
-    if (!b) return VISO_ERR_ARG;
+    if (dead(b)) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     // the pinned mirror of the device block (run_rest's last kernel; zeros before the first run, like the device's)
     const size_t nf = (size_t)b->nf;
@@ -767,7 +784,7 @@ extern "C" int viso_batch_get_poses(viso_batch* b, double* tr, int32_t* ok, int3
 // cnt_h [n_frames][iters] (frame 0 unused), *n_undecided = hypotheses the lane-per-hypothesis kernel handed on.
 extern "C" int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, double* tr_h, int32_t* ok_h, int32_t* cnt_h,
                                           int32_t* n_undecided) {
-    if (!b || iters_capacity < (b->iters > 0 ? b->iters : 1)) {
+    if (dead(b) || iters_capacity < (b->iters > 0 ? b->iters : 1)) {
         viso_set_error("viso_batch_get_hypotheses2: arrays hold %d hypotheses per frame, the batch has %d", iters_capacity, b ? b->iters : 0);
         return VISO_ERR_ARG;
     }
@@ -788,7 +805,7 @@ extern "C" int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, dou
 }
 
 extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* ok_h, int32_t* cnt_h, int32_t* n_undecided) {
-    if (!b || !b->tr_h) { viso_set_error("viso_batch_get_hypotheses: no run yet"); return VISO_ERR_ARG; }
+    if (dead(b) || !b->tr_h) { viso_set_error("viso_batch_get_hypotheses: no run yet"); return VISO_ERR_ARG; }
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
     if (tr_h) HIP_TRY(hipMemcpy(tr_h, b->tr_h, sizeof(double) * 6 * k, hipMemcpyDeviceToHost));
@@ -801,7 +818,7 @@ extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* o
 // Which images the pack kernel flagged in the last run (descriptor values that are not integers in
 // [-32768, 32767]): the problems reading them took the general (double) kernel, all others the u16 kernels.
 extern "C" int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags) {
-    if (!b || !flags) return VISO_ERR_ARG;
+    if (dead(b) || !flags) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     HIP_TRY(hipMemcpy(flags, b->bad_img, sizeof(int) * 2 * (size_t)b->nf, hipMemcpyDeviceToHost));
     return VISO_OK;
@@ -810,14 +827,14 @@ extern "C" int viso_batch_get_general_path_flags(viso_batch* b, int32_t* flags) 
 // How many queries of the last run the tile kernels handed to match_overflow_kernel (more than K in-radius
 // candidates, a candidate list that outgrew its LDS slot, an exact tie of the minimum): the data-dependent slow path.
 extern "C" int viso_batch_get_overflow_count(viso_batch* b, int32_t* n) {
-    if (!b || !n) return VISO_ERR_ARG;
+    if (dead(b) || !n) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     HIP_TRY(hipMemcpy(n, b->ovf_cnt, sizeof(int), hipMemcpyDeviceToHost));
     return VISO_OK;
 }
 
 extern "C" int viso_batch_get_counters(viso_batch* b, int64_t* scored, int64_t* m_out) {
-    if (!b) return VISO_ERR_ARG;
+    if (dead(b)) return VISO_ERR_ARG;
     { const int rs_ = batch_sync(b); if (rs_ < 0) return rs_; }
     const size_t k = 3 * (size_t)b->nf;
     if (scored) HIP_TRY(hipMemcpy(scored, b->scored, sizeof(int64_t) * k, hipMemcpyDeviceToHost));

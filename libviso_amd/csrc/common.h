@@ -122,6 +122,14 @@ struct viso_ctx {
     struct PlainCache* plain;    // the plain family's image cache (plain.hip), created on first use
 };
 
+// handle registry (ctx.hip): the live contexts, the live batches of each, tombstones of batches their context took along
+struct viso_batch;
+bool viso_ctx_live(const viso_ctx* c);
+bool viso_batch_live(const viso_batch* b);
+bool viso_batch_register(viso_ctx* c, viso_batch* b);   // false: the context is not live
+int viso_batch_unregister(viso_batch* b);               // 1 live (now the caller's to free), 0 tombstone (consumed), -1 unknown
+int viso_batch_free(viso_batch* b);                     // batch.hip: frees a batch that has left the registry
+
 struct PlainLock { PlainLock(); ~PlainLock(); };   // serialises the plain family on the default context
 // viso_plain_profile: phases of one plain-family call, bracketed by four events on the call's stream (ctx.hip).  Used
 // inside a PlainLock.  mark(1) = inputs enqueued, mark(2) = kernels enqueued, mark(3) = results on the host.
@@ -243,6 +251,9 @@ struct SolverItem {            // one ransac_minimize_reproj problem (one frame)
     int* ok;                   // 1
     int* n_inl;                // 1
     int* inl;                  // up to m
+    int* kept;                 // null, or 1 word: set to 1 when the stage leaves best_tr as the caller passed it -- no hypothesis found any
+                               //     support (best_tr is assigned only on improvement, src/viso.cpp:1564-1568) or m < 3 -- and `tr` is then
+                               //     NOT written; 0 otherwise.  Null (the batch family: sequence_odometry passes zeros, :1312): `tr` gets zeros.
 };
 
 struct JoinItem {

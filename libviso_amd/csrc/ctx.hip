@@ -2,6 +2,9 @@
 #include "common.h"
 
 #include <mutex>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +21,48 @@ void viso_set_error(const char* fmt, ...) {
 
 extern "C" const char* viso_last_error(void) { return g_err; }
 extern "C" const char* viso_version(void) { return "libviso_hip 0.1 (gfx950, HIP, wave64)"; }
+
+// ---- handle registry ---------------------------------------------------------------------------------------------
+// "We never abort across the ABI" has to hold for a caller that gets the teardown order wrong, too: a batch follows its
+// context pointer in every call, so a batch that outlives its context used to hand a dead stream to the HIP runtime
+// (std::bad_variant_access inside hipStreamSynchronize: an abort).  The library therefore knows its live handles: a context
+// keeps the list of the batches created on it; viso_ctx_destroy frees those that are still alive FIRST and leaves a
+// tombstone per batch, so that the caller's later viso_batch_destroy is a no-op (VISO_OK) and any other call on such a handle
+// -- or on a handle that never existed, or was destroyed twice -- returns VISO_ERR_ARG.  A tombstone goes away when the
+// caller destroys the handle or when the allocator hands the address out again.
+static std::mutex g_reg_mu;
+static std::unordered_map<const viso_ctx*, std::vector<viso_batch*>> g_ctx_batches;   // the live contexts and their live batches
+static std::unordered_map<const viso_batch*, viso_ctx*> g_batch_ctx;                  // the live batches
+static std::unordered_set<const viso_batch*> g_batch_tomb;                            // freed by their context, not yet by the caller
+
+bool viso_ctx_live(const viso_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return g_ctx_batches.count(c) != 0;
+}
+bool viso_batch_live(const viso_batch* b) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return g_batch_ctx.count(b) != 0;
+}
+bool viso_batch_register(viso_ctx* c, viso_batch* b) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_ctx_batches.find(c);
+    if (it == g_ctx_batches.end()) return false;
+    g_batch_tomb.erase(b);   // the address of a batch that died with its context, handed out again
+    it->second.push_back(b);
+    g_batch_ctx[b] = c;
+    return true;
+}
+// 1 = was live, now the caller's to free; 0 = its context freed it already (tombstone consumed); -1 = unknown handle
+int viso_batch_unregister(viso_batch* b) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_batch_ctx.find(b);
+    if (it == g_batch_ctx.end()) return g_batch_tomb.erase(b) ? 0 : -1;
+    auto& v = g_ctx_batches[it->second];
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == b) { v[i] = v.back(); v.pop_back(); break; }
+    g_batch_ctx.erase(it);
+    return 1;
+}
 
 extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
     int ndev = 0;
@@ -55,16 +100,30 @@ extern "C" viso_ctx* viso_ctx_create(int device, void* stream) {
         delete c;
         return nullptr;
     }
+    { std::lock_guard<std::mutex> lk(g_reg_mu); g_ctx_batches[c]; }
     return c;
 }
 
 // Frees everything it can and reports the FIRST HIP error it met (viso_last_error).  Must not be called once the
 // HIP runtime is being unloaded (static destructors / atexit handlers that run after it): destroy contexts before
 // the process starts exiting (the Python wrapper does so from an atexit hook of its own).
+// Batches of the context that are still alive are destroyed first (see the registry above); a handle that is not a live
+// context -- destroyed before, or never created -- is VISO_ERR_ARG.
 extern "C" int viso_ctx_destroy(viso_ctx* c) {
     if (!c) return VISO_OK;
+    std::vector<viso_batch*> orphans;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_ctx_batches.find(c);
+        if (it == g_ctx_batches.end()) { viso_set_error("viso_ctx_destroy: not a live context handle"); return VISO_ERR_ARG; }
+        orphans.swap(it->second);
+        g_ctx_batches.erase(it);
+        for (viso_batch* b : orphans) { g_batch_ctx.erase(b); g_batch_tomb.insert(b); }
+    }
     hipError_t first = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    bool batch_err = false;
+    for (viso_batch* b : orphans) if (viso_batch_free(b) < 0) batch_err = true;   // while the context's streams still exist
     note(hipSetDevice(c->device));
     note(hipStreamSynchronize(c->stream));
     if (c->solver_stream) { note(hipStreamSynchronize(c->solver_stream)); note(hipStreamDestroy(c->solver_stream)); }
@@ -74,10 +133,15 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
     if (c->own_stream) note(hipStreamDestroy(c->stream));
     delete c;
     if (first != hipSuccess) { viso_set_error("viso_ctx_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
+    if (batch_err) return VISO_ERR_HIP;   // viso_last_error() holds the batch's own message
     return VISO_OK;
 }
 
-static viso_ctx* ctx_or_default(viso_ctx* c) { return c ? c : viso_default_ctx(); }
+static viso_ctx* ctx_or_default(viso_ctx* c) {
+    if (!c) return viso_default_ctx();
+    if (!viso_ctx_live(c)) { viso_set_error("not a live context handle"); return nullptr; }
+    return c;
+}
 
 static bool matcher_known(int variant) {
 #ifdef VISO_DEBUG_VARIANTS
@@ -99,6 +163,7 @@ extern "C" int viso_matcher_default(void) {
 }
 
 extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
+    if (c && !viso_ctx_live(c)) { viso_set_error("not a live context handle"); return VISO_ERR_ARG; }
     c = ctx_or_default(c);
     if (!c) return VISO_ERR_HIP;
     if (!matcher_known(variant)) { viso_set_error("viso_ctx_set_matcher: unknown variant %d", variant); return VISO_ERR_ARG; }
@@ -107,6 +172,7 @@ extern "C" int viso_ctx_set_matcher(viso_ctx* c, int variant) {
 }
 
 extern "C" int viso_ctx_set_row8_shift(viso_ctx* c, int shift) {
+    if (c && !viso_ctx_live(c)) { viso_set_error("not a live context handle"); return VISO_ERR_ARG; }
     c = ctx_or_default(c);
     if (!c) return VISO_ERR_HIP;
     if (shift < -1 || shift > 3) { viso_set_error("viso_ctx_set_row8_shift: -1 (from the data) or 0..3"); return VISO_ERR_ARG; }
@@ -115,6 +181,7 @@ extern "C" int viso_ctx_set_row8_shift(viso_ctx* c, int shift) {
 }
 
 extern "C" int viso_ctx_set_gn_split(viso_ctx* c, int split) {
+    if (c && !viso_ctx_live(c)) { viso_set_error("not a live context handle"); return VISO_ERR_ARG; }
     c = ctx_or_default(c);
     if (!c) return VISO_ERR_HIP;
     if (split < 0 || split > 100) { viso_set_error("viso_ctx_set_gn_split: 0 (default) or 1..100"); return VISO_ERR_ARG; }
@@ -139,10 +206,10 @@ extern "C" const char* viso_ctx_matcher_kernel_name(viso_ctx* c) {
     return matcher_kernel_name(c ? c->matcher_variant : VISO_MATCHER_DEFAULT);
 }
 
-extern "C" void* viso_ctx_stream(viso_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" void* viso_ctx_stream(viso_ctx* c) { return c && viso_ctx_live(c) ? (void*)c->stream : nullptr; }
 
 extern "C" int viso_ctx_synchronize(viso_ctx* c) {
-    if (!c) return VISO_ERR_ARG;
+    if (!c || !viso_ctx_live(c)) { viso_set_error("viso_ctx_synchronize: not a live context handle"); return VISO_ERR_ARG; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->solver_stream) HIP_TRY(hipStreamSynchronize(c->solver_stream));   // RANSAC stages of its batches
     return VISO_OK;

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -35,8 +36,16 @@
 // next pass over the same array -- the loop's `d1.copyTo(d1_prev)`, src/viso.cpp:1213 -- goes from 30-40 to 65-130 us per
 // frame, because slices of it now sit in other cores' caches: 1290 against 1400 frames/s.  Kept for hosts whose arrays are
 // larger.  Used under the PlainLock only.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 struct PlainPool {
     std::vector<std::thread> th;
+    pid_t owner = getpid();           // threads do not survive fork(): a child must not wait for helpers it does not have
     std::mutex mu;
     std::condition_variable cv;
     std::atomic<unsigned long long> gen{0};
@@ -62,7 +71,7 @@ struct PlainPool {
         for (;;) {
             const auto t0 = std::chrono::steady_clock::now();
             while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
-                __builtin_ia32_pause();
+                cpu_relax();
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(60)) {
                     std::unique_lock<std::mutex> lk(mu);
                     sleepers.fetch_add(1);
@@ -92,15 +101,21 @@ struct PlainPool {
         { std::lock_guard<std::mutex> lk(mu); gen.fetch_add(1, std::memory_order_release); }
         if (sleepers.load() > 0) cv.notify_all();
         work(n);
-        while (done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        while (done.load(std::memory_order_acquire) < n) cpu_relax();
         return differ.load(std::memory_order_relaxed);
     }
 };
 static PlainPool* g_pool = nullptr;
 static bool g_pool_tried = false;
-static struct PlainPoolReaper { ~PlainPoolReaper() { delete g_pool; g_pool = nullptr; } } g_pool_reaper;
+// joins the helper threads at process exit (no HIP call in there); not in a forked child, which has none to join
+static struct PlainPoolReaper { ~PlainPoolReaper() { if (g_pool && g_pool->owner == getpid()) delete g_pool; g_pool = nullptr; } } g_pool_reaper;
 
 static PlainPool* plain_pool() {
+    // a process forked after the pool was made (the per-rank launchers fork BEFORE any HIP call, but a host may not) has the
+    // object and none of its threads: go() would spin forever.  The child works without helpers; the parent's object is
+    // leaked there on purpose (its destructor would join threads that do not exist).  $VISO_PLAIN_THREADS is not meant to be
+    // combined with forked ranks.
+    if (g_pool && g_pool->owner != getpid()) g_pool = nullptr;
     if (!g_pool_tried) {
         g_pool_tried = true;
         int n = 0;
@@ -128,6 +143,7 @@ static bool big_equal(const void* shadow, const void* user, size_t bytes) {
 }
 
 #define PLAIN_SLOTS 4
+#define PLAIN_DISTRUST_FRAMES 64
 #define PLAIN_HDR 256      // bytes of an image's header block {n, bad}
 
 struct PlainSlot {
@@ -196,6 +212,7 @@ struct PlainCache {
     hipStream_t side; hipEvent_t side_ev;  // a call's SECOND new image is brought in on a stream of its own, beside the first
     bool side_join;                        // ... and the context's stream has not been put behind side_ev yet
     int good_streak;                       // launches in a row whose images all fitted the u16 rows
+    int distrust;                          // > 0: a flagged image was seen within the last PLAIN_DISTRUST_FRAMES clean launches
     long long general_reruns;
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
@@ -252,11 +269,12 @@ static PlainCache* plain_cache(viso_ctx* c) {
 
 void plain_cache_free(viso_ctx* c) {
     if (!c->plain) return;
+    if (c->plain->side) (void)hipStreamSynchronize(c->plain->side);   // its pack kernels read the slots' pinned shadows
     for (int i = 0; i < PLAIN_SLOTS; ++i) {
         if (c->plain->slot[i].pin) (void)hipHostFree(c->plain->slot[i].pin);
         if (c->plain->slot[i].dev) (void)hipFree(c->plain->slot[i].dev);
     }
-    if (c->plain->side) { (void)hipStreamSynchronize(c->plain->side); (void)hipStreamDestroy(c->plain->side); }
+    if (c->plain->side) (void)hipStreamDestroy(c->plain->side);
     if (c->plain->side_ev) (void)hipEventDestroy(c->plain->side_ev);
     for (int i = 0; i < 3; ++i) {
         if (c->plain->frame[i].host) (void)hipHostFree(c->plain->frame[i].host);
@@ -567,6 +585,23 @@ static int plain_side_join(PlainCache* pc, hipStream_t s) {
     return VISO_OK;
 }
 
+// An error return must not leave work in flight: the kernels queued so far (copy, sort_kp, pack -- possibly on the side
+// stream) read the slots' pinned shadows and the context's pinned block, a slot may already be marked valid although its
+// pack kernel never ran to the end, and the next call would memcpy over a shadow a queued kernel is still pulling over
+// PCIe, or get a byte-comparison hit on half-packed rows.  So: wait for both streams, forget every image and every frame.
+// (Errors here are HIP failures; nothing is optimised for them.)
+static void plain_quiesce(viso_ctx* c, PlainCache* pc) {
+    (void)hipStreamSynchronize(c->stream);
+    if (pc->side) (void)hipStreamSynchronize(pc->side);
+    pc->side_join = false;
+    for (int i = 0; i < PLAIN_SLOTS; ++i) pc->slot[i].valid = false;
+    for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; pc->frame[i].pending_J = false; }
+    pc->good_streak = 0;
+}
+
+static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int n1, const float* kp2, int n2, const float* d1, const float* d2,
+                             int dlen, const viso_match_params* mp, int32_t* out_match, int* out_n);
+
 // match_desc, reference src/viso.cpp:669-726.
 extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n2,
                                const float* d1, const float* d2, int dlen,
@@ -588,6 +623,13 @@ extern "C" int viso_match_desc(const float* kp1, int n1, const float* kp2, int n
     HIP_TRY(hipSetDevice(c->device));
     PlainCache* pc = plain_cache(c);
     if (!pc) { viso_set_error("viso_match_desc: out of memory"); return VISO_ERR_NOMEM; }
+    const int r = match_desc_locked(c, pc, kp1, n1, kp2, n2, d1, d2, dlen, mp, out_match, out_n);
+    if (r < 0) plain_quiesce(c, pc);
+    return r;
+}
+
+static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int n1, const float* kp2, int n2, const float* d1, const float* d2,
+                             int dlen, const viso_match_params* mp, int32_t* out_match, int* out_n) {
     hipStream_t s = c->stream;
     PlainProf pp(VISO_PLAIN_MATCH_DESC, s);
     int r;
@@ -668,7 +710,10 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
     bool spec_x = false, spec_B = false;
     if (stereo_call && pc->speculate) {
         if (pc->frame[pc->cur ^ 1].pending_B && (r = frame_wait_B(c, pc->frame[pc->cur ^ 1])) < 0) return r;
-        frame_retire(pc, pc->frame[pc->cur ^ 1]);   // the frame that leaves
+        // The frame that leaves is the one before the last stereo call's: every call that could have used its results is over,
+        // so what it computed ahead and nobody asked for is known now, whatever becomes of THIS launch (a repeated launch finds
+        // the object reset -- not valid -- and counts nothing twice)
+        frame_retire(pc, pc->frame[pc->cur ^ 1]);
         pc->frame_no += 1;
         pc->cur ^= 1;
         f = &pc->frame[pc->cur];
@@ -719,7 +764,9 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         if (a.bad_host == 1 || b.bad_host == 1) any_bad = true;
         if (a.bad_host < 0 || b.bad_host < 0) any_unknown = true;
     }
-    const bool trust = pc->good_streak >= 2 && !force_general;
+    // A source that has produced a flagged image lately keeps the general kernels in the launch: a stream with sporadic
+    // fractional images would otherwise pay a dropped launch + a full synchronize + a second launch on every such frame
+    const bool trust = pc->good_streak >= 2 && !force_general && pc->distrust == 0;
     const bool need_general = any_bad || (any_unknown && !trust) || dlen > VISO_ROW;
     for (int p = 0; p < np; ++p) {
         PlainSlot &a = pc->slot[f->tq[p]], &b = pc->slot[f->tt[p]];
@@ -760,7 +807,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         it.m_ptr = dmisc + 32; it.ld = (int)C; it.samples = nullptr; it.samp_h = rs_queue + 2 + iters; it.frame = f->rs_frame;
         it.tr_h = dtrh; it.ok_h = dhyp; it.cnt_h = dhyp + iters; it.rot = drot;
         int* rso = reinterpret_cast<int*>(f->dev + f->o_rs);
-        it.ok = rso + 1; it.n_inl = rso + 2; it.tr = reinterpret_cast<double*>(f->dev + f->o_rs + 64); it.inl = reinterpret_cast<int*>(f->dev + f->o_rs + 128);
+        it.kept = rso; it.ok = rso + 1; it.n_inl = rso + 2; it.tr = reinterpret_cast<double*>(f->dev + f->o_rs + 64); it.inl = reinterpret_cast<int*>(f->dev + f->o_rs + 128);
         H->rs = it;
         (void)prv;
     }
@@ -868,6 +915,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
     sq.bad_host = omisc[40] != 0; st.bad_host = omisc[41] != 0;   // the images' own flags, as their pack kernels left them
     if (sq.bad_host || st.bad_host) {
         pc->good_streak = 0;
+        pc->distrust = PLAIN_DISTRUST_FRAMES;
         if (!need_general) {   // unexpected: the launch had no kernel for them.  Everything it produced is dropped, the call repeated
             HIP_TRY(hipStreamSynchronize(s));
             f->pending_B = false; f->pending_J = false;
@@ -878,6 +926,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         }
     } else {
         pc->good_streak += 1;
+        if (pc->distrust > 0) pc->distrust -= 1;
     }
     const int m = f->m[0];
     if (m > 0) memcpy(out_match, frame_rows(*f, 0), sizeof(int) * 3 * (size_t)m);
@@ -990,7 +1039,9 @@ int plain_try_ransac(viso_ctx* c, const double* X, const double* obs, int m, dou
         for (int k = 0; k < 4 && same; ++k) same = memcmp(hxc + C * k, obs + (size_t)k * m, sizeof(double) * (size_t)m) == 0;
         const int* rso = reinterpret_cast<const int*>(f.host + (f.o_rs - f.o_misc));
         if (same && rso[2] >= 0 && rso[2] <= m) {
-            memcpy(best_tr, f.host + (f.o_rs - f.o_misc) + 64, sizeof(double) * 6);
+            // computed ahead without knowing the caller's best_tr: where the reference would leave it alone (no hypothesis with
+            // support, src/viso.cpp:1564-1568) the stage wrote none and says so in rso[0]
+            if (!rso[0]) memcpy(best_tr, f.host + (f.o_rs - f.o_misc) + 64, sizeof(double) * 6);
             *n_inl = rso[2];
             if (rso[2] > 0) memcpy(best_inl, f.host + (f.o_rs - f.o_misc) + 128, sizeof(int) * (size_t)rso[2]);
             *ret = rso[1] ? 1 : 0;

@@ -692,8 +692,8 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
-        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
-        if (threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // vector<double> tr(6,0), :1312 (no memset in front of the stage)
+        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; if (S.kept) *S.kept = 1; }
+        if (!S.kept && threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // vector<double> tr(6,0), :1312 (no memset in front of the stage)
         return;
     }
     // The hypothesis with the largest support, the FIRST of them among equals (strict >, :1564), none without support:
@@ -725,8 +725,8 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
     const int best = scratch[REFIT_WAVES];
     __syncthreads();
     if (best < 0) {   // no hypothesis found any support: best_inliers stays empty, :1571
-        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; }
-        if (threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;   // best_tr keeps the caller's zeros, :1312
+        if (threadIdx.x == 0) { *S.ok = 0; *S.n_inl = 0; if (S.kept) *S.kept = 1; }   // best_tr is assigned on improvement only (:1564-1568):
+        if (!S.kept && threadIdx.x < 6) S.tr[threadIdx.x] = 0.0;                       // the caller's value stays -- zeros in sequence_odometry, :1312
         return;
     }
     double tr[6];
@@ -749,6 +749,7 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
         for (int j = 0; j < 6; ++j) S.tr[j] = tr_s[j];
         *S.ok = ok;
         *S.n_inl = n;
+        if (S.kept) *S.kept = 0;
     }
 }
 
@@ -987,7 +988,7 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
         if (plain_try_ransac(c, X, obs, m, best_tr, best_inl, n_inl, p, samples, seed, frame, &ret)) return ret;
     }
     int r;
-    // ONE upload: X | obs | samples | {m} | the item; ONE read-back: {-, ok, n_inl} | tr[6] | inliers[m]
+    // ONE upload: X | obs | samples | {m} | the item; ONE read-back: {kept, ok, n_inl} | tr[6] | inliers[m]
     PlainStage in;
     if ((r = in.begin(c, PlainStage::need(sizeof(double) * 3 * (size_t)m) + PlainStage::need(sizeof(double) * 4 * (size_t)m) +
                          PlainStage::need(sizeof(int) * 3 * (size_t)(iters + 1)) + PlainStage::need(16) + PlainStage::need(sizeof(SolverItem)))) < 0) return r;
@@ -1008,9 +1009,10 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     it.samp_h = dqueue + 2 + iters;
     it.tr_h = dtrh; it.ok_h = dhyp; it.cnt_h = dhyp + iters;
     if ((r = ctx_scratch(c, 9, viso_rot_bytes(iters), (void**)&it.rot)) < 0) return r;
-    // the refit writes tr, ok and n_inl whatever happens (refit_item): nothing of the result block needs a value in advance.
-    // (best_tr is an input of the reference's function only as the value that stays when no hypothesis finds support,
-    // and sequence_odometry passes zeros, src/viso.cpp:1312: the stage leaves zeros in that case.)
+    // the refit writes kept, ok and n_inl whatever happens (refit_item): nothing of the result block needs a value in advance.
+    // best_tr is an input of the reference's function only as the value that STAYS when no hypothesis finds support
+    // (src/viso.cpp:1564-1568): the stage says so in `kept` and the caller's array is then left alone, below.
+    it.kept = reinterpret_cast<int*>(dout);
     it.ok = reinterpret_cast<int*>(dout) + 1; it.n_inl = reinterpret_cast<int*>(dout) + 2;
     it.tr = reinterpret_cast<double*>(dout + 64); it.inl = reinterpret_cast<int*>(dout + 128);
     const SolverItem* ditem = in.put(&it, 1);
@@ -1029,7 +1031,7 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     pp.wait_end();
     const int* res = reinterpret_cast<const int*>(hout);
     if (res[2] < 0 || res[2] > m) { viso_set_error("viso_ransac_minimize_reproj: device returned %d inliers of %d points", res[2], m); return VISO_ERR_HIP; }
-    memcpy(best_tr, hout + 64, sizeof(double) * 6);
+    if (!res[0]) memcpy(best_tr, hout + 64, sizeof(double) * 6);   // kept: in/out like the reference's (:1564-1568)
     *n_inl = res[2];
     if (res[2] > 0) memcpy(best_inl, hout + 128, sizeof(int) * (size_t)res[2]);
     pp.mark(3);

@@ -118,6 +118,38 @@ static void drop_in_leg() {
                                       st.us[fn] / st.calls[fn], st.us[fn] / (st.frames - 1));
 }
 
+// ---- teardown in the wrong order, on raw handles ------------------------------------------------------------------------
+// include/viso_hip.h: "we never abort across the ABI".  A batch follows its context in every call, so a caller that
+// destroys the context first used to send a dead stream into the HIP runtime (an abort inside hipStreamSynchronize).
+// The library knows its live handles now: viso_ctx_destroy takes the context's live batches along, the late
+// viso_batch_destroy is a no-op, everything else on a dead handle is VISO_ERR_ARG -- return codes, once each.
+static void destroy_order_leg() {
+    viso_ctx* c = viso_ctx_create(0, nullptr);
+    CHECK(c != nullptr);
+    viso_batch* b1 = viso_batch_create(c, 3, 64, VISO_DESC_LEN);
+    viso_batch* b2 = viso_batch_create(c, 2, 32, VISO_DESC_LEN);
+    CHECK(b1 && b2);
+    CHECK(viso_batch_destroy(b2) == VISO_OK);            // the right order for one of them
+    CHECK(viso_batch_destroy(b2) == VISO_ERR_ARG);       // twice: an argument error, not a double free
+    CHECK(viso_ctx_destroy(c) == VISO_OK);               // b1 is still alive: the context frees it first
+    double tr[18]; int ok[3], n_inl[3];
+    CHECK(viso_batch_get_poses(b1, tr, ok, n_inl) == VISO_ERR_ARG);   // a getter on the dead handle
+    CHECK(viso_batch_run(b1) == VISO_ERR_ARG);
+    CHECK(viso_batch_destroy(b1) == VISO_OK);            // the caller's late destroy: a no-op
+    CHECK(viso_batch_destroy(b1) == VISO_ERR_ARG);       // ... once
+    CHECK(viso_ctx_destroy(c) == VISO_ERR_ARG);          // the context twice
+    CHECK(viso_ctx_synchronize(c) == VISO_ERR_ARG);
+    CHECK(viso_batch_create(c, 2, 32, VISO_DESC_LEN) == nullptr);
+    int bogus = 0;
+    CHECK(viso_batch_destroy(reinterpret_cast<viso_batch*>(&bogus)) == VISO_ERR_ARG);   // never was a handle
+    // and the library is still usable
+    viso_ctx* c2 = viso_ctx_create(0, nullptr);
+    viso_batch* b3 = c2 ? viso_batch_create(c2, 2, 32, VISO_DESC_LEN) : nullptr;
+    CHECK(c2 && b3);
+    CHECK(viso_batch_destroy(b3) == VISO_OK);
+    CHECK(viso_ctx_destroy(c2) == VISO_OK);
+}
+
 int main() {
     using namespace viso;
     // The loop frees and allocates ~1 MB descriptor matrices every frame (as cv::Mat does in the reference).  glibc serves
@@ -170,6 +202,7 @@ int main() {
         for (int j = 3; j < 6; ++j) CHECK(std::fabs(b[j] - tr_gt[j]) < 5e-2);
     }
     CHECK(procrustes_tr(Matd(3, 2), Matd(4, 2), p, {0, 1}) == std::vector<double>(6, 0.0));   // fewer than 3 usable points
+    destroy_order_leg();
     drop_in_leg();
     std::printf(fails ? "gputest: %d failure(s)\n" : "gputest ok\n", fails);
     return fails ? 1 : 0;

@@ -200,7 +200,7 @@ def main(argv=None):
     ap.add_argument("--same-device", action="store_true", help="every rank on device 0 (rehearsal on a one-GPU box; use --backend gloo)")
     ap.add_argument("--force-collective", action="store_true",
                     help="build the process group and run the all-gather even with one rank (RCCL on a one-GPU box)")
-    ap.add_argument("--decode-threads", type=int, default=0, help="PNG decoding threads per rank (0: min(16, cpus / ranks))")
+    ap.add_argument("--decode-threads", type=int, default=0, help="PNG decoding threads per rank (0: min(64, cpus / ranks))")
     ap.add_argument("--reference-pose-list", action="store_true",
                     help="write the list the reference's code actually produces, [P1..Pn, Pn] (src/viso.cpp:1317-1321)")
     args = ap.parse_args(argv)
@@ -243,7 +243,7 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
     L = load_host()
-    threads = args.decode_threads or int(os.environ.get("VISO_DECODE_THREADS", "0")) or max(1, min(16, (os.cpu_count() or 1) // world))
+    threads = args.decode_threads or int(os.environ.get("VISO_DECODE_THREADS", "0")) or max(1, min(64, (os.cpu_count() or 1) // world))
     L.viso_kitti_set_decode_threads(threads)
 
     def die(code, what):

@@ -88,7 +88,7 @@ def test_per_call_loop_equals_oracle(viso, oracle, seq):
         assert np.array_equal(o["matches"][1][t], m_cpu)
 
 
-def _loop_frame(seq, t, st, tm, state, seed=5):
+def _loop_frame(seq, t, st, tm, state, seed=5, rs_param=None, tr0=None):
     """One iteration of the reference's loop body through the Python wrappers of the plain family; returns its products."""
     nL, nR = seq["n"][t]
     kp1, kp2 = seq["kp"][t, 0, :nL].copy(), seq["kp"][t, 1, :nR].copy()
@@ -104,7 +104,7 @@ def _loop_frame(seq, t, st, tm, state, seed=5):
         out.update(m11=m11, m22=m22, circ=circ, pcl=pcl)
         if n >= 3:
             x_c, Xp_c = np.ascontiguousarray(x[:, pcl[:, 0]]), np.ascontiguousarray(state["X"][:, pcl[:, 1]])
-            out["rs"] = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=seed, frame=t)
+            out["rs"] = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, rs_param if rs_param is not None else seq["param"], seed=seed, frame=t, tr0=tr0)
             out.update(x_c=x_c, Xp_c=Xp_c)
     return out
 
@@ -174,6 +174,32 @@ def test_calls_that_are_not_the_loops_take_the_direct_path(viso, oracle, seq):
     r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=5, frame=t)
     r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xp_c, x_c, seq["param"], seed=5, frame=t)
     assert r_a == r_o and np.array_equal(inl_a, inl_o)
+
+
+@pytest.mark.parametrize("speculate", [True, False])
+def test_best_tr_survives_a_frame_without_support_in_both_modes(viso, oracle, seq, speculate):
+    """ransac_minimize_reproj leaves the caller's best_tr alone when no hypothesis finds support (src/viso.cpp:1564-1568).  The
+    stage that was computed ahead inside the stereo call cannot know the caller's array: it must say "nothing assigned"
+    and the call must then leave the array as it came -- same as the direct path, same as the oracle.  A threshold of 0
+    (err2 < 0 never holds) makes every frame of the loop such a frame."""
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(speculate)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    p0 = type(seq["param"]).from_buffer_copy(seq["param"]); p0.inlier_threshold = 0.0
+    tr0 = np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    before = drop_in.plain_stats()
+    state, seen = None, 0
+    for t in range(12):
+        state = _loop_frame(seq, t, st, tm, state, rs_param=p0, tr0=tr0)
+        if "rs" in state:
+            r_a, tr_a, inl_a = state["rs"]
+            r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(state["Xp_c"], state["x_c"], p0, seed=5, frame=t, tr0=tr0)
+            assert (r_a, len(inl_a)) == (r_o, len(inl_o)) == (0, 0), t
+            assert np.array_equal(tr_o, tr0) and np.array_equal(tr_a.view(np.int64), tr0.view(np.int64)), (t, tr_a)
+            seen += 1
+    assert seen >= 10
+    served = [a - b for a, b in zip(drop_in.plain_stats()["served"], before["served"])]
+    assert (served[3] >= 4) if speculate else (served[3] == 0), served   # the answered-ahead path WAS the one under test
 
 
 def test_an_image_that_does_not_fit_the_u16_rows_where_none_was_expected(viso, oracle, seq):

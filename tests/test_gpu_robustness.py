@@ -206,6 +206,44 @@ def test_a_context_closed_first_takes_its_batches_along(viso):
     del b1, b2, ctx
 
 
+def test_raw_handles_destroyed_in_the_wrong_order_get_return_codes(viso, oracle):
+    """The C-ABI itself (no Context / Batch wrapper): a batch that outlives its context.  include/viso_hip.h promises return
+    codes, never an abort: viso_ctx_destroy takes the context's live batches along, the caller's late viso_batch_destroy is
+    a no-op, every other call on a dead handle is VISO_ERR_ARG (-1).  Run once, in this process."""
+    import ctypes as C
+    L = viso
+    seq = synth.make_sequence(2, 3, n_kp=200, width=400, height=200)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    c = L.viso_ctx_create(0, None)
+    assert c
+    b1, b2 = L.viso_batch_create(c, 3, 200, 121), L.viso_batch_create(c, 2, 32, 121)
+    assert b1 and b2
+    from libviso_amd.abi import ptr
+    kp, desc, n = (np.ascontiguousarray(seq[k]) for k in ("kp", "desc", "n"))
+    assert L.viso_batch_upload(b1, 0, 3, ptr(kp, C.c_float), ptr(desc, C.c_float), ptr(n, C.c_int32)) == 1
+    assert L.viso_batch_set_params(b1, C.byref(st), C.byref(tm), C.byref(seq["param"]), 1, 0) == 1
+    assert L.viso_batch_run(b1) == 1                       # work in flight when the context goes
+    assert L.viso_batch_destroy(b2) == 1
+    assert L.viso_batch_destroy(b2) == -1                  # twice
+    assert L.viso_ctx_destroy(c) == 1                      # b1 still alive: freed with its context
+    tr, ok, ni = np.zeros((3, 6)), np.zeros(3, np.int32), np.zeros(3, np.int32)
+    assert L.viso_batch_get_poses(b1, ptr(tr, C.c_double), ptr(ok, C.c_int32), ptr(ni, C.c_int32)) == -1
+    assert L.viso_batch_run(b1) == -1
+    assert L.viso_batch_destroy(b1) == 1                   # the late destroy: a no-op ...
+    assert L.viso_batch_destroy(b1) == -1                  # ... once
+    assert L.viso_ctx_destroy(c) == -1
+    assert L.viso_ctx_synchronize(c) == -1
+    assert not L.viso_batch_create(c, 2, 32, 121)
+    # the library is still usable, and still right
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 3, 200)
+    b.upload(seq["kp"], seq["desc"], seq["n"]); b.set_params(st, tm, seq["param"], seed=1); b.run()
+    want = oracle.sequence(seq["kp"], seq["desc"], seq["n"], st, tm, seq["param"], seed=1)
+    _, ok2, n2 = b.poses()
+    assert np.array_equal(ok2, want["ok"]) and np.array_equal(n2, want["n_inl"])
+    b.close(); ctx.close()
+
+
 def test_hypotheses_getter_with_a_wider_capacity(viso):
     """viso_batch_get_hypotheses2 with arrays of [n_frames][capacity > ransac_iter]: every frame's row at the caller's stride
     (the first version forwarded to the tight getter and put frame 1's row where frame 0's padding belonged)."""

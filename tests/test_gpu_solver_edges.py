@@ -279,3 +279,37 @@ def test_create_set_params_destroy_does_not_leak(viso):
     free1 = torch.cuda.mem_get_info(0)[0]
     ctx.close()
     assert free0 - free1 < (1 << 20), f"{(free0 - free1) / 2**20:.1f} MiB lost over 40 create/destroy cycles"
+
+
+def test_best_tr_is_in_out_like_the_references(viso, oracle):
+    """ransac_minimize_reproj assigns best_tr only when a hypothesis IMPROVES the support (src/viso.cpp:1564-1568): a caller's
+    value survives when no hypothesis finds any support (and the function returns false with no inliers, :1571), and for
+    fewer than three points.  With 3-5 points a hypothesis does find support (< 6: false) and best_tr is that hypothesis'."""
+    tr0 = np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    X, obs, _, param = synth.make_solver_case(9, m=300, outlier_frac=0.3)
+    # (a) no support at all: every observation far from anything a rigid motion of X can project to
+    far = np.full_like(obs, 1.0e6) + np.arange(obs.size, dtype=np.float64).reshape(obs.shape) % 7.0
+    for kw in ({"seed": 3, "frame": 12}, {"samples": oracle.ransac_samples(3, 12, param.ransac_iter, X.shape[1])}):
+        r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(X, far, param, tr0=tr0, **kw)
+        r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(X, far, param, tr0=tr0, **kw)
+        assert r_o == 0 and len(inl_o) == 0 and np.array_equal(_bits(tr_o), _bits(tr0))   # what the reference does
+        assert r_a == 0 and len(inl_a) == 0
+        assert np.array_equal(_bits(tr_a), _bits(tr0)), "the caller's best_tr must survive when no hypothesis finds support"
+    # the same with a threshold nothing can meet (err2 < 0)
+    p0 = type(param).from_buffer_copy(param); p0.inlier_threshold = 0.0
+    r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(X, obs, p0, seed=3, frame=12, tr0=tr0)
+    r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(X, obs, p0, seed=3, frame=12, tr0=tr0)
+    assert (r_a, len(inl_a)) == (r_o, len(inl_o)) == (0, 0) and np.array_equal(_bits(tr_a), _bits(tr_o)) and np.array_equal(_bits(tr_a), _bits(tr0))
+    # (b) fewer than three points: nothing is touched
+    for m in (0, 1, 2):
+        r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(X[:, :m], obs[:, :m], param, seed=3, frame=12, tr0=tr0)
+        r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(X[:, :m], obs[:, :m], param, seed=3, frame=12, tr0=tr0)
+        assert (r_a, len(inl_a)) == (r_o, len(inl_o)) == (0, 0) and np.array_equal(_bits(tr_a), _bits(tr_o)) and np.array_equal(_bits(tr_a), _bits(tr0))
+    # (c) 3-5 clean points: support of 3..5 < 6 -> false, best_tr = the best hypothesis' motion, its inliers reported
+    Xc, obsc, _, pc = synth.make_solver_case(10, m=40, outlier_frac=0.0, noise=0.0)
+    for m in (3, 4, 5):
+        r_a, tr_a, inl_a = libviso_amd.ransac_minimize_reproj(Xc[:, :m], obsc[:, :m], pc, seed=8, frame=m, tr0=tr0)
+        r_o, tr_o, inl_o = oracle.ransac_minimize_reproj(Xc[:, :m], obsc[:, :m], pc, seed=8, frame=m, tr0=tr0)
+        assert r_o == 0 and 0 < len(inl_o) < 6
+        assert r_a == r_o and np.array_equal(inl_a, inl_o)
+        assert not np.array_equal(tr_o, tr0) and np.allclose(tr_a, tr_o, rtol=0, atol=1e-9)

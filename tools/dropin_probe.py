@@ -1,5 +1,5 @@
-import sys, time, json, numpy as np
-sys.path.insert(0, '/root/repo')
+import os, sys, time, json, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # the tree this file lives in, not a fixed path
 import libviso_amd
 from libviso_amd import synth, drop_in
 from libviso_amd.abi import MatchParams
@@ -14,6 +14,7 @@ o = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=1
 import ctypes
 try: libviso_amd.load().viso_plain_trace_dump()
 except Exception as e: print(e)
+print("libraries loaded:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "libviso_" in l}))   # an A/B that swaps .so files shows WHICH one it timed
 print("frames", o["frames"], "loop_s", o["loop_s"], "fps", (o["frames"]-1)/o["loop_s"], "carry_s", o["carry_s"])
 for k,(c,us) in o["calls"].items(): print(f"  {k:28s} calls {c:5d}  {us/c:9.1f} us/call  {us/(o['frames']-1):9.1f} us/frame")
 st=(ctypes.c_int64*8)(); libviso_amd.load().viso_plain_speculate_stats(st); print("speculation served (temporal, collect, tri/circle, ransac):", list(st)[:4], "wasted:", list(st)[4:])
