@@ -36,7 +36,7 @@ struct viso_batch {
     JoinItem* join; SolverItem* sitems;
     int *circ, *pcl, *mc;
     double* tr_h; int *ok_h, *cnt_h, *hq; char* rot;   // hq: list of undecided hypotheses (launch_ransac)
-    int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_sample_kernel)
+    int* samp_h;                            // [nf][iters][3] sample triples of the run (ransac_hyp_kernel)
     // the *_async uploads stage the caller's (pageable, possibly temporary) n array through a small pinned ring:
     // slot k is reusable once the copy that read it has passed (n_pin_ev[k])
     int* n_pin; hipEvent_t n_pin_ev[VISO_NPIN_SLOTS]; bool n_pin_used[VISO_NPIN_SLOTS]; int n_pin_next;
@@ -472,12 +472,13 @@ extern "C" int viso_batch_set_params(viso_batch* b, const viso_match_params* ste
         const size_t k = (size_t)b->nf * (size_t)(b->iters > 0 ? b->iters : 1);
         int r;
         if ((r = dalloc(&b->tr_h, k * 6)) < 0 || (r = dalloc(&b->ok_h, k)) < 0 || (r = dalloc(&b->cnt_h, k)) < 0 ||
-            (r = dalloc(&b->hq, k + 1)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0 ||
+            (r = dalloc(&b->hq, k + 2)) < 0 || (r = dalloc(&b->samp_h, k * 3)) < 0 ||
             (r = dalloc(&b->rot, (size_t)b->nf * viso_rot_bytes(b->iters))) < 0) return r;
         // frame 0 has no solve: its rows are never written, and viso_batch_get_hypotheses hands them out with the rest
         HIP_TRY(hipMemset(b->tr_h, 0, sizeof(double) * 6 * k));
         HIP_TRY(hipMemset(b->ok_h, 0, sizeof(int) * k));
         HIP_TRY(hipMemset(b->cnt_h, 0, sizeof(int) * k));
+        HIP_TRY(hipMemset(b->hq, 0, sizeof(int) * 2));   // the list of undecided hypotheses starts empty; every chain leaves it empty
     }
     int r = build_solver_items(b);
     if (r < 0) return r;
@@ -800,7 +801,7 @@ extern "C" int viso_batch_get_hypotheses2(viso_batch* b, int iters_capacity, dou
                                   hipMemcpyDeviceToHost));
     if (cnt_h) HIP_TRY(hipMemcpy2D(cnt_h, sizeof(int) * (size_t)iters_capacity, b->cnt_h, sizeof(int) * (size_t)iters, sizeof(int) * (size_t)iters, nf,
                                    hipMemcpyDeviceToHost));
-    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq + 1, sizeof(int), hipMemcpyDeviceToHost));   // [1]: the last chain's count (solver.hip)
     return VISO_OK;
 }
 
@@ -811,7 +812,7 @@ extern "C" int viso_batch_get_hypotheses(viso_batch* b, double* tr_h, int32_t* o
     if (tr_h) HIP_TRY(hipMemcpy(tr_h, b->tr_h, sizeof(double) * 6 * k, hipMemcpyDeviceToHost));
     if (ok_h) HIP_TRY(hipMemcpy(ok_h, b->ok_h, sizeof(int) * k, hipMemcpyDeviceToHost));
     if (cnt_h) HIP_TRY(hipMemcpy(cnt_h, b->cnt_h, sizeof(int) * k, hipMemcpyDeviceToHost));
-    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_undecided) HIP_TRY(hipMemcpy(n_undecided, b->hq + 1, sizeof(int), hipMemcpyDeviceToHost));   // [1]: the last chain's count (solver.hip)
     return VISO_OK;
 }
 

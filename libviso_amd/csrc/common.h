@@ -141,7 +141,7 @@ struct PlainProf {
     void wait_end();
     int fn; hipStream_t s; bool on; int marks; double t0, tw, wait;
 };
-int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out);
+int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out, bool zero_new = false);   // zero_new: a block that is (re)allocated starts zeroed
 int ctx_pinned(viso_ctx* c, int which, size_t bytes, char** out);
 void plain_cache_free(viso_ctx* c);   // plain.hip; from viso_ctx_destroy
 // plain.hip: a call of the reference's loop that the frame's stereo call has already answered (1 = served, 0 = go to the device)
@@ -241,7 +241,7 @@ struct SolverItem {            // one ransac_minimize_reproj problem (one frame)
     int ld;
     int _pad;
     const int* samples;        // iters x 3, or NULL -> splitmix64 stream
-    int* samp_h;               // iters x 3   the triples in use (ransac_sample_kernel: drawn, or copied from `samples`)
+    int* samp_h;               // iters x 3   the triples in use (ransac_hyp_kernel: drawn, or copied from `samples`)
     unsigned long long frame;  // stream key
     double* tr_h;              // iters x 6   hypothesis transforms
     int* ok_h;                 // iters
@@ -274,7 +274,8 @@ struct TriItem {
     double* x; double* X; int ld;         // 4 x ld, 3 x ld (X may be NULL)
 };
 
-// queue: device scratch of 1 + n_items * iters ints (list of the hypotheses stage 1 leaves undecided)
+// queue: device scratch of 2 + n_items * iters ints (list of the hypotheses stage 1 leaves undecided); queue[0] must be ZERO
+// when the chain starts: zero it at allocation -- every chain leaves it zero behind its reader (ransac_rot_kernel)
 // split: iterations the lane-per-hypothesis kernel runs before it hands undecided hypotheses to the wave-per-hypothesis
 // kernel (viso_ctx::gn_split; 100 = the lane kernel does everything)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,

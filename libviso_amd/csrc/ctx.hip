@@ -215,7 +215,7 @@ extern "C" int viso_ctx_synchronize(viso_ctx* c) {
     return VISO_OK;
 }
 
-int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out) {
+int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out, bool zero_new) {
     if (bytes < 256) bytes = 256;
     HIP_TRY(hipSetDevice(c->device));
     if (c->scratch_bytes[slot] < bytes) {
@@ -226,6 +226,7 @@ int ctx_scratch(viso_ctx* c, int slot, size_t bytes, void** out) {
         size_t want = bytes + bytes / 2;
         HIP_TRY(hipMalloc(&c->scratch[slot], want));
         c->scratch_bytes[slot] = want;
+        if (zero_new) HIP_TRY(hipMemsetAsync(c->scratch[slot], 0, want, c->stream));
     }
     *out = c->scratch[slot];
     return VISO_OK;

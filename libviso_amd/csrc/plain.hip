@@ -799,7 +799,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         if ((r = ctx_scratch(c, 16, sizeof(int) * 3 * (size_t)(rs_tabn + 1), (void**)&rs_tab)) < 0) return r;
         if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dhyp)) < 0) return r;
         if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)(iters + 1), (void**)&dtrh)) < 0) return r;
-        if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&rs_queue)) < 0) return r;
+        if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&rs_queue, true)) < 0) return r;
         if ((r = ctx_scratch(c, 9, viso_rot_bytes(iters), (void**)&drot)) < 0) return r;
         f->rs_p = pc->rs_p; f->rs_seed = pc->rs_seed; f->rs_frame = pc->rs_last_frame + pc->rs_delta;
         SolverItem it{};

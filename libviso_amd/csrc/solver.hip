@@ -1,8 +1,8 @@
 // solver.hip — RANSAC + Gauss-Newton stereo reprojection pose solver kernels
 // (reference src/viso.cpp:1543-1580 ransac_minimize_reproj, :1583-1623
-// minimize_reproj, :1509-1537 get_inliers).  Latency-bound fp64 work: the sample
-// triples of all hypotheses are drawn by one wave each, all hypotheses of all
-// frames then run concurrently (one lane per 3-point hypothesis; the few that
+// minimize_reproj, :1509-1537 get_inliers).  Latency-bound fp64 work: all hypotheses of all
+// frames run concurrently (one lane per 3-point hypothesis, which draws its own
+// sample triple in O(1) first; the few that
 // need more than VISO_GN_SPLIT iterations continue one wave each), support sets
 // are counted per frame x 10 hypotheses, and the all-inlier refit builds
 // J^T J / J^T r per iteration as a workgroup reduction with the 6x6 LU solve on
@@ -20,56 +20,18 @@ struct SolverArgs {
     unsigned long long seed;
     SolverParamsDev sp;
     int split;    // iterations done by ransac_hyp_kernel (VISO_GN_SPLIT)
-    int* queue;   // [0] = number of undecided hypotheses, [1..] = item * iters + h of each (any order)
+    int* queue;   // [0] = number of undecided hypotheses, ZERO when the chain starts (zeroed at allocation, and again by
+                  //       ransac_rot_kernel -- the kernel behind the list's only reader -- after saving it to [1]);
+                  // [1] = the last chain's count (diagnostics); [2..] = item * iters + h of each undecided hypothesis (any order)
 };
 
-// ---- stage 0: the sample triples ------------------------------------------------------------------------------
-// randomsample (src/viso.cpp:88-107) is selection sampling: one uniform draw per candidate index t, index t is
-// taken when (N - t) * u_t < 3 - m.  The draws come from a splitmix64 stream keyed on (seed, frame, hypothesis)
-// (viso_sample3); splitmix64 is counter based — draw t is a function of s0 + (t + 1) * gamma — so a wave tests 64
-// consecutive t at once and walks its hits in order: the same triples as the serial loop (which costs ~50 k
-// instructions per hypothesis: three quarters of what ransac_hyp_kernel used to execute), in ~600.
-__global__ __launch_bounds__(256) void ransac_sample_kernel(SolverArgs a) {
-    const int lane = threadIdx.x & 63;
-    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gid == 0 && lane == 0) a.queue[0] = 0;   // the list of undecided hypotheses (ransac_hyp_kernel appends) starts empty
-    if (gid >= (long long)a.n_items * a.iters) return;
-    const int item = (int)(gid / a.iters), h = (int)(gid % a.iters);
-    const SolverItem S = a.items[item];
-    int* out = S.samp_h + 3 * h;
-    if (S.samples) {   // explicit triples: copied, so that the later stages read one place
-        if (lane < 3) out[lane] = S.samples[3 * h + lane];
-        return;
-    }
-    const int N = *S.m_ptr;
-    int m = 0, mine = 0;   // lane k keeps the k-th index
-    if (N >= 3) {
-        const unsigned long long s0 = a.seed ^ (0xD1B54A32D192ED03ULL * (S.frame + 1)) ^
-                                      (0x8CB92BA72F3D8DD7ULL * ((unsigned long long)h + 1));
-        // draw t = f(s0 + (t + 1) gamma): the lane's counter advances by 64 gamma per round (an add, not a 64-bit multiply)
-        unsigned long long ctr = s0 + 0x9E3779B97F4A7C15ULL * ((unsigned long long)lane + 1);
-        for (int base = 0; m < 3 && base < N; base += 64, ctr += 64ULL * 0x9E3779B97F4A7C15ULL) {
-            const int t = base + lane;
-            unsigned long long z = ctr;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-            z ^= z >> 31;
-            const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
-            const double x = (double)(N - t) * u;
-            int lo = 0;
-            while (m < 3) {
-                const bool sel = t < N && lane >= lo && !(x >= (double)(3 - m));
-                const unsigned long long mask = __ballot(sel);
-                if (!mask) break;
-                const int l = __ffsll((long long)mask) - 1;
-                if (lane == m) mine = base + l;
-                ++m;
-                lo = l + 1;
-            }
-        }
-    }
-    if (lane < 3) out[lane] = mine;   // N < 3: zeros, as viso_sample3
-}
+// ---- stage 0: the sample triples -- no kernel of their own any more --------------------------------------------------
+// Rounds 1-5 drew every triple with the reference's algorithm S (src/viso.cpp:88-107: one uniform draw per candidate
+// index) in ransac_sample_kernel, a wave per hypothesis testing 64 candidates per step: 16.9 M vector instructions per
+// 25 600 triples, the second largest kernel of the chain, 6 us of every per-call frame.  The stream is this build's
+// definition (the reference's is random_device, Q9), so the triple is now defined in O(1) -- three splitmix64 draws
+// through Floyd's subset sampling, viso_sample3 in solver_dev.h: the same distribution, uniform 3-subsets in ascending
+// order -- and every lane of ransac_hyp_kernel draws its own in its prologue.
 
 // ---- stage 1: one lane per (frame, hypothesis): 3-point GN from zero -------
 // Almost every hypothesis converges (or turns singular) within a few iterations; the ~1-2 % that do not run all 100
@@ -89,8 +51,16 @@ __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
     const int m = *S.m_ptr;
     int ok = 0;
     double tr[6] = {0, 0, 0, 0, 0, 0};        // "start search from 0", :1557
+    int sample[3] = {0, 0, 0};
+    if (S.samples) {   // explicit triples: copied, so that the later stages read one place
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sample[k] = S.samples[3 * h + k];
+    } else {
+        viso_sample3(a.seed, S.frame, h, m, sample);   // randomsample(3, m, .), :1558 (zeros for m < 3)
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S.samp_h[3 * h + k] = sample[k];   // ransac_coop_kernel, viso_batch_get_hypotheses read them here
     if (m >= 3) {
-        const int sample[3] = {S.samp_h[3 * h], S.samp_h[3 * h + 1], S.samp_h[3 * h + 2]};   // ransac_sample_kernel
         bool valid = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) valid = valid && sample[k] >= 0 && sample[k] < m;
@@ -99,7 +69,7 @@ __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) S.tr_h[6 * h + j] = tr[j];
     S.ok_h[h] = ok;
-    if (ok == 2) a.queue[1 + atomicAdd(&a.queue[0], 1)] = gid;   // ransac_coop_kernel continues it
+    if (ok == 2) a.queue[2 + atomicAdd(&a.queue[0], 1)] = gid;   // ransac_coop_kernel continues it
 }
 
 // ---- stage 1b: one WAVE per unfinished hypothesis: iterations VISO_GN_SPLIT..99, same arithmetic ------------
@@ -180,10 +150,10 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     const int row = lane >> 3, col = lane & 7;       // this lane's entry of [A | b] (row < 6, col < 7)
     const int mrow = min(row, 5), mcol = min(col, 6);
     for (int qi = (int)blockIdx.x * 4 + wv; qi < n_undecided; qi += (int)gridDim.x * 4) {
-    const int gid = a.queue[1 + qi];
+    const int gid = a.queue[2 + qi];
     const int item = gid / a.iters, h = gid % a.iters;
     const SolverItem S = a.items[item];
-    const int sample[3] = {S.samp_h[3 * h], S.samp_h[3 * h + 1], S.samp_h[3 * h + 2]};   // ransac_sample_kernel
+    const int sample[3] = {S.samp_h[3 * h], S.samp_h[3 * h + 1], S.samp_h[3 * h + 2]};   // ransac_hyp_kernel left them there
     const SolverParamsDev& sp = a.sp;
     const double* X = S.X;
     const double* obs = S.obs;
@@ -338,6 +308,10 @@ size_t viso_rot_bytes(int iters) { return (rot_off_d(iters) + (size_t)iters * 96
 __global__ __launch_bounds__(256) void ransac_rot_kernel(SolverArgs a) {
     const int np2 = ((a.iters + 1) / 2) * 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the list of undecided hypotheses has had its only reader (ransac_coop_kernel, the kernel in front of this one): empty
+    // it for the next chain -- no launch in front of ransac_hyp_kernel just to zero a word -- and keep its length for
+    // viso_batch_get_hypotheses (viso_support_sizes comes here without a list)
+    if (idx == 0 && a.queue) { a.queue[1] = a.queue[0]; a.queue[0] = 0; }
     if (idx >= (long long)a.n_items * np2) return;
     const int item = (int)(idx / np2), t = (int)(idx % np2);
     const SolverItem S = a.items[item];
@@ -776,8 +750,6 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
-        hipLaunchKernelGGL(ransac_sample_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, a);
-        HIP_TRY(hipGetLastError());
         // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
         // 200 waves go to 50 CUs instead of one to each of 200
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
@@ -790,9 +762,13 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
         if (cb < 128) cb = 128;
         if (cb > (nh + 3) / 4) cb = (nh + 3) / 4;
         hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb), dim3(256), 0, s, a);
-        HIP_TRY(hipGetLastError());
-        const int ri = launch_inlier_count(s, a, max_points);
-        if (ri < 0) return ri;
+        int ri = hipGetLastError() == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+        if (ri >= 0) ri = launch_inlier_count(s, a, max_points);
+        if (ri < 0) {   // the chain broke behind ransac_hyp_kernel: the list would stay filled for the next one
+            (void)hipMemsetAsync(queue, 0, sizeof(int), s);
+            viso_set_error("ransac: a launch of the chain failed");
+            return ri;
+        }
     }
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(n_items), dim3(REFIT_THREADS), 0, s, a);
     HIP_TRY(hipGetLastError());
@@ -1000,7 +976,7 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     if ((r = ctx_scratch(c, 4, sizeof(int) * (4 + 2 * (size_t)iters), (void**)&dhyp)) < 0) return r;
     if ((r = ctx_scratch(c, 5, sizeof(double) * 6 * (size_t)(iters + 1), (void**)&dtrh)) < 0) return r;
     // undecided-hypothesis list, then the triples in use
-    if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&dqueue)) < 0) return r;
+    if ((r = ctx_scratch(c, 8, sizeof(int) * (2 + 4 * (size_t)iters + 3), (void**)&dqueue, true)) < 0) return r;
     SolverItem it{};
     it.X = in.put(X, 3 * (size_t)m); it.obs = in.put(obs, 4 * (size_t)m); it.ld = m; it.frame = frame;
     it.samples = samples ? in.put(samples, 3 * (size_t)iters) : nullptr;

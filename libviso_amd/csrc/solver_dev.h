@@ -297,28 +297,41 @@ __device__ inline int gn_serial(const double* X, const double* obs, int ld, cons
     return it_end >= 100 ? 0 : 2;                 // :1622
 }
 
-// splitmix64-driven selection sampling == viso_ransac_samples (hostmath.cpp)
+// ---- the sample triples: randomsample(3, N, .), src/viso.cpp:87-107 ----------------------------------------------------
+// The reference returns a uniformly distributed 3-subset of 0..N-1, ascending, from a per-call random_device (Q9): which
+// generator drives it is this build's definition.  Since round 6: the first three outputs of a splitmix64 stream keyed
+// on (seed, frame, hypothesis) through Floyd's subset sampling -- pick t uniform on 0..j, or j itself if t is taken, for
+// j = N-3, N-2, N-1 -- then sorted: the same distribution in O(1) (rounds 1-5 walked the reference's algorithm S over
+// the stream: ~N/2 draws per triple, 16.9 M vector instructions per 25 600 triples in a kernel of its own).  Host twin
+// viso_ransac_samples (hostmath.cpp), oracle twin oracle_ransac_samples: the same integers on every side.
 __host__ __device__ inline unsigned long long viso_splitmix64(unsigned long long* s) {
     unsigned long long z = (*s += 0x9E3779B97F4A7C15ULL);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+__host__ __device__ inline unsigned long long viso_mulhi64(unsigned long long a, unsigned long long b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (unsigned long long)(((unsigned __int128)a * b) >> 64);
+#endif
+}
 
 __host__ __device__ inline void viso_sample3(unsigned long long seed, unsigned long long frame, int h,
                                              int N, int out[3]) {
     unsigned long long s = seed ^ (0xD1B54A32D192ED03ULL * (frame + 1)) ^
                            (0x8CB92BA72F3D8DD7ULL * ((unsigned long long)h + 1));
-    int n = 3, t = 0, m = 0;
     out[0] = out[1] = out[2] = 0;
-    if (N < n) return;
-    while (m < n) {
-        const double u = (double)(viso_splitmix64(&s) >> 11) * (1.0 / 9007199254740992.0);
-        if ((double)(N - t) * u >= (double)(n - m)) {
-            t++;
-        } else {
-            out[m] = t;
-            t++; m++;
-        }
-    }
+    if (N < 3) return;
+    const int a = (int)viso_mulhi64(viso_splitmix64(&s), (unsigned long long)(N - 2));            // uniform on 0..N-3
+    int b = (int)viso_mulhi64(viso_splitmix64(&s), (unsigned long long)(N - 1));                  // 0..N-2
+    int c = (int)viso_mulhi64(viso_splitmix64(&s), (unsigned long long)N);                        // 0..N-1
+    b = b == a ? N - 2 : b;
+    c = (c == a || c == b) ? N - 1 : c;
+    // ascending, like randomsample's output: min / median / max
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    out[0] = lo < c ? lo : c;
+    out[2] = hi > c ? hi : c;
+    out[1] = a + b + c - out[0] - out[2];
 }

@@ -45,6 +45,8 @@ def lib():
         L.oracle_minimize_reproj.argtypes = [f64p, f64p, C.c_int, f64p, PP, i32p, C.c_int, intp]
         L.oracle_lu_solve6.restype = C.c_int
         L.oracle_lu_solve6.argtypes = [f64p, f64p]
+        L.oracle_ransac_samples_algorithm_s.restype = None
+        L.oracle_ransac_samples_algorithm_s.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, i32p]
         L.oracle_harris_response.restype = C.c_int
         L.oracle_harris_response.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, f32p]
         L.oracle_harris_response_v1.restype = C.c_int
@@ -162,9 +164,9 @@ def get_inliers(X, obs, tr, param):
     return inl[:n.value].copy(), rms.value
 
 
-def ransac_samples(seed, frame, iters, m):
+def ransac_samples(seed, frame, iters, m, algorithm_s=False):
     out = np.empty((iters, 3), np.int32)
-    lib().oracle_ransac_samples(seed, frame, iters, m, ptr(out, C.c_int32))
+    (lib().oracle_ransac_samples_algorithm_s if algorithm_s else lib().oracle_ransac_samples)(seed, frame, iters, m, ptr(out, C.c_int32))
     return out
 
 

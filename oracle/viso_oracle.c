@@ -428,11 +428,42 @@ static inline uint64_t splitmix64_next(uint64_t* s) {
     return z ^ (z >> 31);
 }
 
-/* randomsample(3,N,.) src/viso.cpp:87-107 (Knuth's selection sampling), with
- * the per-call random_device/mt19937 (Q9) replaced by a splitmix64 stream
- * keyed on (seed, frame, hypothesis) so both sides draw the same triples and
- * the result does not depend on how frames are partitioned over ranks. */
+/* randomsample(3,N,.) src/viso.cpp:87-107 returns a uniformly distributed 3-subset of 0..N-1 in ascending order
+ * (Knuth's selection sampling, algorithm S) from a per-call random_device/mt19937 (Q9: irreproducible).  WHICH
+ * generator drives it is therefore this build's definition, not the reference's; since round 6 the definition is: the
+ * first three outputs of a splitmix64 stream keyed on (seed, frame, hypothesis) -- both sides draw the same triples and
+ * the result does not depend on how frames are partitioned over ranks -- through Floyd's subset sampling (three draws,
+ * whatever N: algorithm S walks ~N/2 candidates per triple), then sorted ascending:
+ *     for i = 0, 1, 2:  j = N - 3 + i;  t = floor(draw_i * (j + 1) / 2^64)  (uniform on 0..j);  pick t, or j if t was picked
+ * Every 3-subset has probability 1 / C(N,3) up to the 2^-64 granularity of the draws: the distribution of
+ * randomsample(3, N) (tests/test_oracle.py checks subsets and marginals empirically).  Rounds 1-5 ran algorithm S over
+ * the same stream; the triples differ, their distribution does not. */
+static void sample3_floyd(uint64_t seed, uint64_t frame, int h, int N, int32_t out[3]) {
+    uint64_t s = seed ^ (0xD1B54A32D192ED03ULL * (frame + 1)) ^ (0x8CB92BA72F3D8DD7ULL * ((uint64_t)h + 1));
+    out[0] = out[1] = out[2] = 0;
+    if (N < 3) return;
+    int32_t pick[3];
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t j = (uint64_t)(N - 3 + i);
+        const int32_t t = (int32_t)(((unsigned __int128)splitmix64_next(&s) * (j + 1)) >> 64);
+        int taken = 0;
+        for (int k = 0; k < i; ++k) taken |= pick[k] == t;
+        pick[i] = taken ? (int32_t)j : t;
+    }
+    /* ascending, like randomsample's output */
+    if (pick[0] > pick[1]) { int32_t x = pick[0]; pick[0] = pick[1]; pick[1] = x; }
+    if (pick[1] > pick[2]) { int32_t x = pick[1]; pick[1] = pick[2]; pick[2] = x; }
+    if (pick[0] > pick[1]) { int32_t x = pick[0]; pick[0] = pick[1]; pick[1] = x; }
+    out[0] = pick[0]; out[1] = pick[1]; out[2] = pick[2];
+}
+
 void oracle_ransac_samples(uint64_t seed, uint64_t frame, int iters, int N, int32_t* out) {
+    for (int h = 0; h < iters; ++h) sample3_floyd(seed, frame, h, N, out + 3 * h);
+}
+
+/* The literal algorithm S of src/viso.cpp:87-107 over the same stream (one uniform double per candidate index): the
+ * rounds 1-5 definition, kept for the distribution test that compares the two samplers. */
+void oracle_ransac_samples_algorithm_s(uint64_t seed, uint64_t frame, int iters, int N, int32_t* out) {
     for (int h = 0; h < iters; ++h) {
         uint64_t s = seed ^ (0xD1B54A32D192ED03ULL * (frame + 1)) ^ (0x8CB92BA72F3D8DD7ULL * ((uint64_t)h + 1));
         int n = 3, t = 0, m = 0;

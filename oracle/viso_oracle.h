@@ -67,7 +67,11 @@ int oracle_ransac_minimize_reproj(const double* X, const double* obs, int m,
                                   double best_tr[6], int32_t* best_inl, int* n_inl,
                                   const viso_param* p, const int32_t* samples,
                                   uint64_t seed, uint64_t frame);
+/* randomsample(3, m, .) src/viso.cpp:87-107: uniform 3-subsets, ascending; three splitmix64 draws keyed on
+ * (seed, frame, hypothesis) through Floyd's subset sampling (viso_oracle.c).  _algorithm_s: the reference's algorithm
+ * over the same stream (the definition of rounds 1-5), for the distribution test. */
 void oracle_ransac_samples(uint64_t seed, uint64_t frame, int iters, int m, int32_t* out);
+void oracle_ransac_samples_algorithm_s(uint64_t seed, uint64_t frame, int iters, int m, int32_t* out);
 
 /* 6x6 LU solve as cv::solve(DECOMP_LU) does it (OpenCV 3.0 LUImpl, un-vendored;
  * singular iff |pivot| < DBL_EPSILON). A (36) and b (6) are overwritten; x in b.

@@ -104,13 +104,15 @@ def fuzz_solver(rng, L, O, synth):
             what += " | get_inliers: %d / %d inliers, rms %r / %r" % (len(i0[0]), len(i1[0]), i0[1], i1[1])
         ok = ok and ok_i
         act = np.sort(rng.permutation(m)[: int(rng.integers(3, m + 1))]).astype(np.int32)
-        r0, t0 = O.minimize_reproj(X, obs, np.zeros(6), param, act)[:2]
+        r0, t0, it0 = O.minimize_reproj(X, obs, np.zeros(6), param, act)
         r1, t1 = L.minimize_reproj(X, obs, np.zeros(6), param, act)
-        # (kind 3's observation at 1e6 is an outlier no RANSAC protects a bare minimize_reproj from: ill-posed there too)
-        # ... and a solve that the oracle itself does not finish near the truth (no outlier-free 3-point set, say) is a
-        # wandering iteration: compared only where the oracle converged to a motion of sane size
-        sane = r0 == 1 and np.abs(t0[:3]).max() < 1.0 and np.abs(t0[3:]).max() < 50.0
-        ok_m = not posed or kind == 3 or not sane or (r1 == 1 and _close(L, t0, t1))
+        # (kind 3's observation at 1e6 is an outlier no RANSAC protects a bare minimize_reproj from: ill-posed there too.)
+        # A solve the oracle DECIDES within 20 iterations -- converged, or left through the singular exit (src/viso.cpp:1605)
+        # -- must get the same verdict, and the same motion when there is one.  The others wander (no outlier-free point
+        # set, say) through rotations where one ulp of sincos decides where they end: exempt, and only those
+        # (tests/test_gpu_solver_edges.py::test_every_hypothesis_against_the_oracle measures and bounds their share)
+        decided = it0 <= 20
+        ok_m = not posed or kind == 3 or not decided or (r1 == r0 and (r0 == 0 or _close(L, t0, t1)))
         if not ok_m:
             what += " | minimize_reproj on %d points: %d / %d, tr %s / %s" % (len(act), r0, r1, t0, t1)
         ok = ok and ok_m

@@ -15,7 +15,9 @@ def _solved_alike(ok, n_inl, want):
     """the same frames solved, and the same support where a pose was found.  (A frame WITHOUT a pose reports the support
     of its best failed hypothesis; on a handful of circle matches that can be a 3-point Gauss-Newton run that wanders
     through rotations of thousands of radians, where one ulp of sincos -- the device's differs from libm's in 3 % of
-    arguments, tools/experiments/sincos_parity.hip -- decides whether it comes back: not compared.)"""
+    arguments, tools/experiments/sincos_parity.hip -- decides whether it comes back: not compared here.  tests/test_gpu_solver_edges.py::test_every_hypothesis_against_the_oracle
+    compares every hypothesis of a sequence with the oracle -- exactly for the ones the oracle decides within 20
+    iterations -- and bounds the share of the wanderers that differ.)"""
     ok, w = np.asarray(ok), np.asarray(want["ok"])
     return np.array_equal(ok, w) and np.array_equal(np.asarray(n_inl)[ok != 0], np.asarray(want["n_inl"])[w != 0])
 

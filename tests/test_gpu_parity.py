@@ -267,9 +267,9 @@ def test_ransac_minimize_reproj(viso, oracle, seed):
 
 @pytest.mark.parametrize("m", [3, 4, 5, 63, 64, 65, 127, 129, 700, 3000])
 def test_ransac_device_drawn_triples_equal_the_host_stream(viso, oracle, m):
-    """ransac_sample_kernel walks the splitmix64 selection-sampling stream 64 candidates at a time (src/viso.cpp:88-107
-    restated); its triples must be the ones viso_ransac_samples / the oracle draw one candidate at a time: a run that
-    draws on the device equals, bit for bit, a run that is handed the host's triples."""
+    """Every lane of ransac_hyp_kernel draws its own triple -- three splitmix64 draws through Floyd's subset sampling, the
+    distribution of randomsample(3, m, .), src/viso.cpp:87-107 --; its triples must be the ones viso_ransac_samples and the
+    oracle compute: a run that draws on the device equals, bit for bit, a run that is handed the host's triples."""
     X, obs, tr_gt, param = synth.make_solver_case(77 + m, m=m, outlier_frac=0.25 if m > 8 else 0.0, noise=0.2)
     for seed, frame in ((0, 0), (5, 17), (2**40 + 3, 2**33)):
         s_host = libviso_amd.ransac_samples(seed, frame, param.ransac_iter, m)

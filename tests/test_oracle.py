@@ -174,10 +174,65 @@ def test_ransac_samples_are_ascending_distinct_and_partition_invariant(oracle):
     assert np.array_equal(s, oracle.ransac_samples(123, 5, 50, 40))
     assert not np.array_equal(s, oracle.ransac_samples(123, 6, 50, 40))
     assert np.array_equal(oracle.ransac_samples(9, 0, 20, 3), np.tile([0, 1, 2], (20, 1)))
+    assert np.array_equal(oracle.ransac_samples(9, 0, 20, 2), np.zeros((20, 3), np.int32))
     # roughly uniform
     big = oracle.ransac_samples(1, 0, 4000, 10)
     cnt = np.bincount(big.reshape(-1), minlength=10)
     assert cnt.min() > 1000 and cnt.max() < 1400
+
+
+def _chi2(counts, expected):
+    return float(((counts - expected) ** 2 / expected).sum())
+
+
+@pytest.mark.parametrize("algorithm_s", [False, True])
+def test_ransac_samples_are_uniform_three_subsets(oracle, algorithm_s):
+    """randomsample(3, N, .) (src/viso.cpp:87-107) yields every 3-subset of 0..N-1 with probability 1 / C(N,3), ascending.
+    The O(1) definition of round 6 (three draws through Floyd's subset sampling) must have that distribution -- and so
+    must the literal algorithm S over the same stream, the definition of rounds 1-5, which is what the reference runs:
+    the same test on both.  Chi-square against the uniform law over all subsets (small N), over the per-position
+    marginals (larger N: P(first = a) = C(N-1-a, 2) / C(N,3), ...) and over the pair (gap1, gap2)."""
+    from itertools import combinations
+    from math import comb
+    # all subsets, N = 5, 6, 7: 10 / 20 / 35 cells
+    for N in (4, 5, 6, 7):
+        n = 60000
+        s = oracle.ransac_samples(77, N, n, N, algorithm_s=algorithm_s)
+        assert np.all(s[:, 0] < s[:, 1]) and np.all(s[:, 1] < s[:, 2]) and s.min() >= 0 and s.max() < N
+        idx = {c: i for i, c in enumerate(combinations(range(N), 3))}
+        counts = np.bincount([idx[tuple(r)] for r in s.tolist()], minlength=len(idx)).astype(float)
+        k = len(idx)
+        # chi-square with k - 1 degrees of freedom: mean k - 1, sd sqrt(2 (k - 1)); 6 sd is a one-in-a-billion event
+        assert _chi2(counts, n / k) < (k - 1) + 6 * np.sqrt(2 * (k - 1)), (N, counts)
+    # marginals of every position, N = 50 and N = 1200 (binned)
+    for N in (50, 1200):
+        n = 200000
+        s = oracle.ransac_samples(5, 3 * N, n, N, algorithm_s=algorithm_s)
+        assert np.all(s[:, 0] < s[:, 1]) and np.all(s[:, 1] < s[:, 2]) and s.min() >= 0 and s.max() < N
+        tot = comb(N, 3)
+        a = np.arange(N)
+        p_first = np.array([comb(N - 1 - int(x), 2) for x in a]) / tot
+        p_mid = np.array([int(x) * (N - 1 - int(x)) for x in a]) / tot
+        p_last = np.array([comb(int(x), 2) for x in a]) / tot
+        for col, p in ((0, p_first), (1, p_mid), (2, p_last)):
+            counts = np.bincount(s[:, col], minlength=N).astype(float)
+            # merge cells into bins of expected count >= 50
+            order = np.argsort(-p)
+            bins_c, bins_e, c_acc, e_acc = [], [], 0.0, 0.0
+            for i in order:
+                c_acc += counts[i]; e_acc += n * p[i]
+                if e_acc >= 50:
+                    bins_c.append(c_acc); bins_e.append(e_acc); c_acc = e_acc = 0.0
+            if e_acc > 0:
+                bins_c[-1] += c_acc; bins_e[-1] += e_acc
+            k = len(bins_c)
+            assert _chi2(np.array(bins_c), np.array(bins_e)) < (k - 1) + 6 * np.sqrt(2 * (k - 1)), (N, col)
+        # every index equally often over all positions: 3 / N each
+        counts = np.bincount(s.reshape(-1), minlength=N).astype(float)
+        assert _chi2(counts, 3 * n / N) < (N - 1) + 6 * np.sqrt(2 * (N - 1))
+    # hypotheses of one frame and frames of one hypothesis are different streams
+    assert len({tuple(r) for r in oracle.ransac_samples(1, 1, 50, 2000, algorithm_s=algorithm_s).tolist()}) >= 49
+    assert len({tuple(oracle.ransac_samples(1, f, 1, 2000, algorithm_s=algorithm_s)[0].tolist()) for f in range(50)}) >= 49
 
 
 def test_triangulate_no_clamp(oracle):
