@@ -27,6 +27,7 @@ struct viso_batch {
     float2* skp; int *sidx, *rank, *bstart; float* xinfo; uint8_t* qord;   // column-bucket view of every image
     uint8_t* images; int img_rows, img_cols;                // optional: [nf][2][rows][cols] uint8 (image-in mode)
     float* h_resp; float2* h_tmp_kp; float* h_tmp_resp; int* h_cnt; size_t h_slots;   // Harris detector scratch
+    void* h_part = nullptr; size_t h_part_bytes = 0;                                   // ... of the strip kernel (harris_strip_bytes)
     ImageView* views;                                       // [nf*2] (+1 empty)
     MatchProblem* probs;
     int2* ovf_q;                 // the launch's overflow queue: up to one entry per query of the batch
@@ -131,7 +132,7 @@ int viso_batch_free(viso_batch* b) {
     if (b->r8pin) note(hipHostFree(b->r8pin));
     if (b->pose_pin) note(hipHostFree(b->pose_pin));
     if (b->r8ev) note(hipEventDestroy(b->r8ev));
-    void* ptrs[] = {b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
+    void* ptrs[] = {b->h_part, b->h_resp, b->h_tmp_kp, b->h_tmp_resp, b->h_cnt, b->images, b->skp, b->sidx, b->rank, b->bstart, b->xinfo, b->views,
                     b->kp, b->desc, b->n, b->packed, b->packed8, b->r8cnt, b->sums, b->zero, b->probs, b->res, b->sorted,
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr /* + ok, n_inl */, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->rot, b->tile_flag, b->qord, b->ovf_q};
@@ -667,9 +668,18 @@ extern "C" int viso_batch_detect(viso_batch* b, int n_features, int nbinx, int n
     }
     int r;
     if (per == 0) { HIP_TRY(hipMemsetAsync(b->n, 0, sizeof(int) * (size_t)n_img, s)); return VISO_OK; }
-    if (fused)
+    if (fused) {
+        const size_t pb = harris_strip_bytes(n_img, b->img_rows, b->img_cols, nbinx, nbiny, per);   // 0: the wave-per-bin kernel
+        if (pb > b->h_part_bytes) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (b->h_part) HIP_TRY(hipFree(b->h_part));
+            b->h_part = nullptr; b->h_part_bytes = 0;
+            HIP_TRY(hipMalloc(&b->h_part, pb));
+            b->h_part_bytes = pb;
+        }
         return launch_harris_detect(s, b->images, n_img, b->img_rows, b->img_cols, n_features, nbinx, nbiny, k, b->h_tmp_kp,
-                                    b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap);
+                                    b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap, pb ? b->h_part : nullptr);
+    }
     if ((r = launch_harris_response(s, b->images, n_img, b->img_rows, b->img_cols, k, b->h_resp)) < 0) return r;
     return launch_harris_bins(s, b->h_resp, n_img, b->img_rows, b->img_cols, n_features, nbinx, nbiny, b->h_tmp_kp,
                               b->h_tmp_resp, b->h_cnt, b->kp, nullptr, b->n, b->cap, (size_t)b->cap);

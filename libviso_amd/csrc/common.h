@@ -305,9 +305,12 @@ int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int
                         int rows, int cols, int extras, int r8s, int* r8cnt);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);
 size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per);
+// part: harris_strip_bytes(...) bytes of device scratch for the strip kernel (waves over 58-column strips instead of bins), or
+// null: the wave-per-bin kernel.  harris_strip_bytes returns 0 where the strip kernel does not apply or would not pay.
+size_t harris_strip_bytes(int n_img, int rows, int cols, int nbinx, int nbiny, int per);
 int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,
                          int nbiny, double k, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
-                         int* n_out, int cap, size_t kp_stride);
+                         int* n_out, int cap, size_t kp_stride, void* part = nullptr);
 int launch_harris_bins(hipStream_t s, const float* resp, int n_img, int rows, int cols, int n_features, int nbinx,
                        int nbiny, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
                        int* n_out, int cap, size_t kp_stride);

@@ -12,6 +12,7 @@
 // - k*(a+c)*(a+c)).  OpenCV's running column sums are the one thing an algorithm-level
 // restatement cannot pin (see the oracle's header): parity with a real OpenCV is unpinned.
 #include "common.h"
+#include <stdlib.h>
 
 // ---- the response of a tile, one pass, registers only ---------------------------------------------------------
 // Arithmetic contract = the oracle's restatement of cv::cornerHarris in OpenCV's evaluation order (oracle/viso_oracle.c,
@@ -532,18 +533,19 @@ __global__ __launch_bounds__(256) void harris_bins_kernel(BinArgs a) {
 // words (push order): when more of them exist than places are left, the old pick-by-pick loop runs (rare: equal
 // |response| bits).  The walk only tests the high word of tau, so the set kept here is the exact top `per`.
 struct HarrisKept { unsigned long long tau; int n; };
-__device__ __forceinline__ HarrisKept harris_keep_best_picks(unsigned long long (&mine)[HD_CAND / 64], unsigned long long* list, int per) {
+template <int CAND>
+__device__ __forceinline__ HarrisKept harris_keep_best_picks(unsigned long long (&mine)[CAND / 64], unsigned long long* list, int per) {
     const int lane = threadIdx.x & 63;
     int kept = 0;
     unsigned long long last = 0;
     for (int round = 0; round < per; ++round) {
         unsigned long long loc = mine[0];
 #pragma unroll
-        for (int u = 1; u < HD_CAND / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
+        for (int u = 1; u < CAND / 64; ++u) loc = mine[u] > loc ? mine[u] : loc;
         const unsigned long long best = wave_max_u64(loc);
         if (best == 0) break;
 #pragma unroll
-        for (int u = 0; u < HD_CAND / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
+        for (int u = 0; u < CAND / 64; ++u) if (mine[u] == best) mine[u] = 0;   // keys are unique
         if (lane == 0) list[kept] = best;
         last = best;
         ++kept;
@@ -555,11 +557,12 @@ __device__ __forceinline__ HarrisKept harris_keep_best_picks(unsigned long long 
     return out;
 }
 
+template <int CAND = HD_CAND>
 __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list, int n, int per, bool sorted) {
     const int lane = threadIdx.x & 63;
-    unsigned long long mine[HD_CAND / 64];
+    unsigned long long mine[CAND / 64];
 #pragma unroll
-    for (int u = 0; u < HD_CAND / 64; ++u) mine[u] = (lane + 64 * u < n) ? list[lane + 64 * u] : 0ull;
+    for (int u = 0; u < CAND / 64; ++u) mine[u] = (lane + 64 * u < n) ? list[lane + 64 * u] : 0ull;
     __builtin_amdgcn_wave_barrier();
     HarrisKept out;
     if (n <= per && !sorted) {                              // uniform: nothing to drop, nothing to order
@@ -572,9 +575,9 @@ __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list,
         }
         return out;
     }
-    uint32_t hi[HD_CAND / 64];
+    uint32_t hi[CAND / 64];
 #pragma unroll
-    for (int u = 0; u < HD_CAND / 64; ++u) hi[u] = (uint32_t)(mine[u] >> 32);
+    for (int u = 0; u < CAND / 64; ++u) hi[u] = (uint32_t)(mine[u] >> 32);
     // T = a high word with #(hi >= T) >= per, built from the top bit down (the greatest such T = the per-th largest high
     // word when every bit is decided; 0 when fewer than `per` keys exist).  Every prefix is such a T already, so the
     // descent stops as soon as few enough keys are at or above it: exactly `per` for the final, ordered list (they ARE the
@@ -588,15 +591,15 @@ __device__ __forceinline__ HarrisKept harris_keep_best(unsigned long long* list,
         const uint32_t cand = T | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int u = 0; u < HD_CAND / 64; ++u) cnt += __popcll(__ballot(hi[u] >= cand));
+        for (int u = 0; u < CAND / 64; ++u) cnt += __popcll(__ballot(hi[u] >= cand));
         if (cnt >= per) { T = cand; kept = cnt; }           // uniform
     }
     // every bit decided and still more than `per` at or above T: keys tie T's high word, the low words decide among them
-    if (bit < 0 && T != 0 && kept > per) return harris_keep_best_picks(mine, list, per);   // uniform
+    if (bit < 0 && T != 0 && kept > per) return harris_keep_best_picks<CAND>(mine, list, per);   // uniform
     // compaction of everything at or above T (T == 0: fewer than `per` keys, all stay)
     int base = 0;
 #pragma unroll
-    for (int u = 0; u < HD_CAND / 64; ++u) {
+    for (int u = 0; u < CAND / 64; ++u) {
         const bool take = mine[u] != 0ull && hi[u] >= T;
         const unsigned long long m = __ballot(take);
         const int at = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -674,6 +677,133 @@ __global__ __launch_bounds__(HW_THREADS) void harris_detect_kernel(BinArgs a, co
     if (lane == 0) a.cnt[(size_t)img * nbins + bin] = n;
 }
 
+
+#ifdef VISO_DEBUG_VARIANTS
+// ---- strips that ignore the bin boundaries (round 6): MEASURED AND LOST, built in -DVISO_DEBUG_VARIANTS libraries only -------
+// (0.268 ms against 0.241 ms per 258 images alone, alternating on one box, tools/experiments/harris_strips_ab.sh: one wave
+// in twelve less, but every PART of a bin prunes its own candidate list -- 2.1 parts per wave, each with its own mid-walk and
+// final harris_keep_best -- and a narrow part takes ~19 rows instead of 3 to fill its list and get a threshold, during which
+// every row takes the append path.  HISTORY.md, round 6.)
+// A bin of the reference's geometry is 51 columns wide (1241 / 24): the walk above, a wave per bin with lane = pixel
+// column, leaves 13 of 64 lanes without an output column.  Here a wave takes a STRIP of HW_DIRECT_MAXW = 58 output columns
+// of one bin ROW instead -- 22 strips cover what 24 bins cover, one wave in twelve less for the same pixels -- and keeps
+// one candidate list per bin COLUMN its lanes fall into (a lane's bin column never changes during the walk: at most
+// HS_NG = 3 groups of lanes, each with its own list, count and threshold; the row's test stays ONE compare against a
+// per-lane threshold and one ballot, the appends only run for groups that have a candidate).  At the end of the walk
+// every group leaves the best `per` keys of its part of the bin, in order; a bin's corners are the best `per` of the
+// (at most two) parts that cover it: the true top `per` of a union is contained in the union of the parts' top `per`, and
+// harris_merge_kernel selects it.  Same arithmetic per pixel (the walk is the same function), same keys, same order:
+// bit-identical to the wave-per-bin kernel (tests/test_gpu_harris.py runs both).
+#define HS_NG 3        // bin columns a strip can touch: needs stridex >= (HW_DIRECT_MAXW - 1) / 2 = 29 (launcher)
+#define HS_CAND 192    // candidate keys per group: 3 x 1.5 KB per wave keeps 8 waves per SIMD inside the LDS
+// the mid-walk pruning as a real call: inlined into 15 unrolled rows x 3 groups it made the kernel 80 KB of code (the
+// wave-per-bin kernel: 40 KB; a call there measured the same time as the inlined body, HISTORY.md round 5)
+__device__ __noinline__ HarrisKept harris_keep_best_strip(unsigned long long* list, int n, int per) {
+    return harris_keep_best<HS_CAND>(list, n, per, false);
+}
+struct StripArgs {
+    int nstrips;                 // strips per bin row: ceil(nbinx * stridex / HW_DIRECT_MAXW)
+    unsigned long long* part;    // [n_img][nbins][2][per] keys of the parts, descending
+    int* part_cnt;               // [n_img][nbins][2]
+};
+__global__ __launch_bounds__(HW_THREADS) void harris_strip_kernel(BinArgs a, StripArgs sa, const uint8_t* __restrict__ images, double k) {
+    __shared__ unsigned long long s_list[HW_THREADS / 64][HS_NG][HS_CAND];
+    const int nbins = a.nbinx * a.nbiny;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * (HW_THREADS / 64) + wave;
+    const int per_img = sa.nstrips * a.nbiny;
+    if (unit >= (long long)a.n_img * per_img) return;
+    const int img = (int)(unit / per_img), rem = (int)(unit % per_img);
+    const int by = rem / sa.nstrips, strip = rem % sa.nstrips;
+    const int xend = a.nbinx * a.stridex;                  // columns past the last bin are nobody's (:934-936)
+    const int tx0 = strip * HW_DIRECT_MAXW, ty0 = by * a.stridey;
+    const int tw = min(HW_DIRECT_MAXW, xend - tx0), th = a.stridey;
+    const int per = a.per;
+    const uint8_t* im = images + (size_t)img * a.rows * a.cols;
+    // this lane's output column (DIRECT layout: lane l <-> pixel column tx0 - 3 + l, output column x = l - 3), its bin
+    // column, its group and its column inside the bin
+    const int x = lane - 3;
+    const bool owns = x >= 0 && x < tw;
+    const int gxo = tx0 + (owns ? x : 0);
+    const int bx0 = tx0 / a.stridex;
+    const int bx = gxo / a.stridex;
+    const int grp = bx - bx0;                              // 0 .. HS_NG - 1
+    const int xin = gxo - bx * a.stridex;
+    unsigned long long gmask[HS_NG];
+    int n[HS_NG];
+#pragma unroll
+    for (int g = 0; g < HS_NG; ++g) { gmask[g] = __builtin_amdgcn_ballot_w64(owns && grp == g); n[g] = 0; }
+    uint32_t thi = 1;                                      // per LANE: max(its group's tau high word, 1)
+    const uint32_t posx = (uint32_t)(xin * th);
+    harris_walk_band_impl<true>(nullptr, im, a.rows, a.cols, tx0, ty0, tw, 0, th, k, [&](int y, int, float R, bool, unsigned long long vmask) {
+        const uint32_t hi = __float_as_uint(R) & 0x7fffffffu;
+        const unsigned long long m = vmask & __builtin_amdgcn_ballot_w64(hi >= thi);
+        if (m) {                                           // uniform
+            const unsigned long long key = ((unsigned long long)hi << 32) | (uint32_t)(0xffffffffu - (posx + (uint32_t)y));
+#pragma unroll
+            for (int g = 0; g < HS_NG; ++g) {
+                const unsigned long long mg = m & gmask[g];
+                if (mg) {                                  // uniform
+                    unsigned long long* list = s_list[wave][g];
+                    const bool take = __builtin_amdgcn_inverse_ballot_w64(mg);
+                    const int at = n[g] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u));
+                    if (take) list[at] = key;
+                    n[g] += __popcll(mg);
+                    if (n[g] > HS_CAND - HW_DIRECT_MAXW) { // uniform: the next row might not fit
+                        __builtin_amdgcn_wave_barrier();
+                        const HarrisKept kb = harris_keep_best_strip(list, n[g], per);
+                        n[g] = kb.n;
+                        const uint32_t t = max((uint32_t)(kb.tau >> 32), 1u);
+                        if (__builtin_amdgcn_inverse_ballot_w64(gmask[g])) thi = t;
+                    }
+                }
+            }
+        }
+    });
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < HS_NG; ++g) {
+        if (!gmask[g]) continue;                           // uniform: the strip does not reach that bin column
+        unsigned long long* list = s_list[wave][g];
+        const HarrisKept kb = harris_keep_best<HS_CAND>(list, n[g], per, true);
+        const int bxg = bx0 + g;
+        const int slot = strip - (bxg * a.stridex) / HW_DIRECT_MAXW;   // 0: the first strip that reaches the bin, 1: the second
+        const size_t o = (((size_t)img * nbins + (size_t)bxg * a.nbiny + by) * 2 + (size_t)slot);
+        if (lane < kb.n) sa.part[o * per + lane] = list[lane];         // per <= HD_MAXPER <= 64
+        if (lane == 0) sa.part_cnt[o] = kb.n;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// A bin's corners from its parts: thread per (image, bin), merge of at most two descending key lists.
+__global__ __launch_bounds__(256) void harris_merge_kernel(BinArgs a, StripArgs sa) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nbins = a.nbinx * a.nbiny;
+    if (t >= (long long)a.n_img * nbins) return;
+    const int img = (int)(t / nbins), bin = (int)(t % nbins);
+    const int bxg = bin / a.nbiny, by = bin % a.nbiny;
+    const int s0 = (bxg * a.stridex) / HW_DIRECT_MAXW, s1 = (bxg * a.stridex + a.stridex - 1) / HW_DIRECT_MAXW;
+    const size_t o = ((size_t)img * nbins + bin) * 2;
+    const unsigned long long* A = sa.part + o * a.per;
+    const unsigned long long* B = A + a.per;
+    const int na = sa.part_cnt[o], nb = s1 > s0 ? sa.part_cnt[o + 1] : 0;
+    const int x0 = bxg * a.stridex, y0 = by * a.stridey;
+    const size_t obase = ((size_t)img * nbins + bin) * a.per;
+    int i = 0, j = 0, n = 0;
+    while (n < a.per && (i < na || j < nb)) {
+        const unsigned long long ka = i < na ? A[i] : 0ull, kb = j < nb ? B[j] : 0ull;   // keys are unique and non-zero
+        const unsigned long long best = ka > kb ? ka : kb;
+        if (ka > kb) ++i; else ++j;
+        const int pos = (int)(0xffffffffu - (uint32_t)best);
+        a.tmp_kp[obase + n] = make_float2((float)(x0 + pos / a.stridey), (float)(y0 + pos % a.stridey));
+        a.tmp_resp[obase + n] = __uint_as_float((uint32_t)(best >> 32));
+        ++n;
+    }
+    a.cnt[(size_t)img * nbins + bin] = n;
+}
+
+#endif   // VISO_DEBUG_VARIANTS
+
 // One workgroup per image: concatenate the bins' corners in bin order.
 __global__ __launch_bounds__(256) void harris_compact_kernel(BinArgs a, float2* kp_out, float* resp_out, int* n_out,
                                                              int cap, size_t kp_stride) {
@@ -721,10 +851,31 @@ size_t harris_fused_lds(int rows, int cols, int nbinx, int nbiny, int per) {
     return b <= 64 * 1024 ? b : 0;
 }
 
+// Scratch of the strip kernel for this geometry in bytes (0: the geometry, or a batch too small to fill the GPU with strips,
+// keeps the wave-per-bin kernel; always 0 in the product build).  $VISO_HARRIS_STRIPS=0 / 1 forces either (tests run both).
+size_t harris_strip_bytes(int n_img, int rows, int cols, int nbinx, int nbiny, int per) {
+#ifndef VISO_DEBUG_VARIANTS
+    (void)n_img; (void)rows; (void)cols; (void)nbinx; (void)nbiny; (void)per;
+    return 0;   // the strip kernel lost (see above): not in the product build
+#else
+    const int sx = cols / nbinx, sy = rows / nbiny;
+    if (sx <= 0 || sy <= 0 || per <= 0 || per > HD_MAXPER) return 0;
+    if (sx > HW_DIRECT_MAXW || sx < (HW_DIRECT_MAXW - 1) / 2 + 1) return 0;            // a strip must not reach more than HS_NG bin columns
+    const int nstrips = (nbinx * sx + HW_DIRECT_MAXW - 1) / HW_DIRECT_MAXW;
+    int mode = -1;
+    if (const char* e = getenv("VISO_HARRIS_STRIPS")) mode = atoi(e) != 0;
+    if (mode == 0) return 0;
+    if (mode < 0 && (nstrips >= nbinx || (long long)n_img * nstrips * nbiny < 16384)) return 0;   // nothing to gain / too few waves
+    const size_t nb = (size_t)n_img * nbinx * nbiny;
+    return nb * 2 * per * sizeof(unsigned long long) + nb * 2 * sizeof(int);
+#endif
+}
+
 // images -> corners without a response image (callers check harris_fused_lds first)
+// part: harris_strip_bytes(...) bytes of scratch, or null: the wave-per-bin kernel
 int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, int n_features, int nbinx,
                          int nbiny, double k, float2* tmp_kp, float* tmp_resp, int* cnt, float2* kp_out, float* resp_out,
-                         int* n_out, int cap, size_t kp_stride) {
+                         int* n_out, int cap, size_t kp_stride, void* part) {
     if (n_img <= 0) return VISO_OK;
     BinArgs a;
     a.resp = nullptr; a.rows = rows; a.cols = cols; a.n_img = n_img;
@@ -734,15 +885,31 @@ int launch_harris_detect(hipStream_t s, const uint8_t* images, int n_img, int ro
     const int nbins = nbinx * nbiny;
     const size_t lds = harris_fused_lds(rows, cols, nbinx, nbiny, a.per);
     if (!lds) { viso_set_error("harris: bin geometry does not fit the fused detector"); return VISO_ERR_UNSUPPORTED; }
-    const dim3 grid((unsigned)(((long long)n_img * nbins + HW_THREADS / 64 - 1) / (HW_THREADS / 64)));
-    if (a.stridex <= HW_DIRECT_MAXW) {
-        hipLaunchKernelGGL(harris_detect_kernel<true>, grid, dim3(HW_THREADS), lds, s, a, images, k);
-    } else {
-        if (lds > 32 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(harris_detect_kernel<false>, grid, dim3(HW_THREADS), lds, s, a, images, k);
+#ifdef VISO_DEBUG_VARIANTS
+    if (part && harris_strip_bytes(n_img, rows, cols, nbinx, nbiny, a.per)) {
+        StripArgs sa;
+        sa.nstrips = (nbinx * a.stridex + HW_DIRECT_MAXW - 1) / HW_DIRECT_MAXW;
+        sa.part = reinterpret_cast<unsigned long long*>(part);
+        sa.part_cnt = reinterpret_cast<int*>(sa.part + (size_t)n_img * nbins * 2 * a.per);
+        const long long units = (long long)n_img * sa.nstrips * nbiny;
+        hipLaunchKernelGGL(harris_strip_kernel, dim3((unsigned)((units + HW_THREADS / 64 - 1) / (HW_THREADS / 64))), dim3(HW_THREADS), 0, s, a, sa, images, k);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(harris_merge_kernel, dim3((unsigned)(((long long)n_img * nbins + 255) / 256)), dim3(256), 0, s, a, sa);
+        HIP_TRY(hipGetLastError());
+    } else
+#endif
+    {
+        (void)part;
+        const dim3 grid((unsigned)(((long long)n_img * nbins + HW_THREADS / 64 - 1) / (HW_THREADS / 64)));
+        if (a.stridex <= HW_DIRECT_MAXW) {
+            hipLaunchKernelGGL(harris_detect_kernel<true>, grid, dim3(HW_THREADS), lds, s, a, images, k);
+        } else {
+            if (lds > 32 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void*)harris_detect_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(harris_detect_kernel<false>, grid, dim3(HW_THREADS), lds, s, a, images, k);
+        }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(harris_compact_kernel, dim3(n_img), dim3(256), sizeof(int) * (size_t)(nbins + 1), s, a, kp_out,
                        resp_out, n_out, cap, kp_stride);
     HIP_TRY(hipGetLastError());
@@ -814,8 +981,11 @@ extern "C" int viso_detect_harris_binned(const uint8_t* img, int rows, int cols,
     if ((r = ctx_scratch(c, 6, sizeof(float) * slots, (void**)&dro)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(dimg, img, px, hipMemcpyHostToDevice, c->stream));
     if (harris_fused_lds(rows, cols, nbinx, nbiny, per)) {
+        void* part = nullptr;   // one image never fills the GPU with strips: only when $VISO_HARRIS_STRIPS=1 forces them (tests)
+        if (const size_t pb = harris_strip_bytes(1, rows, cols, nbinx, nbiny, per))
+            if ((r = ctx_scratch(c, 7, pb, &part)) < 0) return r;
         if ((r = launch_harris_detect(c->stream, dimg, 1, rows, cols, n_features, nbinx, nbiny, k, dtk, dtr, dcnt, dko, dro,
-                                      dcnt + nbins, (int)slots, slots)) < 0) return r;
+                                      dcnt + nbins, (int)slots, slots, part)) < 0) return r;
     } else {
         if ((r = launch_harris_response(c->stream, dimg, 1, rows, cols, k, dr)) < 0) return r;
         if ((r = launch_harris_bins(c->stream, dr, 1, rows, cols, n_features, nbinx, nbiny, dtk, dtr, dcnt, dko, dro,

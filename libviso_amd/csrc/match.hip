@@ -23,6 +23,7 @@
 // minimal SAD with the LARGEST key.  No neighbour list is materialised, and the
 // order in which candidates are visited (here: column buckets) is irrelevant.
 #include "common.h"
+#include <stdlib.h>
 #include "match_dev.h"
 
 #include <math.h>
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(256) void pack_desc_kernel(const ImageView* __restr
         if (!(a == ar) || a < -32768.f || a > 32767.f || !(b == br) || b < -32768.f || b > 32767.f) isbad = true;
         const uint32_t ua = (uint32_t)((int)ar + VISO_BIAS) & 0xffffu, ub = (uint32_t)((int)br + VISO_BIAS) & 0xffffu;
         const int d = __builtin_amdgcn_readlane(dst, k);
+#ifdef VISO_DEBUG_VARIANTS   // timing experiment only ($VISO_EXP_PACK_NO_U16, HISTORY.md round 6): what the kernel would cost without the u16 rows
+        if (!(extras & 0x100))
+#endif
         ((gout_t)reinterpret_cast<uint32_t*>(I.rows + (size_t)d * VISO_ROW))[lane] = ua | (ub << 16);
         // block sums (ImageView::sums; only match_prune_kernel reads them): lanes 16b..16b+15 hold block b; meaningless
         // for flagged images (never read then)
@@ -340,6 +344,9 @@ int launch_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, in
     const long long waves = (long long)n_img * capp / VISO_PACK_RPW;
     if (waves == 0) return VISO_OK;
     const int blocks = (int)((waves + 3) / 4);
+#ifdef VISO_DEBUG_VARIANTS
+    { static const int no_u16 = [] { const char* e = getenv("VISO_EXP_PACK_NO_U16"); return e && *e == '1'; }(); if (no_u16) extras |= 0x100; }
+#endif
     hipLaunchKernelGGL(pack_desc_kernel, dim3(blocks), dim3(256), 0, s, imgs_dev, n_img, capp, dlen, bad_any, extras, r8s, (extras & VISO_PACK_ROWS8) ? r8cnt : nullptr, r8_mask(waves));
     HIP_TRY(hipGetLastError());
     return VISO_OK;

@@ -80,6 +80,80 @@ def test_detect_random_geometries(viso, oracle):
         assert np.array_equal(libviso_amd.harris_response(img), oracle.harris_response(img)), img.shape
 
 
+# The strip kernel (waves over 58-column strips of a bin row, a candidate list per bin column, parts merged per bin; round 6:
+# measured 11 % slower than the wave-per-bin kernel, so it is compiled into -DVISO_DEBUG_VARIANTS libraries only -- in the
+# product build $VISO_HARRIS_STRIPS changes nothing and these tests run the one kernel twice) must give
+# what the wave-per-bin kernel gives: forced by $VISO_HARRIS_STRIPS=1 for single images -- bin widths from 29 (the narrowest
+# it takes: a strip then touches three bin columns) to 58, strips that end inside the last bin, bins in one part and in
+# two, both image borders -- and chosen by the launcher itself for a batch large enough.
+@pytest.mark.parametrize("shape,bx,by,per", [
+    ((376, 1241), 24, 5, 10),     # the reference's geometry: 51-column bins, 22 strips, columns 1224..1240 in no bin
+    ((376, 1241), 22, 5, 10),     # 56 columns
+    ((376, 1241), 21, 5, 10),     # 59 columns: not the strip kernel's (LDS tile), the switch must not break it
+    ((120, 400), 13, 3, 7),       # 30 columns: three bin columns per strip
+    ((120, 400), 10, 2, 32),      # 40 columns, per at the cap
+    ((90, 300), 6, 4, 5),         # 50 columns
+    ((100, 58), 1, 2, 16),        # one bin = one strip, both borders
+    ((64, 116), 2, 1, 20),        # 58 columns: bins and strips coincide
+    ((50, 95), 3, 1, 9),          # 31 columns, 93 of 95 in bins: the second strip is 35 wide
+    ((30, 64), 2, 10, 3),         # 3 rows per bin
+])
+def test_detect_strip_kernel_bit_exact(viso, oracle, shape, bx, by, per, monkeypatch):
+    nf = per * bx * by
+    for seed in (3, 4):
+        img = synth.make_images(seed, shape[0], shape[1])
+        k0, r0 = oracle.detect_harris_binned(img, nf, bx, by)
+        monkeypatch.setenv("VISO_HARRIS_STRIPS", "0")
+        ka, ra = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        monkeypatch.setenv("VISO_HARRIS_STRIPS", "1")
+        kb, rb = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        assert np.array_equal(k0, ka) and np.array_equal(r0, ra)
+        assert np.array_equal(k0, kb) and np.array_equal(r0, rb), (shape, bx, by, per)
+        assert len(k0) > 0
+
+
+def test_detect_strip_kernel_random_geometries(viso, oracle, monkeypatch):
+    import harris_fuzz
+    monkeypatch.setenv("VISO_HARRIS_STRIPS", "1")
+    n_strip = 0
+    for img, nf, bx, by in harris_fuzz.cases(7, 500):
+        sx = img.shape[1] // bx
+        if not (29 <= sx <= 58):      # the geometries the strip kernel takes
+            continue
+        n_strip += 1
+        k0, r0 = oracle.detect_harris_binned(img, nf, bx, by)
+        k1, r1 = libviso_amd.detect_harris_binned(img, nf, bx, by)
+        assert np.array_equal(k0, k1) and np.array_equal(r0, r1), harris_fuzz.describe(img, nf, bx, by, k0, k1)
+    assert n_strip >= 40
+
+
+def test_batch_detect_takes_the_strip_kernel_when_it_pays(viso, oracle, monkeypatch):
+    """A batch of enough images for 16384 strip waves: the launcher picks the strip kernel by itself; keypoints of sampled
+    images against the oracle, and the whole batch against the wave-per-bin kernel."""
+    monkeypatch.delenv("VISO_HARRIS_STRIPS", raising=False)
+    rows, cols, nf = 120, 400, 98          # 13 x 12 bins of 30 x 10: 98 frames x 2 images x 7 strips x 12 bin rows = 16464 waves (>= 16384)
+    rng = np.random.default_rng(5)
+    base = [synth.make_images(100 + i, rows, cols) for i in range(6)]
+    images = np.stack([np.stack([np.roll(base[(2 * t + s) % 6], (t + 3 * s) % 17, axis=1) for s in range(2)]) for t in range(nf)])
+    got = {}
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("VISO_HARRIS_STRIPS", raising=False)
+        else:
+            monkeypatch.setenv("VISO_HARRIS_STRIPS", mode)
+        ctx = libviso_amd.Context(0)
+        b = libviso_amd.Batch(ctx, nf, 13 * 12 * 3)
+        b.upload_images_only(images)
+        b.detect(n_features=13 * 12 * 3, nbinx=13, nbiny=12)
+        got[mode] = [b.keypoints(t, s) for t in range(nf) for s in range(2)]
+        b.close(); ctx.close()
+    for a, c in zip(got[None], got["0"]):
+        assert np.array_equal(a, c)
+    for t, s in ((0, 0), (17, 1), (97, 1)):
+        k0, _ = oracle.detect_harris_binned(images[t, s], 13 * 12 * 3, 13, 12)
+        assert np.array_equal(got[None][2 * t + s], k0)
+
+
 def test_image_to_pose_pipeline(viso, oracle):
     seq = synth.make_image_sequence(9, 4, n_kp=1500)
     nf = 4
