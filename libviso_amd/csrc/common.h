@@ -200,8 +200,12 @@ int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, con
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
 // zero_words / n_zero: optional 32-bit words the kernel zeroes on the way (a run's counters: one memset less in front of it)
 // r8zero: the batch's four VISO_R8_* counters, zeroed too when the run is one that counts (or null)
+// imp (plain family, n_img == 1): the image comes from pinned HOST memory -- its view rides in the kernel arguments, the
+// kernel reads the keypoints over PCIe, leaves them in view.kp, writes *view.n = n, *view.bad = bad0 and a copy of the view
+// at view_dst (where the pack kernel's launch finds it): the copy kernel that used to run in front is gone
+struct KpImport { const float2* src_kp; int n, bad0; ImageView* view_dst; ImageView view; };
 int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words = nullptr, int n_zero = 0,
-                   int* r8zero = nullptr);
+                   int* r8zero = nullptr, const KpImport* imp = nullptr);
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 #endif
 
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
-                                                                   uint32_t* zero_words, int n_zero, int* r8zero) {
+                                                                   uint32_t* zero_words, int n_zero, int* r8zero, KpImport imp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* ykey = reinterpret_cast<uint32_t*>(smem);   // [n rounded up to 64] sortable y of the entry at each position
     __shared__ int s_cnt[VISO_NB + 1];                    // bucket counts -> starts -> running offsets
@@ -65,8 +65,19 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
             if (j < n_zero) zero_words[j] = 0u;
         }
     }
-    const ImageView I = imgs[blockIdx.x];
-    const int n = *I.n;
+    // One image straight from the caller's side (the plain family, KpImport): the view comes with the launch, the keypoints
+    // are read from pinned host memory and left in the image's device array on the way, the header words are written here --
+    // no copy kernel in front of this one
+    const bool importing = imp.src_kp != nullptr;
+    const ImageView I = importing ? imp.view : imgs[blockIdx.x];
+    const int n = importing ? imp.n : *I.n;
+    if (importing) {
+        if (threadIdx.x == 0) { *const_cast<int*>(I.n) = n; *I.bad = imp.bad0; }
+        if (threadIdx.x < sizeof(ImageView) / 4) reinterpret_cast<uint32_t*>(imp.view_dst)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&imp.view)[threadIdx.x];
+        // keypoints past the registers' share are walked from memory three times: bring them over first
+        for (int i = threadIdx.x + VISO_KP_REGS * VISO_IMG_THREADS; i < n; i += VISO_IMG_THREADS) const_cast<float2*>(I.kp)[i] = imp.src_kp[i];
+    }
+    const float2* kp_in = importing ? imp.src_kp : I.kp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // ---- x extent (x0 = smallest x, x1 = largest non-NaN x: the bucket map), finite y extent, number of non-NaN x
     float xmn = __builtin_huge_valf(), xmx = -__builtin_huge_valf(), ymn = __builtin_huge_valf(), ymx = -__builtin_huge_valf();
@@ -77,7 +88,8 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
 #pragma unroll
     for (int u = 0; u < VISO_KP_REGS; ++u) {
         const int i = threadIdx.x + u * VISO_IMG_THREADS;
-        kreg[u] = i < n ? I.kp[i] : make_float2(0.f, 0.f);
+        kreg[u] = i < n ? kp_in[i] : make_float2(0.f, 0.f);
+        if (importing && i < n) const_cast<float2*>(I.kp)[i] = kreg[u];
     }
     // visit(i, k) for every keypoint of this thread: the register ones (compile-time slots), then the rest from memory
     auto walk = [&](auto visit) {
@@ -164,8 +176,11 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     }
 }
 
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero) {
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero, const KpImport* imp) {
     if (n_img <= 0) return VISO_OK;
+    if (imp && n_img != 1) { viso_set_error("launch_sort_kp: an import is one image"); return VISO_ERR_ARG; }
+    KpImport ki{};
+    if (imp) ki = *imp;
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
         return VISO_ERR_UNSUPPORTED;
@@ -174,7 +189,7 @@ int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_
     const size_t lds = (size_t)n64 * sizeof(uint32_t) + 16;
     if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_kp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64, zero_words, n_zero, r8zero);
+    hipLaunchKernelGGL(sort_kp_kernel, dim3(n_img), dim3(VISO_IMG_THREADS), lds, s, imgs_dev, n_img, n64, zero_words, n_zero, r8zero, ki);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -15,6 +15,7 @@
 // Same results as the other kernels.  Irregular queries (more than K or 128 in-radius candidates, an exact SAD
 // tie) go to match_overflow_kernel.
 #include "common.h"
+#include <stdlib.h>
 #include "match_dev.h"
 
 #define MB_THREADS 256
@@ -495,8 +496,22 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         const int r = launch_match_prune_temporal(s, at, bt);
         if (r < 0) return r;
     } else if (variant == 6) {
+#ifdef VISO_DEBUG_VARIANTS
+        // experiment ($VISO_EXP_HEAVY_TOKEN=1, HISTORY.md round 6): the VALU-bound temporal kernels of ALL batches of the process
+        // run one after the other (a device-wide event chain), so that what runs beside one is another batch's pack / stereo /
+        // sort kernels, never a second copy of itself
+        static const int token = [] { const char* e = getenv("VISO_EXP_HEAVY_TOKEN"); return e ? atoi(e) : 0; }();
+        static hipEvent_t heavy_ev = nullptr;
+        if (token) {
+            if (!heavy_ev) HIP_TRY(hipEventCreateWithFlags(&heavy_ev, hipEventDisableTiming));
+            HIP_TRY(hipStreamWaitEvent(s, heavy_ev, 0));
+        }
+#endif
         const int r = launch_match_union8_temporal(s, at, bt);
         if (r < 0) return r;
+#ifdef VISO_DEBUG_VARIANTS
+        if (token) HIP_TRY(hipEventRecord(heavy_ev, s));
+#endif
     } else {
         const int r = launch_match_union_temporal(s, at, bt);
         if (r < 0) return r;

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "match_dev.h"
 #include <stddef.h>
+#include <stdlib.h>
 
 #define MU_THREADS 256
 #define MU_WAVES 4
@@ -711,7 +712,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
 }
 
 int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks) {
-    hipLaunchKernelGGL(match_union8_kernel, dim3((unsigned)blocks), dim3(MU_THREADS), 0, s, a);
+    size_t pad = 0;
+#ifdef VISO_DEBUG_VARIANTS   // experiment ($VISO_EXP_U8_LDS_PAD bytes of unused dynamic LDS): 6 instead of 7 workgroups per CU, so that another
+    // batch's pack kernel finds LDS and wave slots beside this kernel (HISTORY.md round 6)
+    { static const int p = [] { const char* e = getenv("VISO_EXP_U8_LDS_PAD"); return e ? atoi(e) : 0; }(); if (p > 0 && p < 32768) pad = (size_t)p; }
+#endif
+    hipLaunchKernelGGL(match_union8_kernel, dim3((unsigned)blocks), dim3(MU_THREADS), pad, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { viso_set_error("match_union8_kernel launch: %s", hipGetErrorString(e)); return VISO_ERR_HIP; }
     return VISO_OK;

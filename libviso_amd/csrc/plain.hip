@@ -433,11 +433,16 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     hdr[0] = n;
     hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
     memcpy(s.pin + o_hdr + 64, &v, sizeof(v));   // the image's view, where sort_kp_kernel / pack_desc_kernel find it
-    int r = plain_blit(stream, s.pin, s.dev, o_desc / 4);
-    if (r < 0) return r;
-    // sort_kp_kernel needs the keypoints only: it runs while the host copies the 968 KB of rows into the shadow
+    // sort_kp_kernel needs the keypoints only: it runs while the host copies the 968 KB of rows into the shadow -- and it
+    // fetches them from the shadow itself (16 KB over PCIe), with the image's view in its arguments and the header words
+    // {n, bad} written on the way: the copy kernel that used to bring keypoints + header over first (7.6 us of the chain
+    // in front of every new image's pack kernel) is gone
+    int r;
     const ImageView* dview = reinterpret_cast<const ImageView*>(s.dev + o_hdr + 64);
-    if ((r = launch_sort_kp(stream, dview, 1, n > 0 ? n : 1)) < 0) return r;
+    KpImport imp{};
+    imp.src_kp = reinterpret_cast<const float2*>(s.pin); imp.n = n; imp.bad0 = hdr[1];
+    imp.view_dst = reinterpret_cast<ImageView*>(s.dev + o_hdr + 64); imp.view = v;
+    if ((r = launch_sort_kp(stream, dview, 1, n > 0 ? n : 1, nullptr, 0, nullptr, &imp)) < 0) return r;
     // (the rows in two halves, the first packed while the second is copied: two more launches on the host for 6 us less of
     // the GPU's chain -- 2 356 against 2 337 frames/s, inside the noise; not kept)
     big_copy(s.pin + o_desc, d, db);

@@ -38,10 +38,12 @@ def F(oracle):
 
 
 # ------------------------------------------------------------------ matcher
-@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 3), (63, 64), (64, 65), (65, 63), (300, 280), (1000, 900)])
+# (2048 / 2049 / 3000: either side of what sort_kp_kernel keeps in registers per thread -- the plain family's images come to it
+# straight from pinned host memory, keypoints past that share are copied first and walked from device memory)
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 3), (63, 64), (64, 65), (65, 63), (300, 280), (1000, 900), (2048, 2049), (3000, 2100)])
 def test_match_desc_bit_exact(viso, oracle, F, n1, n2):
     rng = np.random.default_rng(n1 * 1000 + n2)
-    kp1, kp2, d1, d2 = rand_problem(rng, n1, n2)
+    kp1, kp2, d1, d2 = rand_problem(rng, n1, n2) if n1 < 2000 else rand_problem(rng, n1, n2, width=1241, height=376)
     for mp in (MatchParams.temporal(), MatchParams.stereo(F)):
         got = libviso_amd.match_desc(kp1, kp2, d1, d2, mp)
         want = oracle.match_desc(kp1, kp2, d1, d2, mp)
@@ -339,7 +341,7 @@ def test_batch_full_pipeline_vs_oracle_sequence(viso, oracle, seq_small):
         assert ok[1:].all()
         for t in range(1, nf):
             assert rel_fro(libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])) < POSE_TOL
-            assert np.abs(tr[t] - s["tr_gt"][t]).max() < 2e-2
+            assert np.abs(tr[t] - s["tr_gt"][t]).max() < 3e-2   # sanity against the scene's motion (which triples are drawn moves it by ~1e-2)
     # circle join == literal nested loops on the match lists
     for t in (1, nf - 1):
         r, circ, pcl, n = oracle.match_circle(b.matches(0, t), b.matches(0, t - 1), b.matches(1, t), b.matches(2, t))
