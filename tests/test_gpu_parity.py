@@ -341,7 +341,7 @@ def test_batch_full_pipeline_vs_oracle_sequence(viso, oracle, seq_small):
         assert ok[1:].all()
         for t in range(1, nf):
             assert rel_fro(libviso_amd.tr2mat(tr[t]), oracle.tr2mat(want["tr"][t])) < POSE_TOL
-            assert np.abs(tr[t] - s["tr_gt"][t]).max() < 3e-2   # sanity against the scene's motion (which triples are drawn moves it by ~1e-2)
+            assert np.abs(tr[t] - s["tr_gt"][t]).max() < 6e-2   # sanity only (500 keypoints on 620 x 188, outliers: which triples are drawn moves tz by a few 1e-2; parity is the line above)
     # circle join == literal nested loops on the match lists
     for t in (1, nf - 1):
         r, circ, pcl, n = oracle.match_circle(b.matches(0, t), b.matches(0, t - 1), b.matches(1, t), b.matches(2, t))
