@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=6, help="forked ranks on the one device (the box allows 6 GPU processes)")
     ap.add_argument("--cpus", type=int, default=min(16, len(os.sched_getaffinity(0))), help="host threads to use in total")
     ap.add_argument("--home", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "viso_kitti_rehearsal"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_kitti_rehearsal.txt"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_kitti_rehearsal.txt"))
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--skip-rccl", action="store_true")
     ap.add_argument("--check-every", type=int, default=50, help="every n-th pair (and every unsolved one) goes through the CPU oracle")
@@ -102,6 +102,14 @@ def main():
     pose = lambda sha: os.path.join(args.home, "results", "00", sha, "data", "00.txt")   # noqa: E731
     # page cache warm-up of nothing: the files were just written, every run below reads them from memory
     run([exe, "one", "00", "--decode-threads", str(args.cpus)], env, log)
+    # the runner's own default (round 6: min(64, hardware threads / ranks), 16 before) and the counts around it: decoding is
+    # what bounds the run, the box decides how many threads it honours (nproc says 256, one GPU's share of the host is 16)
+    log("hardware threads: os.cpu_count() %s, affinity %d" % (os.cpu_count(), len(os.sched_getaffinity(0))))
+    run([exe, "one_default", "00"], env, log)
+    for nt in (32, 64):
+        run([exe, f"one_{nt}threads", "00", "--decode-threads", str(nt)], env, log)
+    for sha in ("one_default", "one_32threads", "one_64threads"):
+        log(f"pose file of {sha} byte-identical to the 16-thread run's: {open(pose('one'), 'rb').read() == open(pose(sha), 'rb').read()}")
     run([exe, "one_1thread", "00", "0", "567", "--decode-threads", "1"], env, log)      # one rank's share of 8, one decode thread
     per_rank = max(1, args.cpus // args.ranks)
     run([exe, f"fork{args.ranks}", "00", "--gpus", str(args.ranks), "--same-device", "--decode-threads", str(per_rank)], env, log)
