@@ -25,6 +25,12 @@
 #include "../../include/viso_hip.h"
 
 namespace viso {
+// Host threads this process may really use: the hardware's, cut down to the affinity mask and to the cgroup's CPU quota
+// (/sys/fs/cgroup/cpu.max).  A container that shows 256 hardware threads and is given 16 cores' worth of time runs 64 decode
+// threads no faster than 16 (KITTI rehearsal, profiles/r06_kitti_rehearsal.txt: 1.38 s with 16 threads, 1.41 s with 64, the
+// thread time 17 s -> 41 s): the runners size their decode pools from this.
+int cpu_budget();
+
 
 template <class T>
 struct Mat_ {

@@ -2,6 +2,11 @@
 // the C-ABI (include/viso_hip.h).  No arithmetic of the hot path happens here:
 // this file reshapes containers into the ABI's plain arrays and chains poses.
 #include "viso.hpp"
+#ifdef __linux__
+#include <sched.h>
+#endif
+#include <cstdio>
+#include <cstring>
 
 #include <algorithm>
 #include <atomic>
@@ -690,10 +695,31 @@ private:
 
 int default_decode_threads() {
     if (const char* e = std::getenv("VISO_DECODE_THREADS")) { const int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(64u, hw ? hw : 1u));   // decoding is what bounds a KITTI run (17.6 s of thread time against 0.06 s of kernels)
+    return std::max(1, std::min(64, cpu_budget()));   // decoding is what bounds a KITTI run (17.6 s of thread time against 0.06 s of kernels)
 }
 }  // namespace
+
+int cpu_budget() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+#ifdef __linux__
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[64] = "";
+            long long period = 0;
+            if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+                const long long quota = std::atoll(q);
+                if (quota > 0) { const int c = (int)((quota + period - 1) / period); if (c > 0 && c < n) n = c; }
+            }
+            std::fclose(f);
+        }
+    }
+#endif
+    return n;
+}
 
 // Chunks of `chunk` frames (plus the one-frame halo), two in flight: while the GPU runs chunk c (its own context,
 // asynchronous uploads from the slot's pinned buffer), the worker threads decode chunk c + 1 straight into the other

@@ -14,7 +14,7 @@
 //   --device d          HIP device ordinal of this process (default: the rank, 0 without --rank)
 //   --same-device       with --gpus: every rank on device 0 (rehearsal on a one-GPU box)
 //   --chunk n           frames per device batch (default 64)      --seed s   RANSAC stream seed (default 0)
-//   --decode-threads n  PNG decoding threads per rank (default: min(64, hardware threads / ranks): decoding bounds the run)
+//   --decode-threads n  PNG decoding threads per rank (default: min(64, usable host threads / ranks): decoding bounds the run; usable = hardware, affinity, cgroup quota)
 //   --reference-pose-list   write the list the reference's code actually produces, [P1, ..., Pn, Pn] (src/viso.cpp:1317-1321
 //                       overwrites poses.back() before pushing the clone), instead of [I, P1, ..., Pn]
 // Every rank reports where its wall time went: decode (PNG inflate on the worker threads; the calling thread's wait for
@@ -89,8 +89,7 @@ void print_stats(const char* who, const viso::OdometryStats& s) {
 }
 
 int threads_per_rank(int ranks) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int share = (int)(hw ? hw : 1) / (ranks > 0 ? ranks : 1);
+    const int share = viso::cpu_budget() / (ranks > 0 ? ranks : 1);   // hardware threads, affinity and cgroup quota
     return share < 1 ? 1 : (share > 64 ? 64 : share);
 }
 }  // namespace

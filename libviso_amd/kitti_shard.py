@@ -69,6 +69,23 @@ def load_host():
     return L
 
 
+def cpu_budget():
+    """Host threads this process may really use: hardware threads cut down to the affinity mask and the cgroup's CPU quota
+    (the C++ runner's viso::cpu_budget, host/viso_host.cpp)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 STAT_NAMES = ("frames", "decode_threads", "wall_s", "decode_wait_s", "decode_cpu_s", "issue_s", "drain_wait_s", "upload_ms", "gpu_ms")
 
 
@@ -243,7 +260,7 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
     L = load_host()
-    threads = args.decode_threads or int(os.environ.get("VISO_DECODE_THREADS", "0")) or max(1, min(64, (os.cpu_count() or 1) // world))
+    threads = args.decode_threads or int(os.environ.get("VISO_DECODE_THREADS", "0")) or max(1, min(64, cpu_budget() // world))
     L.viso_kitti_set_decode_threads(threads)
 
     def die(code, what):

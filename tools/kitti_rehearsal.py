@@ -104,7 +104,12 @@ def main():
     run([exe, "one", "00", "--decode-threads", str(args.cpus)], env, log)
     # the runner's own default (round 6: min(64, hardware threads / ranks), 16 before) and the counts around it: decoding is
     # what bounds the run, the box decides how many threads it honours (nproc says 256, one GPU's share of the host is 16)
-    log("hardware threads: os.cpu_count() %s, affinity %d" % (os.cpu_count(), len(os.sched_getaffinity(0))))
+    try:
+        cg = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        cg = "(no /sys/fs/cgroup/cpu.max)"
+    from libviso_amd.kitti_shard import cpu_budget
+    log("hardware threads: os.cpu_count() %s, affinity %d, cgroup cpu.max '%s' -> the runners' budget %d" % (os.cpu_count(), len(os.sched_getaffinity(0)), cg, cpu_budget()))
     run([exe, "one_default", "00"], env, log)
     for nt in (32, 64):
         run([exe, f"one_{nt}threads", "00", "--decode-threads", str(nt)], env, log)
