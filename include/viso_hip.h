@@ -186,8 +186,13 @@ int viso_support_sizes(const double* X3xM, const double* obs4xM, int m, const do
                        const viso_param* p, int32_t* cnt);
 
 /* Deterministic replacement for randomsample's per-call random_device
- * (src/viso.cpp:87-107): selection sampling (same algorithm) driven by a
- * splitmix64 stream keyed on (seed, frame, hypothesis).  out: iters x 3. */
+ * (src/viso.cpp:87-107: a uniformly distributed 3-subset of 0..m-1, ascending).
+ * Triple h = the first three outputs of a splitmix64 stream keyed on
+ * (seed, frame, h) through Floyd's subset sampling -- t_i = floor(draw_i * (j+1) / 2^64)
+ * for j = m-3, m-2, m-1, taken, or j itself if t_i was taken already -- sorted
+ * ascending: the same distribution in three draws (the reference's algorithm S
+ * needs ~m/2; rounds 1-5 ran it over the same stream: other triples, same law).
+ * m < 3: zeros.  out: iters x 3. */
 void viso_ransac_samples(uint64_t seed, uint64_t frame, int iters, int m, int32_t* out);
 
 /* tr2mat, src/viso.cpp:109-133. T: 4x4 row-major. Host arithmetic (six
