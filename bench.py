@@ -69,7 +69,7 @@ CLK_GHZ = 2.4                  # max clock
 VALU_CYCLES_FULL = 2
 VALU_CYCLES_SAD = 4
 L2_REQ_BYTES = 128             # TCP_TCC_READ_REQ: one 128-B line per request (r01: 35.3 M requests for 4.6 GB of row gathers)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 GATHER_KERNELS = ("match_union_kernel", "match_union8_kernel")   # rows gathered from the XCD's L2 by index
 
 

@@ -1,7 +1,7 @@
 # rocprofv3 evidence for the image-in legs: per-kernel durations with ONE batch in flight and the two
 # HBM-traffic counter passes, of `python3 bench.py --no-cpu --no-streaming --no-e2e` (resident uint8 images -> [binned
 # Harris] -> descriptors -> matcher -> solver; the program directly behind `--`)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 Q="--streams 1 --e2e-streams 1 --no-cpu --no-streaming --no-e2e --no-i16 --steps 12 --warmup 2 --min-region-seconds 0"
 rocprofv3 --kernel-trace --stats -d gpurun_out/img_stats -o s --output-format csv -- python3 bench.py $Q > gpurun_out/img_stats_bench.json 2>gpurun_out/img_stats.err &&

@@ -1,6 +1,6 @@
 # SQ / TA / TCP counter passes over the default matcher workload, one stream (bench.py, matcher only):
 #   gpurun -- 'bash tools/pmc_batch.sh [tag]'   ->  gpurun_out/<tag>_pmc_sq.json (per-kernel averages)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --streams 1 --no-cpu --no-e2e --no-streaming --no-images --no-i16 --steps 3 --warmup 1 --min-region-seconds 0 $VISO_BENCH_EXTRA"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d gpurun_out/pmcb1 -o p --output-format csv -- $B > /dev/null 2>gpurun_out/pmcb1.err &&

@@ -2,7 +2,7 @@
 # tools/profile_all.sh [tag]: everything profiles/<tag>_* is made of, in ONE gpurun call (about ten minutes of GPU time):
 # kernel stats (3 streams / 1 stream), HBM and SQ counter passes, the full pipeline's kernel stats, the image legs, and the
 # bench lines (default with CPU baseline, RCCL group of one, clustered, configs[4] geometry).  Results: gpurun_out/<tag>_*
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1 && echo "profile_round ok" &&
 bash tools/pmc_batch.sh $TAG > gpurun_out/${TAG}_pmc_batch.log 2>&1 && echo "pmc_batch ok" &&

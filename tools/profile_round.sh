@@ -3,7 +3,7 @@
 #   2. kernel-trace stats of the same workload with ONE stream: per-kernel averages that fit inside the step
 #   3./4. the two HBM-traffic counter passes (separate runs, one stream)
 # then: python3 tools/pmc_to_json.py gpurun_out/prof_fetch gpurun_out/prof_write <kernel> > profiles/<round>_pmc_hbm.json
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 Q="--no-cpu --no-e2e --no-streaming --no-images --no-i16"   # matcher step only (--no-e2e also leaves the drop-in leg out)
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o s --output-format csv -- python3 bench.py --no-cpu --no-streaming --no-images --no-i16 --no-drop-in > gpurun_out/prof_stats_bench.json 2>gpurun_out/prof_stats.err &&
