@@ -58,8 +58,13 @@ def test_host_entry_points_match_oracle(L, oracle):
     assert np.allclose(F, Fo, rtol=1e-9, atol=1e-9)
     P1 = np.hstack([np.eye(3), np.zeros((3, 1))]); P2 = P1.copy(); P2[0, 3] = 1
     assert np.array_equal(libviso_amd.F_from_P(P1, P2), np.array([[0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]))
-    for m in (3, 10, 500):
-        assert np.array_equal(libviso_amd.ransac_samples(42, 7, 50, m), oracle.ransac_samples(42, 7, 50, m))
+    # the host twin of the device's sampler (viso_sample3, csrc/solver_dev.h: the code ransac_hyp_kernel runs per lane) against
+    # the oracle's: the same integers for every point count, seed and stream key (64-bit keys included)
+    for m in (0, 2, 3, 4, 5, 10, 63, 64, 65, 500, 2047, 16384):
+        for seed, frame in ((42, 7), (0, 0), (2**63 + 11, 2**40 + 3), (2**64 - 1, 2**64 - 1)):
+            assert np.array_equal(libviso_amd.ransac_samples(seed, frame, 50, m), oracle.ransac_samples(seed, frame, 50, m)), (m, seed, frame)
+    s = libviso_amd.ransac_samples(1, 2, 2000, 7)
+    assert (s[:, 0] < s[:, 1]).all() and (s[:, 1] < s[:, 2]).all() and s.min() == 0 and s.max() == 6
 
 
 def test_argument_errors_do_not_abort(L):

@@ -315,7 +315,8 @@ def test_best_tr_is_in_out_like_the_references(viso, oracle):
         assert not np.array_equal(tr_o, tr0) and np.allclose(tr_a, tr_o, rtol=0, atol=1e-9)
 
 
-def test_every_hypothesis_against_the_oracle(viso, oracle):
+@pytest.mark.parametrize("case", ["outlier_rich", "few_matches"])
+def test_every_hypothesis_against_the_oracle(viso, oracle, case):
     """The RANSAC stage hypothesis by hypothesis (src/viso.cpp:1555-1568): for every frame of an outlier-rich sequence and
     every sample triple, the device's verdict (ok_h), motion (tr_h) and support size (cnt_h) against
     oracle.minimize_reproj + oracle.get_inliers on the same triple.  A hypothesis the oracle DECIDES within 20 iterations
@@ -325,14 +326,17 @@ def test_every_hypothesis_against_the_oracle(viso, oracle):
     tools/experiments/sincos_parity.hip) decides where the iteration goes; the reference never reads their motion unless
     they converge, and their share that differs is reported and bounded.  (This is the comparison that found the cause
     of the two fuzz asserts loosened in round 5; tests/batch_fuzz.py and tests/api_fuzz.py point here.)"""
-    seq = synth.make_sequence(303, 17, n_kp=900, width=900, height=300, outlier_frac=0.35, noise_sigma=9.0)
+    if case == "outlier_rich":
+        seq = synth.make_sequence(303, 17, n_kp=900, width=900, height=300, outlier_frac=0.35, noise_sigma=9.0)
+    else:   # a few dozen circle matches per frame, half of the keypoints outliers: 3-point sets without a motion, the wanderers' home
+        seq = synth.make_sequence(404, 25, n_kp=90, width=400, height=160, outlier_frac=0.5, noise_sigma=12.0)
     st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
     param = seq["param"]
     iters = param.ransac_iter
     kp, desc, n = seq["kp"], seq["desc"], seq["n"]
-    nf = kp.shape[0]
+    nf, cap = kp.shape[0], kp.shape[2]
     ctx = libviso_amd.Context(0)
-    b = libviso_amd.Batch(ctx, nf, 900)
+    b = libviso_amd.Batch(ctx, nf, cap)
     b.upload(kp, desc, n)
     b.set_params(st, tm, param, seed=11, first_frame=40)
     b.run()
@@ -371,5 +375,5 @@ def test_every_hypothesis_against_the_oracle(viso, oracle):
     total = decided + wander
     print("hypotheses: %d decided by the oracle within 20 iterations (worst |tr - tr_oracle| %.3g), %d later or never, "
           "%d of those differ (%.2f %% of all)" % (decided, worst, wander, wander_diff, 100.0 * wander_diff / max(total, 1)))
-    assert total >= 12 * iters and decided >= 0.8 * total
+    assert total >= 12 * iters and decided >= 0.5 * total
     assert wander_diff <= 0.02 * total, (wander_diff, wander, total)
