@@ -111,13 +111,16 @@ extern "C" int viso_batch_destroy(viso_batch* b) {
     // (the context left a tombstone for it); anything else -- a second destroy, a pointer that never was a batch -- is an
     // argument error, never a dereference
     const int st = viso_batch_unregister(b);
-    if (st == 0) return VISO_OK;
+    if (st == 0) { delete b; return VISO_OK; }   // the shell its context left behind (viso_batch_free(b, true)): nothing else to free
     if (st < 0) { viso_set_error("viso_batch_destroy: not a live batch handle"); return VISO_ERR_ARG; }
-    return viso_batch_free(b);
+    return viso_batch_free(b, false);
 }
 
 // Frees a batch that has left the registry (viso_batch_destroy, or viso_ctx_destroy for the batches still alive on it).
-int viso_batch_free(viso_batch* b) {
+// keep_shell (viso_ctx_destroy): everything the batch owns goes, the small host object itself stays allocated until the caller's
+// own viso_batch_destroy -- a freed address could be handed to ANOTHER batch (of another thread) meanwhile, and the late
+// destroy this library promises to tolerate would then hit that one.
+int viso_batch_free(viso_batch* b, bool keep_shell) {
     hipError_t first = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     note(hipSetDevice(b->ctx->device));
@@ -137,7 +140,8 @@ int viso_batch_free(viso_batch* b) {
                     b->pos, b->m_cnt, b->scored, b->x_c, b->Xp_c, b->join,
                     b->sitems, b->circ, b->pcl, b->mc, b->tr /* + ok, n_inl */, b->inl, b->tr_h, b->ok_h, b->cnt_h, b->hq, b->samp_h, b->rot, b->tile_flag, b->qord, b->ovf_q};
     for (void* p : ptrs) if (p) note(hipFree(p));
-    delete b;
+    if (keep_shell) { b->ctx = nullptr; b->events.clear(); b->desc_family.clear(); b->desc_family.shrink_to_fit(); }
+    else delete b;
     if (first != hipSuccess) { viso_set_error("viso_batch_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
     return VISO_OK;
 }
@@ -301,15 +305,15 @@ extern "C" viso_batch* viso_batch_create(viso_ctx* ctx, int n_frames, int cap, i
     }
     for (int k = 0; r >= 0 && k < VISO_NPIN_SLOTS; ++k)
         if (hipEventCreateWithFlags(&b->n_pin_ev[k], hipEventDisableTiming) != hipSuccess) { b->n_pin_ev[k] = nullptr; r = VISO_ERR_HIP; }
-    if (r < 0) { viso_batch_free(b); return nullptr; }
+    if (r < 0) { viso_batch_free(b, false); return nullptr; }
     bool ok = hipMemset(b->zero, 0, 8 * sizeof(int)) == hipSuccess &&
               hipMemset(b->n, 0, nf * 2 * sizeof(int)) == hipSuccess &&
               hipMemset(b->m_cnt, 0, 3 * nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->mc, 0, nf * sizeof(int)) == hipSuccess &&
               hipMemset(b->tr, 0, b->pose_bytes) == hipSuccess &&
               hipMemset(b->scored, 0, b->zeroed_bytes) == hipSuccess;
-    if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_free(b); return nullptr; }
-    if (!viso_batch_register(ctx, b)) { viso_set_error("viso_batch_create: the context was destroyed meanwhile"); viso_batch_free(b); return nullptr; }
+    if (!ok || build_items(b) < 0) { viso_set_error("viso_batch_create: device initialisation failed"); viso_batch_free(b, false); return nullptr; }
+    if (!viso_batch_register(ctx, b)) { viso_set_error("viso_batch_create: the context was destroyed meanwhile"); viso_batch_free(b, false); return nullptr; }
     return b;
 }
 

@@ -128,7 +128,7 @@ bool viso_ctx_live(const viso_ctx* c);
 bool viso_batch_live(const viso_batch* b);
 bool viso_batch_register(viso_ctx* c, viso_batch* b);   // false: the context is not live
 int viso_batch_unregister(viso_batch* b);               // 1 live (now the caller's to free), 0 tombstone (consumed), -1 unknown
-int viso_batch_free(viso_batch* b);                     // batch.hip: frees a batch that has left the registry
+int viso_batch_free(viso_batch* b, bool keep_shell);    // batch.hip: frees a batch that has left the registry (keep_shell: the host object stays for the caller's late destroy)
 
 struct PlainLock { PlainLock(); ~PlainLock(); };   // serialises the plain family on the default context
 // viso_plain_profile: phases of one plain-family call, bracketed by four events on the call's stream (ctx.hip).  Used

@@ -28,8 +28,9 @@ extern "C" const char* viso_version(void) { return "libviso_hip 0.1 (gfx950, HIP
 // (std::bad_variant_access inside hipStreamSynchronize: an abort).  The library therefore knows its live handles: a context
 // keeps the list of the batches created on it; viso_ctx_destroy frees those that are still alive FIRST and leaves a
 // tombstone per batch, so that the caller's later viso_batch_destroy is a no-op (VISO_OK) and any other call on such a handle
-// -- or on a handle that never existed, or was destroyed twice -- returns VISO_ERR_ARG.  A tombstone goes away when the
-// caller destroys the handle or when the allocator hands the address out again.
+// -- or on a handle that never existed, or was destroyed twice -- returns VISO_ERR_ARG.  A tombstoned batch keeps its small
+// host object (everything it owned is freed) until the caller's own destroy deletes it: its address cannot be handed to
+// another batch meanwhile, so the late destroy can never hit somebody else's handle.
 static std::mutex g_reg_mu;
 static std::unordered_map<const viso_ctx*, std::vector<viso_batch*>> g_ctx_batches;   // the live contexts and their live batches
 static std::unordered_map<const viso_batch*, viso_ctx*> g_batch_ctx;                  // the live batches
@@ -123,7 +124,7 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
     hipError_t first = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
     bool batch_err = false;
-    for (viso_batch* b : orphans) if (viso_batch_free(b) < 0) batch_err = true;   // while the context's streams still exist
+    for (viso_batch* b : orphans) if (viso_batch_free(b, true) < 0) batch_err = true;   // while the context's streams still exist; their shells stay
     note(hipSetDevice(c->device));
     note(hipStreamSynchronize(c->stream));
     if (c->solver_stream) { note(hipStreamSynchronize(c->solver_stream)); note(hipStreamDestroy(c->solver_stream)); }

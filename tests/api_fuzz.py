@@ -117,8 +117,16 @@ def fuzz_solver(rng, L, O, synth):
             what += " | minimize_reproj on %d points: %d / %d, tr %s / %s" % (len(act), r0, r1, t0, t1)
         ok = ok and ok_m
         seed, frame = int(rng.integers(0, 1000)), int(rng.integers(0, 5000))
-        a, b = O.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame), L.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame)
+        # best_tr is in/out (src/viso.cpp:1564-1568): a random start value must come back untouched wherever no hypothesis finds
+        # support -- on both sides, in every kind of case
+        tr0 = rng.normal(0, 1, 6)
+        a, b = O.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame, tr0=tr0), L.ransac_minimize_reproj(X, obs, param, seed=seed, frame=frame, tr0=tr0)
         ok_r = not posed or (a[0] == b[0] and (not a[0] or (_close(L, a[1], b[1]) and _same(a[2], b[2]))))
+        for r in (a, b):
+            if r[0] == 0 and len(r[2]) == 0:
+                ok_r = ok_r and bool(np.array_equal(np.asarray(r[1]).view(np.int64), tr0.view(np.int64)))
+        if posed and a[0] == 0 and len(a[2]) == 0:
+            ok_r = ok_r and b[0] == 0 and len(b[2]) == 0
         if not ok_r:
             what += " | ransac seed %d frame %d: ok %d / %d, inliers %d / %d, tr %s / %s" % (seed, frame, a[0], b[0], len(a[2]), len(b[2]), a[1], b[1])
         ok = ok and ok_r

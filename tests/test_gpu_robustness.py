@@ -244,6 +244,58 @@ def test_raw_handles_destroyed_in_the_wrong_order_get_return_codes(viso, oracle)
     b.close(); ctx.close()
 
 
+def test_handles_from_several_threads_in_any_order(viso):
+    """The handle registry under concurrency: four threads create contexts and batches, run a matcher step, and destroy
+    every handle exactly ONCE in a random order -- the context often before its batches.  Every destroy returns VISO_OK
+    (a batch its context took along: the no-op), a getter on a batch whose context is gone returns VISO_ERR_ARG, nothing
+    crashes.  (Destroying a handle TWICE is an error the registry catches only until the allocator hands the address out
+    again -- to another thread here: that case is the single-threaded test above.)"""
+    import ctypes as C
+    import threading
+    from libviso_amd.abi import ptr
+    L = viso
+    errors = []
+    seq = synth.make_sequence(3, 3, n_kp=150, width=300, height=150)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    kp, desc, n = (np.ascontiguousarray(seq[k]) for k in ("kp", "desc", "n"))
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(6):
+                c = L.viso_ctx_create(0, None)
+                assert c
+                bs = [L.viso_batch_create(c, 3, 150, 121) for _ in range(int(rng.integers(1, 4)))]
+                assert all(bs)
+                assert L.viso_batch_upload(bs[0], 0, 3, ptr(kp, C.c_float), ptr(desc, C.c_float), ptr(n, C.c_int32)) == 1
+                assert L.viso_batch_set_params(bs[0], C.byref(st), C.byref(tm), C.byref(seq["param"]), 1, 0) == 1
+                assert L.viso_batch_run(bs[0]) == 1            # in flight while handles go
+                order = list(bs) + [("ctx", c)]
+                rng.shuffle(order)
+                ctx_dead = False
+                for h in order:
+                    if isinstance(h, tuple):
+                        assert L.viso_ctx_destroy(h[1]) == 1
+                        ctx_dead = True
+                    else:
+                        if ctx_dead:
+                            cnt = C.c_int32(0)
+                            assert L.viso_batch_get_overflow_count(h, C.byref(cnt)) == -1
+                        assert L.viso_batch_destroy(h) == 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    ctx = libviso_amd.Context(0)
+    b = libviso_amd.Batch(ctx, 2, 64)
+    b.close(); ctx.close()
+
+
 def test_hypotheses_getter_with_a_wider_capacity(viso):
     """viso_batch_get_hypotheses2 with arrays of [n_frames][capacity > ransac_iter]: every frame's row at the caller's stride
     (the first version forwarded to the tight getter and put frame 1's row where frame 0's padding belonged)."""
