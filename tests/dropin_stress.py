@@ -1,8 +1,8 @@
 """One-off stress of the per-call loop (GPU box): 240 frames whose keypoint counts jump between 0 and 1400 (frame blocks and
 image slots re-laid out again and again), every cache / speculation mode, ok / inlier counts / poses against the oracle.
 Test infrastructure (imports oracle/): lives under tests/; not collected by pytest.  python tests/dropin_stress.py"""
-import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # the tree this file lives in
 import libviso_amd
 from libviso_amd import synth, drop_in
 from libviso_amd.abi import MatchParams
