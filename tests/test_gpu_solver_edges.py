@@ -320,8 +320,9 @@ def test_every_hypothesis_against_the_oracle(viso, oracle, case):
     """The RANSAC stage hypothesis by hypothesis (src/viso.cpp:1555-1568): for every frame of an outlier-rich sequence and
     every sample triple, the device's verdict (ok_h), motion (tr_h) and support size (cnt_h) against
     oracle.minimize_reproj + oracle.get_inliers on the same triple.  A hypothesis the oracle DECIDES within 20 iterations
-    (converged, or left through the singular exit :1605) must agree exactly in verdict and support and to 1e-9 in the
-    motion.  The others are the wanderers: 3-point solves without a consistent motion that run on through rotations of
+    (converged, or left through the singular exit :1605) on three DISTINCT 3-D points must agree exactly in verdict and
+    support and to 1e-9 in the motion.  The others are the wanderers (and the triples with twin points: normal matrices of
+    condition 1e18, tools/experiments/stress_diag.py): 3-point solves without a consistent motion that run on through rotations of
     thousands of radians, where the one-ulp difference between the device's sincos and glibc's (3 % of arguments,
     tools/experiments/sincos_parity.hip) decides where the iteration goes; the reference never reads their motion unless
     they converge, and their share that differs is reported and bounded.  (This is the comparison that found the cause
@@ -359,7 +360,9 @@ def test_every_hypothesis_against_the_oracle(viso, oracle, case):
             ok0, tr0, it0 = oracle.minimize_reproj(X, obs, np.zeros(6), param, S[h].astype(np.int32))
             c0 = len(oracle.get_inliers(X, obs, tr0, param)[0]) if ok0 else 0
             c1 = int(cnt_h[t, h]) if ok_h[t, h] else 0
-            if it0 <= 20:
+            P3 = X[:, S[h]]
+            twin = bool((P3[:, 0] == P3[:, 1]).all() or (P3[:, 0] == P3[:, 2]).all() or (P3[:, 1] == P3[:, 2]).all())
+            if it0 <= 20 and not twin:   # (two circle matches can share a previous-frame point: a triple with twins is a singular system)
                 decided += 1
                 assert ok_h[t, h] == ok0, (t, h, S[h], it0)
                 if ok0:
