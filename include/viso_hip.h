@@ -254,6 +254,9 @@ typedef struct viso_plain_times {
  *                  byte for byte what was assumed (the functions are pure: same results as the direct path, which any
  *                  other argument takes).  Guessing starts after the call sequence has been seen once and stops when a
  *                  guess goes unused.  viso_plain_speculate(0) / $VISO_PLAIN_SPECULATE=0: every call direct.
+ *   waiting        a call returns when its results are in pinned host memory: its last kernel says so in a pinned word the
+ *                  host spins on (a few microseconds sooner than hipStreamSynchronize sees it; after 20 ms the stream is
+ *                  synchronised instead).  $VISO_PLAIN_SIGNAL=0: always hipStreamSynchronize.
  * Both only change when the work is done, never a result (tests/test_gpu_drop_in.py runs every combination).  The
  * speculation statistics: served[0..3] = calls answered from a frame (temporal match_desc, collect_matches,
  * triangulate_rectified + match_circle, ransac_minimize_reproj), wasted[0..3] = results computed ahead and never asked for. */

@@ -326,9 +326,11 @@ extern "C" int viso_match_circle(const int32_t* lr, int n_lr, const int32_t* lr_
     if ((r = launch_circle_table(c->stream, a, dtab, tabn)) < 0) return r;
     pp.mark(2);
     // the rows that exist (the count is on the device), by a copy kernel into pinned memory
-    if ((r = plain_blit(c->stream, dout, hout, 64, a.out_n, 6, cap)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, 64, a.out_n, 6, cap, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     const int cnt = *reinterpret_cast<const int*>(hout);
     const int w = cnt < cap ? cnt : cap;
     pp.wait_end();
@@ -383,9 +385,11 @@ extern "C" int viso_collect_matches(const float* kp1, int n1, const float* kp2, 
     SolverParamsDev sp{};
     if ((r = launch_collect_triangulate(c->stream, dit, 1, sp, n)) < 0) return r;
     pp.mark(2);
-    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4, nullptr, 0, 0, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();
     memcpy(x, hout, out_bytes);
     pp.mark(3);
@@ -416,9 +420,11 @@ extern "C" int viso_triangulate_rectified(const double* x, int m, const viso_par
     hipLaunchKernelGGL(triangulate_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dx, m, sp, reinterpret_cast<double*>(dout));
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, out_bytes / 4, nullptr, 0, 0, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();
     memcpy(X, hout, out_bytes);
     pp.mark(3);

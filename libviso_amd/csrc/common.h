@@ -120,6 +120,9 @@ struct viso_ctx {
     char* pin[2];
     size_t pin_bytes[2];
     struct PlainCache* plain;    // the plain family's image cache (plain.hip), created on first use
+    // completion signal of the plain family's calls (PlainSignal below): a word of pinned memory the call's LAST kernel writes,
+    // a device counter of that kernel's finished workgroups, the sequence number of the last signal asked for
+    int* sig_flag; int* sig_ctr; int sig_seq;
 };
 
 // handle registry (ctx.hip): the live contexts, the live batches of each, tombstones of batches their context took along
@@ -194,7 +197,17 @@ struct PlainStage {
 };
 // words = 32-bit units.  dst[0..head) = src[0..head), then min(*n_rows, max_rows) rows of row_words behind them (n_rows
 // may be null: head only).  Either side may be pinned host memory.
-int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows = nullptr, int row_words = 0, int max_rows = 0);
+// A plain-family call returns when its results are in pinned host memory.  hipStreamSynchronize sees that ~5 us after the
+// fact (an empty kernel + synchronize: 10.9 us; the same kernel writing a word of pinned memory that the host spins on:
+// 6.2 us -- tools/h2d_probe.hip).  So the call's LAST kernel -- a copy kernel into pinned memory -- signals itself: every thread
+// fences its stores at system scope, the last workgroup to finish (a device counter) release-stores the call's sequence
+// number into a pinned word, and the host spins on that word with an acquire load (plain_signal_wait: bounded, then
+// hipStreamSynchronize as the fallback, so a lost signal costs time, never a hang or a result).
+struct PlainSignal { int* ctr; int* flag; int seq; };   // flag == nullptr: no signal
+int plain_signal_next(viso_ctx* c, PlainSignal* out);   // the next sequence number of the context (allocates on first use)
+int plain_signal_wait(viso_ctx* c, hipStream_t s, int seq);
+int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows = nullptr, int row_words = 0, int max_rows = 0,
+               const PlainSignal* sig = nullptr);
 
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)

@@ -131,6 +131,8 @@ extern "C" int viso_ctx_destroy(viso_ctx* c) {
     plain_cache_free(c);
     for (int i = 0; i < 24; ++i) if (c->scratch[i]) note(hipFree(c->scratch[i]));
     for (int i = 0; i < 2; ++i) if (c->pin[i]) note(hipHostFree(c->pin[i]));
+    if (c->sig_flag) note(hipHostFree(c->sig_flag));
+    if (c->sig_ctr) note(hipFree(c->sig_ctr));
     if (c->own_stream) note(hipStreamDestroy(c->stream));
     delete c;
     if (first != hipSuccess) { viso_set_error("viso_ctx_destroy: %s", hipGetErrorString(first)); return VISO_ERR_HIP; }
@@ -242,7 +244,7 @@ int ctx_pinned(viso_ctx* c, int which, size_t bytes, char** out) {
         c->pin[which] = nullptr;
         c->pin_bytes[which] = 0;
         const size_t want = bytes + bytes / 2;
-        HIP_TRY(hipHostMalloc((void**)&c->pin[which], want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&c->pin[which], want, hipHostMallocCoherent));   // results are read right behind the call's signal (PlainSignal)
         c->pin_bytes[which] = want;
     }
     *out = c->pin[which];

@@ -188,8 +188,10 @@ struct PlainFrame {
     bool have_B, pending_B, used_circ, used_rs;
     int n_circ;                            // rows of the join (host, once B has been waited for)
     viso_param rs_p; uint64_t rs_seed, rs_frame;
-    hipEvent_t evA;                        // behind the first part's copy-out
-    hipEvent_t evJ;                        // behind the join's copy-out (match_circle waits for this one only; the RANSAC stage runs on)
+    hipEvent_t evA;                        // (events of round 5's waits: the copy-out kernels signal themselves now, PlainSignal)
+    hipEvent_t evJ;
+    int seqJ, seqB;                        // sequence numbers of the join's copy-out (match_circle waits for this one only; the RANSAC
+                                           // stage runs on) and of the RANSAC stage's copy-out
     bool pending_J;
 };
 struct PlainCache {
@@ -217,9 +219,53 @@ struct PlainCache {
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
 
+// ---- the completion signal (common.h, PlainSignal) ------------------------------------------------------------------------
+// Called by EVERY thread of the kernel's every workgroup, behind its last store.
+__device__ __forceinline__ void plain_signal_done(const PlainSignal& g, unsigned nblocks) {
+    if (!g.flag) return;                       // uniform
+    __threadfence_system();                    // this thread's stores (to pinned host memory) are out, system scope
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(g.ctr, 1) == (int)nblocks - 1) {   // the last workgroup of the launch: every other one has fenced and counted
+            __threadfence_system();                      // (acquire side of the counter: what the others fenced is ordered before the flag)
+            *g.ctr = 0;                                  // for the next signalling kernel (streams run them one after the other)
+            __hip_atomic_store(g.flag, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+int plain_signal_next(viso_ctx* c, PlainSignal* out) {
+    if (!c->sig_flag) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipHostMalloc((void**)&c->sig_flag, 256, hipHostMallocCoherent));   // fine grained: the host polls it while the kernel runs
+        memset(c->sig_flag, 0, 256);
+        HIP_TRY(hipMalloc((void**)&c->sig_ctr, 256));
+        HIP_TRY(hipMemsetAsync(c->sig_ctr, 0, 256, c->stream));
+        c->sig_seq = 0;
+    }
+    c->sig_seq += 1;
+    out->ctr = c->sig_ctr; out->flag = c->sig_flag; out->seq = c->sig_seq;
+    return VISO_OK;
+}
+
+int plain_signal_wait(viso_ctx* c, hipStream_t s, int seq) {
+    static const int off = [] { const char* e = getenv("VISO_PLAIN_SIGNAL"); return e && *e == '0'; }();   // 0: always hipStreamSynchronize (A/B aid)
+    if (c->sig_flag && !off) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 1;; ++spin) {
+            if ((int)((unsigned)__atomic_load_n(c->sig_flag, __ATOMIC_ACQUIRE) - (unsigned)seq) >= 0) return VISO_OK;
+            cpu_relax();
+            // a signal that does not come (a failed launch, a faulting kernel): the stream knows
+            if ((spin & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return VISO_OK;
+}
+
 // ---- copy kernels: small blocks between pinned host memory and the device without the copy engine ------------------
 __global__ __launch_bounds__(256) void plain_blit_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, unsigned head_words,
-                                                         const int* __restrict__ n_rows, int row_words, int max_rows) {
+                                                         const int* __restrict__ n_rows, int row_words, int max_rows, PlainSignal sig) {
     unsigned total = head_words;
     if (n_rows) {
         int n = *n_rows;
@@ -232,14 +278,18 @@ __global__ __launch_bounds__(256) void plain_blit_kernel(const uint32_t* __restr
         const unsigned j = i + 256u * k;
         if (j < total) dst[j] = src[j];
     }
+    plain_signal_done(sig, gridDim.x);
 }
 
-int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows, int row_words, int max_rows) {
-    const size_t total = head_words + (n_rows ? (size_t)max_rows * (size_t)row_words : 0);
+int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows, int row_words, int max_rows, const PlainSignal* sig) {
+    size_t total = head_words + (n_rows ? (size_t)max_rows * (size_t)row_words : 0);
+    if (total == 0 && sig) total = 1;   // a signal needs its kernel (the kernel copies nothing: its own bound is the device count)
     if (total == 0) return VISO_OK;
+    PlainSignal g{nullptr, nullptr, 0};
+    if (sig) g = *sig;
     if (total > 0x7fffffffu) { viso_set_error("plain_blit: block too large"); return VISO_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(plain_blit_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s,
-                       reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), (unsigned)head_words, n_rows, row_words, max_rows);
+                       reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), (unsigned)head_words, n_rows, row_words, max_rows, g);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -461,13 +511,14 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
 // ---- results out: every region's rows that exist (counts on the device) into the pinned mirror, ONE launch ----------
 struct OutRegion { const uint32_t* src; uint32_t* dst; const int* cnt; int row_words, max_rows; };
 #define OUT_REGIONS 24
-struct OutArgs { OutRegion r[OUT_REGIONS]; };
+struct OutArgs { OutRegion r[OUT_REGIONS]; PlainSignal sig; };
 __global__ __launch_bounds__(256) void plain_out_kernel(OutArgs a) {
     const OutRegion R = a.r[blockIdx.y];
     int n = R.max_rows;
     if (R.cnt) { const int c = *R.cnt; n = c < 0 ? 0 : c < n ? c : n; }
     const unsigned total = (unsigned)n * (unsigned)R.row_words;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) R.dst[i] = R.src[i];
+    plain_signal_done(a.sig, gridDim.x * gridDim.y);
 }
 
 static bool params_equal(const viso_match_params& a, const viso_match_params& b) {
@@ -523,7 +574,7 @@ static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
         if (f.host) HIP_TRY(hipHostFree(f.host));
         f.host = nullptr; f.host_bytes = 0;
         const size_t want = (f.o_end - f.o_misc) + (f.o_end - f.o_misc) / 4;
-        HIP_TRY(hipHostMalloc((void**)&f.host, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&f.host, want, hipHostMallocCoherent));   // read by the host right behind the signal, possibly before the kernel has retired
         f.host_bytes = want;
     }
     if (!f.evA) HIP_TRY(hipEventCreateWithFlags(&f.evA, hipEventDisableTiming));
@@ -541,9 +592,9 @@ static void frame_reset(PlainFrame& f) {
 }
 
 // the second part of a frame's chain has finished: its counters are in the mirror
-static int frame_wait_J(PlainFrame& f) {   // the join (and the gathered columns) are in the mirror
+static int frame_wait_J(viso_ctx* c, PlainFrame& f) {   // the join (and the gathered columns) are in the mirror
     if (!f.pending_J) return VISO_OK;
-    HIP_TRY(hipEventSynchronize(f.evJ));
+    { const int r_ = plain_signal_wait(c, c->stream, f.seqJ); if (r_ < 0) return r_; }
     f.pending_J = false;
     const int* om = reinterpret_cast<const int*>(f.host);
     f.n_circ = om[32];
@@ -551,7 +602,7 @@ static int frame_wait_J(PlainFrame& f) {   // the join (and the gathered columns
 }
 static int frame_wait_B(viso_ctx* c, PlainFrame& f) {
     if (!f.pending_B) return VISO_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int r_ = plain_signal_wait(c, c->stream, f.seqB); if (r_ < 0) return r_; }   // the chain's last kernel: everything before it on the stream is done
     f.pending_B = false; f.pending_J = false;
     const int* om = reinterpret_cast<const int*>(f.host);
     f.n_circ = om[32];
@@ -835,6 +886,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         if ((r = launch_collect_triangulate(s, reinterpret_cast<const TriItem*>(f->dev + offsetof(FrameHead, tri)), 1, sp, n1)) < 0) return r;
     }
     pp.mark(2);
+    int seqA = 0;
     // ---- ONE read-back: a copy kernel writes the counters and the rows that exist into the frame's pinned mirror
     {
         OutArgs oa{};
@@ -858,13 +910,14 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
             for (int k = 0; k < 3; ++k) region(f->o_X + sizeof(double) * C * k, dmisc + 16, 2, n1);
         }
         const unsigned gx = (unsigned)((3 * C + 1023) / 1024);
+        if ((r = plain_signal_next(c, &oa.sig)) < 0) return r;
+        seqA = oa.sig.seq;
         hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, oa);
         HIP_TRY(hipGetLastError());
     }
     pp.mark(3);
     if (spec_B) {   // ---- the second part: it keeps running while the caller goes through collect / triangulate / the temporal calls
         PlainFrame& prv = pc->frame[pc->cur ^ 1];
-        HIP_TRY(hipEventRecord(f->evA, s));
         const int* pmisc = reinterpret_cast<const int*>(prv.dev + prv.o_misc);
         CircleArgs ca{};
         ca.lr = reinterpret_cast<const int*>(f->dev + f->o_sorted[0]); ca.lrp = reinterpret_cast<const int*>(prv.dev + prv.o_sorted[0]);
@@ -892,9 +945,10 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         for (int k = 0; k < 4; ++k) region(f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
         for (int k = 0; k < 3; ++k) region(f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
         const unsigned gx = (unsigned)((6 * C + 1023) / 1024);
+        if ((r = plain_signal_next(c, &ob.sig)) < 0) return r;
+        f->seqJ = ob.sig.seq;
         hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, ob);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(f->evJ, s));
         SolverParamsDev sp;
         fill_solver_params(&sp, &f->rs_p);
         if ((r = launch_ransac(s, reinterpret_cast<const SolverItem*>(f->dev + offsetof(FrameHead, rs)), 1, f->rs_p.ransac_iter, f->rs_seed, sp,
@@ -902,13 +956,15 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         nr = 0;
         region(f->o_rs, nullptr, 32, 1);
         region(f->o_rs + 128, reinterpret_cast<const int*>(f->dev + f->o_rs) + 2, 1, cap);
+        if ((r = plain_signal_next(c, &ob.sig)) < 0) return r;
+        f->seqB = ob.sig.seq;
         hipLaunchKernelGGL(plain_out_kernel, dim3((unsigned)((C + 1023) / 1024 ? (C + 1023) / 1024 : 1), nr), dim3(256), 0, s, ob);
         HIP_TRY(hipGetLastError());
         f->have_B = true; f->pending_B = true; f->pending_J = true;
     }
     if (g_tr_on) tt[4] = tr_now();
     pp.wait_begin();
-    if (spec_B) HIP_TRY(hipEventSynchronize(f->evA)); else HIP_TRY(hipStreamSynchronize(s));
+    if ((r = plain_signal_wait(c, s, seqA)) < 0) return r;   // the first copy-out: whatever was launched behind it runs on
     pp.wait_end();
     if (g_tr_on) tt[5] = tr_now();
     const int* omisc = reinterpret_cast<const int*>(f->host);
@@ -997,7 +1053,7 @@ int plain_try_circle(viso_ctx* c, const int32_t* lr, int n_lr, const int32_t* lr
     if (f.have[1] && f.have[2] && !full) return 0;
     pc->circ_pattern = true;   // the loop's call: the stereo lists of this frame and the last
     if (!f.have_B || !full) return 0;
-    if (frame_wait_J(f) < 0) return 0;
+    if (frame_wait_J(c, f) < 0) return 0;
     const int cnt = f.n_circ;
     if (cnt < 0 || cnt > f.cap) return 0;
     const int w = cnt < cap ? cnt : cap;

@@ -850,9 +850,11 @@ extern "C" int viso_minimize_reproj(const double* X, const double* obs, int m, d
     hipLaunchKernelGGL(minimize_reproj_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    if ((r = plain_blit(c->stream, dout, hout, 32)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, 32, nullptr, 0, 0, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();
     memcpy(tr, hout, sizeof(double) * 6);
     const int ok = *reinterpret_cast<const int*>(hout + 64);
@@ -890,9 +892,11 @@ extern "C" int viso_get_inliers(const double* X, const double* obs, int m, const
     hipLaunchKernelGGL(get_inliers_kernel, dim3(1), dim3(REFIT_THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     pp.mark(2);
-    if ((r = plain_blit(c->stream, dout, hout, 16, a.n_inl, 1, m)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, 16, a.n_inl, 1, m, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();
     const int n = *reinterpret_cast<const int*>(hout);
     if (n < 0 || n > m) { viso_set_error("viso_get_inliers: device returned %d inliers of %d points", n, m); return VISO_ERR_HIP; }
@@ -1001,9 +1005,11 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     // for (viso_ctx_set_gn_split): 203 -> 183 us per call (tools/dropin_probe.py, GN_SPLIT sweep); same hypotheses bit for bit
     if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split ? c->gn_split : 1, m)) < 0) return r;
     pp.mark(2);
-    if ((r = plain_blit(c->stream, dout, hout, 32, it.n_inl, 1, m)) < 0) return r;
+    PlainSignal sig_;
+    if ((r = plain_signal_next(c, &sig_)) < 0) return r;
+    if ((r = plain_blit(c->stream, dout, hout, 32, it.n_inl, 1, m, &sig_)) < 0) return r;
     pp.wait_begin();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();
     const int* res = reinterpret_cast<const int*>(hout);
     if (res[2] < 0 || res[2] > m) { viso_set_error("viso_ransac_minimize_reproj: device returned %d inliers of %d points", res[2], m); return VISO_ERR_HIP; }

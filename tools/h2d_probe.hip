@@ -44,6 +44,10 @@ struct Pool {   // spinning helpers: thread i copies slice i when `gen` advances
     ~Pool() { stop = true; gen.fetch_add(1); for (auto& t : th) t.join(); }
 };
 
+__global__ void flag_kernel(int* flag, int seq) {
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+
 int main() {
     const size_t B = 2000 * 121 * 4;   // one image's descriptors
     char *pin, *dev; int* dflag; int* hflag;
@@ -62,6 +66,19 @@ int main() {
         double t0 = now();
         for (int i = 0; i < R; ++i) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipStreamSynchronize(s)); }
         if (w) printf("empty kernel + sync: %.1f us\n", (now() - t0) / R);
+    }
+    // (round 6) the same round trip with the host SPINNING on a word of pinned memory that the kernel writes (system-scope
+    // release) instead of hipStreamSynchronize: what the completion signal's path costs
+    for (int w = 0; w < 2; ++w) {
+        double t0 = now();
+        volatile int* f = hflag;
+        for (int i = 0; i < R; ++i) {
+            const int seq = w * R + i + 1;
+            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, hflag, seq);
+            while (*f != seq) __builtin_ia32_pause();
+        }
+        if (w) printf("kernel that writes a pinned flag + host spin on it (no synchronize): %.1f us\n", (now() - t0) / R);
+        CK(hipStreamSynchronize(s));
     }
     { int x; double t0 = now();
       for (int i = 0; i < R; ++i) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, dflag); CK(hipMemcpyAsync(&x, dflag, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
