@@ -262,7 +262,9 @@ typedef struct viso_plain_times {
  * triangulate_rectified + match_circle, ransac_minimize_reproj), wasted[0..3] = results computed ahead and never asked for. */
 int viso_plain_cache(int enable);
 int viso_plain_cache_stats(int64_t* hits, int64_t* misses);
-int64_t viso_plain_general_reruns(void);   /* calls repeated because an image unexpectedly did not fit the u16 rows */
+int64_t viso_plain_general_reruns(void);   /* calls repeated because their launch had left out a kernel the data then needed: an image
+                                              that unexpectedly did not fit the u16 rows, or a stereo pair with a wide epipolar band
+                                              after several rectified ones */
 int viso_plain_speculate(int enable);
 int viso_plain_speculate_stats(int64_t served_wasted[8]);
 /* $VISO_PLAIN_TRACE=1: host microseconds of viso_match_desc by phase; this prints and zeroes them (stderr). */

@@ -131,6 +131,18 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
         }
     }
     if (threadIdx.x == 0) *a.out_n = running;
+    if (a.g_x) {   // uniform: the gather of the joined rows' columns (the rows were written by this workgroup)
+        __threadfence_block();
+        __syncthreads();
+        const int n = running < a.cap ? running : a.cap;
+        for (int i = threadIdx.x; i < n; i += CIRCT_THREADS) {
+            const int ci = a.rows[6 * i + 4], k = a.rows[6 * i + 5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.g_xc[(size_t)r * a.g_ldc + i] = a.g_x[(size_t)r * a.g_ldx + ci];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) a.g_Xpc[(size_t)r * a.g_ldc + i] = a.g_Xp[(size_t)r * a.g_ldXp + k];
+        }
+    }
 }
 
 int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn) {

@@ -163,6 +163,9 @@ struct CircleArgs {
     const int* n_lr_p; const int* n_lrp_p; const int* n11_p; const int* n22_p;   // device counts (override the values), or null
     int* rows;      // out: 6 ints per joined row: circ_match (ileft, iright, ileft_prev, iright_prev) | match_pcl (i, k)
     int cap; int* out_n;
+    // optional (the plain family's frames; g_x == null: no gather): x_c / Xp_c of src/viso.cpp:1292-1305 -- columns of this frame's x
+    // and of the previous frame's X picked by match_pcl -- written by the kernel's tail instead of a kernel of their own
+    const double* g_x; const double* g_Xp; double* g_xc; double* g_Xpc; int g_ldx, g_ldXp, g_ldc;
 };
 // tab: 3 * tabn ints of device scratch; keys outside [0, tabn) or duplicate keys take the literal nested loops
 int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn);
@@ -238,6 +241,8 @@ int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int 
 #define VISO_KIND_TEMPORAL 1
 #define VISO_KIND_STEREO 2
 #define VISO_KIND_ALL 3
+#define VISO_KIND_NO_WIDE 4      // (plain family) leave match_batch_kernel<1> out: the launcher expects no tile with a wide epipolar band --
+                                 // the count of declined tiles comes back with the results, and the call is repeated if there was one
 // general_possible = 0: the rows cannot be flagged (descriptors extracted on the device from uint8 images), the
 // kernels of the general (double) path are not even launched
 int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int dlen,
@@ -245,7 +250,10 @@ int launch_match_timed(hipStream_t s, const MatchProblem* probs_dev, int n_probs
                        const int2* ovf_q, const int* ovf_cnt, int r8s, int general_possible = 1, int kinds = VISO_KIND_ALL);
 const char* matcher_kernel_name(int variant);
 #define VISO_MATCHER_DEFAULT 6
-int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty = 0);
+struct TriItem;
+// tri / tri_sp (plain family, or null): collect_matches + triangulate_rectified of problem 0's list inside the sort kernel
+int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty = 0,
+                const TriItem* tri = nullptr, const SolverParamsDev* tri_sp = nullptr);
 void fill_match_params(MatchParamsDev* d, const viso_match_params* h);
 void fill_solver_params(SolverParamsDev* d, const viso_param* h);
 
@@ -318,6 +326,9 @@ int launch_match_prune_temporal(hipStream_t s, const BatchMatchArgs& a, long lon
 int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks);
 int launch_match_strip_temporal(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max);
+// match_frame.hip: the stereo and the temporal problems of a handful of problems (one frame) in ONE launch
+int launch_match_frame(hipStream_t s, const BatchMatchArgs& at, const BatchMatchArgs& as64, long long blocks_t, int cap_max);
+#define VISO_FRAME_MAX_BLOCKS 256   // temporal grids up to this size (8 problem slots of 2000 keypoints) take the one-launch kernel
 int launch_extract_pack(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap, const uint8_t* images,
                         int rows, int cols, int extras, int r8s, int* r8cnt);
 int launch_harris_response(hipStream_t s, const uint8_t* images, int n_img, int rows, int cols, double k, float* resp);

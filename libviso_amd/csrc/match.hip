@@ -1044,8 +1044,23 @@ int launch_match(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int 
 // key counts the smaller keys of ITS bucket (a handful): final row = bucket start + that count.  Five LDS round
 // trips instead of the 66 stages of a 2048-key bitonic network.  Distances piled into one bucket (all equal, say)
 // would make the counting quadratic: such problems (and those beyond VISO_SORT_FAST_MAX keys) take the network.
+// tri (plain family's frames, or null): collect_matches / triangulate_rectified (src/viso.cpp:501-514, 1137-1162) of problem 0's
+// list, row by row as the rows are written -- the thread that stores row r has i1 and i2 in hand: no kernel of its own
+__device__ __forceinline__ void sort_tri_row(const TriItem& T, const SolverParamsDev& sp, int r, int i1, int i2) {
+    const float2 a = T.kp1[i1], b = T.kp2[i2];
+    const double uL = a.x, vL = a.y, uR = b.x, vR = b.y;
+    T.x[0 * T.ld + r] = uL; T.x[1 * T.ld + r] = vL; T.x[2 * T.ld + r] = uR; T.x[3 * T.ld + r] = vR;
+    if (T.X) {
+        const double d = uL - uR;                       // :1148-1151, no clamp
+        T.X[0 * T.ld + r] = sp.base * (uL - sp.cu) / d;
+        T.X[1 * T.ld + r] = sp.base * (vL - sp.cv) / d;
+        T.X[2 * T.ld + r] = sp.f * sp.base / d;
+    }
+}
+
 __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const MatchProblem* probs,
-                                                                         int n_probs, int npad_alloc, int fast, int flagged_empty) {
+                                                                         int n_probs, int npad_alloc, int fast, int flagged_empty,
+                                                                         const TriItem* tri, SolverParamsDev tri_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int s_cnt;
@@ -1056,6 +1071,9 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     const int prob = blockIdx.x;
     if (prob >= n_probs) return;
     const MatchProblem P = probs[prob];
+    const bool do_tri = tri != nullptr && prob == 0;   // uniform
+    TriItem T{};
+    if (do_tri) T = *tri;
     // a launch that left the general kernels out (plain.hip: every image so far fitted the u16 rows, the new ones are
     // expected to) has NO results for a problem with a flagged image: an empty list, the host sees the flag and repeats
     if (flagged_empty && (*P.q.bad | *P.t.bad) != 0) { if (threadIdx.x == 0) *P.m_cnt = 0; return; }
@@ -1181,6 +1199,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
                 P.sorted[3 * r + 1] = rr.x;
                 P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
                 P.pos[i1] = r;
+                if (do_tri) sort_tri_row(T, tri_sp, r, i1, rr.x);
             }
             return;
         }
@@ -1200,10 +1219,11 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
         P.sorted[3 * r + 1] = rr.x;
         P.sorted[3 * r + 2] = (int)(uint32_t)(k >> 32);
         P.pos[i1] = r;
+        if (do_tri) sort_tri_row(T, tri_sp, r, i1, rr.x);
     }
 }
 
-int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty) {
+int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int cap_max, int flagged_empty, const TriItem* tri, const SolverParamsDev* tri_sp) {
     if (n_probs <= 0) return VISO_OK;
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("match_desc: more than %d queries per call is not supported by this build", VISO_SORT_MAX);
@@ -1215,7 +1235,10 @@ int launch_sort(hipStream_t s, const MatchProblem* probs_dev, int n_probs, int c
     const size_t lds = (size_t)npad * sizeof(unsigned long long) * (fast ? 2 : 1) + 16;   // keys (+ the keys in bucket order)
     if (lds > 40 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)sort_matches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS), lds, s, probs_dev, n_probs, npad, fast, flagged_empty);
+    SolverParamsDev sp{};
+    if (tri && tri_sp) sp = *tri_sp;
+    hipLaunchKernelGGL(sort_matches_kernel, dim3(n_probs), dim3(VISO_SORT_THREADS), lds, s, probs_dev, n_probs, npad, fast, flagged_empty,
+                       tri_sp ? tri : nullptr, sp);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

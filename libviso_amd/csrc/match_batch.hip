@@ -478,6 +478,20 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         as.gs = 3; as.gf = 0; as.gc = 1; bs = (long long)g3 * 8 * a.bpp;
     }
     if (bt > 0x7fffffffLL || bs > 0x7fffffffLL) { viso_set_error("matcher grid too large"); return VISO_ERR_UNSUPPORTED; }
+    // one frame's problems (the plain family's stereo call with the temporal problems riding along): stereo and temporal
+    // workgroups in ONE launch, side by side (match_frame.hip).  $VISO_FRAME_KERNEL=0: the two kernels (A/B and test aid)
+    if (variant == 6 && (kinds & VISO_KIND_ALL) == VISO_KIND_ALL && bt <= VISO_FRAME_MAX_BLOCKS && !e_mid) {
+        static const int off = [] { const char* e = getenv("VISO_FRAME_KERNEL"); return e && *e == '0'; }();
+        if (!off) {
+            const int r = launch_match_frame(s, at, as, bt, cap_max);
+            if (r < 0) return r;
+            if (kinds & VISO_KIND_NO_WIDE) return VISO_OK;
+            as.vblocks = (int)bs;
+            hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)(bs < 1024 ? bs : 1024)), dim3(MB_THREADS), 0, s, as);
+            HIP_TRY(hipGetLastError());
+            return VISO_OK;
+        }
+    }
     if (!(kinds & VISO_KIND_TEMPORAL)) { /* no temporal problem in this launch */ } else
 #ifdef VISO_DEBUG_VARIANTS
     if (variant == 2) {
@@ -522,6 +536,7 @@ int launch_match_batch(hipStream_t s, const MatchProblem* probs_dev, int n_probs
         const int r = launch_match_stereo(s, as, cap_max);
         if (r < 0) return r;
     }
+    if (kinds & VISO_KIND_NO_WIDE) return VISO_OK;
     as.vblocks = (int)bs;
     hipLaunchKernelGGL((match_batch_kernel<1>), dim3((unsigned)(bs < 1024 ? bs : 1024)), dim3(MB_THREADS), 0, s, as);
     HIP_TRY(hipGetLastError());

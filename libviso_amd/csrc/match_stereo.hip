@@ -67,13 +67,18 @@ __device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
     return f <= 0.f ? 0 : (f >= (float)(ST_NBY - 1) ? ST_NBY - 1 : (int)f);
 }
 
-__global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs a) {
+// (match_frame.hip includes this file with ST_KERNEL_SIG / ST_BLOCK defined: see match_union8.hip)
+#ifndef ST_KERNEL_SIG
+#define ST_KERNEL_SIG __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs a)
+#define ST_BLOCK blockIdx.x
+#endif
+ST_KERNEL_SIG {
     __shared__ __attribute__((aligned(16))) StWaveLds s_w[ST_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int prob, tile;
     {
-        const int b = blockIdx.x;
+        const int b = ST_BLOCK;
         const int xcd = b & 7, slot = b >> 3;
         const int g = slot / a.bpp;                 // a.bpp = blocks (of ST_WAVES tiles) per problem
         prob = ((g / a.gc) * a.gs + a.gf + g % a.gc) * 8 + xcd;
@@ -344,6 +349,7 @@ __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
+#ifndef ST_NO_LAUNCHER
 int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max) {
     BatchMatchArgs a = a64;
     const int tiles = (cap_max + ST_QPW - 1) / ST_QPW;
@@ -357,3 +363,4 @@ int launch_match_stereo(hipStream_t s, const BatchMatchArgs& a64, int cap_max) {
     if (e != hipSuccess) { viso_set_error("match_stereo_kernel launch: %s", hipGetErrorString(e)); return VISO_ERR_HIP; }
     return VISO_OK;
 }
+#endif   // ST_NO_LAUNCHER

@@ -118,7 +118,13 @@ __device__ __forceinline__ int mu_r8s() {
 // lanes, so that a quad broadcast hands every lane the four queries its half tests in phase 1)
 __device__ __forceinline__ constexpr int mu_qlane(int k) { return (k & 3) + 32 * (k >> 2); }
 
-__global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union8_kernel(BatchMatchArgs a) {
+// (match_frame.hip includes this file with MU_KERNEL_SIG / MU_BLOCK defined: the same body as a device function that takes its
+// block number as an argument -- one launch for a single frame's stereo and temporal problems.  Here: the kernel.)
+#ifndef MU_KERNEL_SIG
+#define MU_KERNEL_SIG __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union8_kernel(BatchMatchArgs a)
+#define MU_BLOCK blockIdx.x
+#endif
+MU_KERNEL_SIG {
     __shared__ __attribute__((aligned(16))) uint32_t s_ul[MU_WAVES][MU_UCAP + MU_PAD];
     __shared__ __attribute__((aligned(16))) uint32_t s_qrow[MU_WAVES][MU_G][32];   // the round's query rows, 8-bit planes
     __shared__ uint8_t s_s8[MU_WAVES][MU_G][MU_S8ROWS];   // SAD8 >> 7 of (query, list position) of the round: what the rescue selects from
@@ -128,7 +134,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     __shared__ float s_xr[2];
     int prob, qblk;
     {
-        const int b = blockIdx.x;
+        const int b = MU_BLOCK;
         const int xcd = b & 7, slot = b >> 3;
         const int g = slot / a.bpp;
         prob = ((g / a.gc) * a.gs + a.gf + g % a.gc) * 8 + xcd;
@@ -711,6 +717,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREA
     if (lane == 0 && scored) atomicAdd(P.scored, scored);
 }
 
+#ifndef MU_NO_LAUNCHER
 int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long long blocks) {
     size_t pad = 0;
 #ifdef VISO_DEBUG_VARIANTS   // experiment ($VISO_EXP_U8_LDS_PAD bytes of unused dynamic LDS): 6 instead of 7 workgroups per CU, so that another
@@ -722,3 +729,4 @@ int launch_match_union8_temporal(hipStream_t s, const BatchMatchArgs& a, long lo
     if (e != hipSuccess) { viso_set_error("match_union8_kernel launch: %s", hipGetErrorString(e)); return VISO_ERR_HIP; }
     return VISO_OK;
 }
+#endif   // MU_NO_LAUNCHER

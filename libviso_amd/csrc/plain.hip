@@ -215,6 +215,7 @@ struct PlainCache {
     bool side_join;                        // ... and the context's stream has not been put behind side_ev yet
     int good_streak;                       // launches in a row whose images all fitted the u16 rows
     int distrust;                          // > 0: a flagged image was seen within the last PLAIN_DISTRUST_FRAMES clean launches
+    int narrow_streak;                     // stereo launches in a row in which match_stereo_kernel declined no tile (rectified pairs: always)
     long long general_reruns;
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
@@ -532,21 +533,6 @@ static bool tri_equal(const viso_param& a, const viso_param& b) {   // the field
 
 struct FrameHead { MatchProblem p[PF_PROBS]; TriItem tri; SolverItem rs; };
 
-// x_c / Xp_c of src/viso.cpp:1292-1305: columns of x (this frame) and of the previous frame's X picked by match_pcl
-__global__ __launch_bounds__(256) void plain_gather_kernel(const int* __restrict__ rows, const int* __restrict__ cnt, int cap,
-                                                           const double* __restrict__ x, int ld_x, const double* __restrict__ Xp, int ld_Xp,
-                                                           double* __restrict__ x_c, double* __restrict__ Xp_c, int ldc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int n = *cnt;
-    n = n < cap ? n : cap;
-    if (i >= n) return;
-    const int a = rows[6 * i + 4], k = rows[6 * i + 5];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x_c[(size_t)r * ldc + i] = x[(size_t)r * ld_x + a];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) Xp_c[(size_t)r * ldc + i] = Xp[(size_t)r * ld_Xp + k];
-}
-
 // lays a frame's blocks out for `cap` rows per problem (grow only)
 static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
     const size_t C = (size_t)(cap > 0 ? cap : 1);
@@ -653,6 +639,7 @@ static void plain_quiesce(viso_ctx* c, PlainCache* pc) {
     for (int i = 0; i < PLAIN_SLOTS; ++i) pc->slot[i].valid = false;
     for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; pc->frame[i].pending_J = false; }
     pc->good_streak = 0;
+    pc->narrow_streak = 0;
 }
 
 static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int n1, const float* kp2, int n2, const float* d1, const float* d2,
@@ -876,15 +863,19 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
     fill_match_params(&mpd[0], mp);
     if (np == 3) fill_match_params(&mpd[1], &pc->tm); else mpd[1] = mpd[0];
     const int general_possible = need_general ? 1 : 0;
-    const int kinds = np == 3 ? VISO_KIND_ALL : mpd[0].epi ? VISO_KIND_STEREO : VISO_KIND_TEMPORAL;
+    int kinds = np == 3 ? VISO_KIND_ALL : mpd[0].epi ? VISO_KIND_STEREO : VISO_KIND_TEMPORAL;
+    // match_batch_kernel<1> takes the tiles whose epipolar band match_stereo_kernel finds too wide (pairs that are not
+    // rectified): after a few stereo launches without such a tile it is left out (5 us of the chain the caller waits for);
+    // the number of declined tiles comes back with the results, and a launch that had one without the kernel is repeated
+    const bool skip_wide = mpd[0].epi != 0 && pc->narrow_streak >= 2 && !force_general;
+    if (skip_wide) kinds |= VISO_KIND_NO_WIDE;
     if ((r = launch_match_timed(s, dprob, np, cap, dlen, mpd, dmisc + 7, nullptr, nullptr, 0, variant, dovf, dmisc + 6, r8s,
                                 general_possible, kinds)) < 0) return r;
-    if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1)) < 0) return r;
-    if (spec_x) {
+    if (spec_x) {   // collect_matches / triangulate_rectified of the stereo list ride in the sort kernel (no kernel of their own)
         SolverParamsDev sp;
         fill_solver_params(&sp, &pc->tri_p);
-        if ((r = launch_collect_triangulate(s, reinterpret_cast<const TriItem*>(f->dev + offsetof(FrameHead, tri)), 1, sp, n1)) < 0) return r;
-    }
+        if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1, reinterpret_cast<const TriItem*>(f->dev + offsetof(FrameHead, tri)), &sp)) < 0) return r;
+    } else if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1)) < 0) return r;
     pp.mark(2);
     int seqA = 0;
     // ---- ONE read-back: a copy kernel writes the counters and the rows that exist into the frame's pinned mirror
@@ -924,12 +915,11 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         ca.m11 = reinterpret_cast<const int*>(f->dev + f->o_sorted[1]); ca.m22 = reinterpret_cast<const int*>(f->dev + f->o_sorted[2]);
         ca.n_lr_p = dmisc + 16; ca.n_lrp_p = pmisc + 16; ca.n11_p = dmisc + 20; ca.n22_p = dmisc + 24;
         ca.rows = reinterpret_cast<int*>(f->dev + f->o_circ); ca.cap = cap; ca.out_n = dmisc + 32;
+        // x_c / Xp_c of :1292-1305 come out of the join kernel's tail (no gather kernel of their own)
+        ca.g_x = reinterpret_cast<const double*>(f->dev + f->o_x); ca.g_ldx = (int)C;
+        ca.g_Xp = reinterpret_cast<const double*>(prv.dev + prv.o_X); ca.g_ldXp = prv.cap > 0 ? prv.cap : 1;
+        ca.g_xc = reinterpret_cast<double*>(f->dev + f->o_xc); ca.g_Xpc = reinterpret_cast<double*>(f->dev + f->o_Xpc); ca.g_ldc = (int)C;
         if ((r = launch_circle_table(s, ca, rs_tab, rs_tabn)) < 0) return r;
-        hipLaunchKernelGGL(plain_gather_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, ca.rows, dmisc + 32, cap,
-                           reinterpret_cast<const double*>(f->dev + f->o_x), (int)C,
-                           reinterpret_cast<const double*>(prv.dev + prv.o_X), prv.cap > 0 ? prv.cap : 1,
-                           reinterpret_cast<double*>(f->dev + f->o_xc), reinterpret_cast<double*>(f->dev + f->o_Xpc), (int)C);
-        HIP_TRY(hipGetLastError());
         OutArgs ob{};
         int nr = 0;
         auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
@@ -972,6 +962,21 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         const int m = omisc[16 + 4 * p];
         if (m < 0 || m > f->nq[p]) { frame_reset(*f); viso_set_error("viso_match_desc: device returned %d matches for %d queries", m, f->nq[p]); return VISO_ERR_HIP; }
         f->m[p] = m;
+    }
+    if (mpd[0].epi != 0) {   // tiles the stereo kernel left to the wide-band kernel (misc[8])
+        if (omisc[8] != 0) {
+            pc->narrow_streak = 0;
+            if (skip_wide) {   // ... which was not in the launch: everything it produced is dropped, the call repeated with it
+                HIP_TRY(hipStreamSynchronize(s));
+                f->pending_B = false; f->pending_J = false;
+                frame_reset(*f);
+                pc->cur = saved_cur; pc->frame_no = saved_no;
+                pc->general_reruns += 1;
+                return PLAIN_RERUN;
+            }
+        } else {
+            pc->narrow_streak += 1;
+        }
     }
     sq.bad_host = omisc[40] != 0; st.bad_host = omisc[41] != 0;   // the images' own flags, as their pack kernels left them
     if (sq.bad_host || st.bad_host) {

@@ -233,6 +233,36 @@ def test_an_image_that_does_not_fit_the_u16_rows_where_none_was_expected(viso, o
             assert np.array_equal(state["m11"], want)
 
 
+def test_a_stereo_pair_that_is_not_rectified_where_rectified_ones_were_expected(viso, oracle, seq):
+    """Rectified pairs for a while (the launches leave the wide-band stereo kernel out), then a fundamental matrix whose
+    epipolar band match_stereo_kernel declines: the call is repeated with the kernel and gives the oracle's matches."""
+    drop_in.plain_cache(True)
+    drop_in.plain_speculate(True)
+    st, tm = MatchParams.stereo(seq["F"]), MatchParams.temporal()
+    state = None
+    for t in range(5):
+        state = _loop_frame(seq, t, st, tm, state)
+    before = drop_in.plain_stats()["general_reruns"]
+    R, _ = synth.rot_from_tr(np.r_[0.2, -0.25, 0.3, 0, 0, 0])
+    P2 = synth.KITTI_P1[:, :3] @ np.c_[R, np.array([-0.54, 0.03, 0.02])]
+    wide = MatchParams.stereo(oracle.F_from_P(synth.KITTI_P1, P2))
+    for t in (5, 6):
+        nL, nR = seq["n"][t]
+        kp1, kp2 = seq["kp"][t, 0, :nL], seq["kp"][t, 1, :nR]
+        d1, d2 = seq["desc"][t, 0, :nL], seq["desc"][t, 1, :nR]
+        lr = libviso_amd.match_desc(kp1, kp2, d1, d2, wide)
+        assert np.array_equal(lr, oracle.match_desc(kp1, kp2, d1, d2, wide))
+        # the first surprises the launcher, the second does not (the kernel is back in the launch)
+        assert drop_in.plain_stats()["general_reruns"] == before + 1
+    # and the loop goes on with rectified pairs
+    state = None
+    for t in range(7, 13):
+        state = _loop_frame(seq, t, st, tm, state)
+        nL, nR = seq["n"][t]
+        want = oracle.match_desc(seq["kp"][t, 0, :nL], seq["kp"][t, 1, :nR], seq["desc"][t, 0, :nL], seq["desc"][t, 1, :nR], st)
+        assert np.array_equal(state["lr"], want)
+
+
 def test_frames_of_changing_size_and_empty_images(viso, oracle):
     """Keypoint counts that change from frame to frame (the frame's blocks are re-laid out), an image without keypoints."""
     s = synth.make_sequence(3, 9, n_kp=300, width=500, height=200, ragged=True)
