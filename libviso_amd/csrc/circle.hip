@@ -70,6 +70,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total, int*
 __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs a, int* tab, int tabn) {
     __shared__ int scratch[16];
     __shared__ int s_dup;
+    if (blockIdx.x > 0) { plain_out_blocks(*a.ride, blockIdx.x - 1); return; }   // riders: the copy-out of the kernel before (common.h, OutArgs)
     if (a.n_lr_p) a.n_lr = *a.n_lr_p;      // lists that an earlier kernel of the chain produced: their lengths are on the device
     if (a.n_lrp_p) a.n_lrp = *a.n_lrp_p;
     if (a.n11_p) a.n11 = *a.n11_p;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
 }
 
 int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn) {
-    hipLaunchKernelGGL(circle_table_kernel, dim3(1), dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
+    hipLaunchKernelGGL(circle_table_kernel, dim3(1 + (a.ride ? a.ride_blocks : 0)), dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

@@ -156,6 +156,8 @@ void plain_note_circle(viso_ctx* c, int cnt);
 int plain_try_ransac(viso_ctx* c, const double* X, const double* obs, int m, double best_tr[6], int32_t* best_inl, int* n_inl,
                      const viso_param* p, const int32_t* samples, uint64_t seed, uint64_t frame, int* ret);
 
+struct PlainSignal { int* ctr; int* flag; int seq; };   // a call's completion signal (described below); flag == nullptr: no signal
+struct OutArgs;                                          // a copy-out into the call's pinned mirror (below)
 // match_circle on lists in device memory (circle.hip): counts by value, or read from the device when the pointers are set
 struct CircleArgs {
     const int* lr; const int* lrp; const int* m11; const int* m22;
@@ -166,6 +168,9 @@ struct CircleArgs {
     // optional (the plain family's frames; g_x == null: no gather): x_c / Xp_c of src/viso.cpp:1292-1305 -- columns of this frame's x
     // and of the previous frame's X picked by match_pcl -- written by the kernel's tail instead of a kernel of their own
     const double* g_x; const double* g_Xp; double* g_xc; double* g_Xpc; int g_ldx, g_ldXp, g_ldc;
+    // optional (plain family): a copy-out of the kernel BEFORE this one rides in the launch as ride_blocks extra workgroups
+    // (OutArgs in device memory; plain_out_blocks)
+    const OutArgs* ride; int ride_blocks;
 };
 // tab: 3 * tabn ints of device scratch; keys outside [0, tabn) or duplicate keys take the literal nested loops
 int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn);
@@ -206,22 +211,62 @@ struct PlainStage {
 // fences its stores at system scope, the last workgroup to finish (a device counter) release-stores the call's sequence
 // number into a pinned word, and the host spins on that word with an acquire load (plain_signal_wait: bounded, then
 // hipStreamSynchronize as the fallback, so a lost signal costs time, never a hang or a result).
-struct PlainSignal { int* ctr; int* flag; int seq; };   // flag == nullptr: no signal
 int plain_signal_next(viso_ctx* c, PlainSignal* out);   // the next sequence number of the context (allocates on first use)
 int plain_signal_wait(viso_ctx* c, hipStream_t s, int seq);
 int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows = nullptr, int row_words = 0, int max_rows = 0,
                const PlainSignal* sig = nullptr);
+#ifdef __HIPCC__
+// Called by EVERY thread of the kernel's every workgroup, behind its last store.
+__device__ __forceinline__ void plain_signal_done(const PlainSignal& g, unsigned nblocks) {
+    if (!g.flag) return;                       // uniform
+    __threadfence_system();                    // this thread's stores (to pinned host memory) are out, system scope
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(g.ctr, 1) == (int)nblocks - 1) {   // the last workgroup of the launch: every other one has fenced and counted
+            __threadfence_system();                      // (acquire side of the counter: what the others fenced is ordered before the flag)
+            *g.ctr = 0;                                  // for the next signalling kernel (streams run them one after the other)
+            __hip_atomic_store(g.flag, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+// ---- results out: every region's rows that exist (counts on the device) into the call's pinned mirror ----------------------
+// A workgroup's path to host memory is narrow (a single one needs 15 us for what 39 spread over the chip write in 4), so the
+// copy is many small workgroups -- and where the chain has a next kernel they RIDE in its launch as extra workgroups (the
+// copy-out of the sort kernel's lists in the join kernel's launch, the join's in ransac_hyp_kernel's): they depend on the
+// kernel before, not on the one they ride in, and the 8.5 us + launch gap of a copy kernel of their own leave the chain.
+// The last kernel of the chain, ransac_refit_kernel, writes its few hundred bytes itself (RefitMirror).
+struct OutRegion { const uint32_t* src; uint32_t* dst; const int* cnt; int row_words, max_rows; };
+#define OUT_REGIONS 16
+struct OutArgs { OutRegion r[OUT_REGIONS]; int n_regions, gx; PlainSignal sig; };   // gx workgroups of 256 threads' worth per region
+#ifdef __HIPCC__
+// workgroup `b` of n_regions * gx (any workgroup size; every thread calls)
+__device__ __forceinline__ void plain_out_blocks(const OutArgs& a, unsigned b) {
+    const OutRegion R = a.r[b / (unsigned)a.gx];
+    const unsigned bx = b % (unsigned)a.gx;
+    int n = R.max_rows;
+    if (R.cnt) { const int c = *R.cnt; n = c < 0 ? 0 : c < n ? c : n; }
+    const unsigned total = (unsigned)n * (unsigned)R.row_words;
+    for (unsigned i = bx * blockDim.x + threadIdx.x; i < total; i += (unsigned)a.gx * blockDim.x) R.dst[i] = R.src[i];
+    plain_signal_done(a.sig, (unsigned)(a.n_regions * a.gx));
+}
+#endif
+struct RefitMirror {                 // ransac_refit_kernel, n_items == 1: the result block and the inliers that exist, copied by the workgroup, which signals
+    const uint32_t* res_src; uint32_t* res_dst; int res_words;
+    const int* n_inl; const uint32_t* inl_src; uint32_t* inl_dst; int max_inl;
+    PlainSignal sig;
+};
 
 // ---- launchers (host) -------------------------------------------------------
 // group every image's keypoints by column bucket (+ inverse permutation, column index, y order inside 64-blocks)
 // zero_words / n_zero: optional 32-bit words the kernel zeroes on the way (a run's counters: one memset less in front of it)
 // r8zero: the batch's four VISO_R8_* counters, zeroed too when the run is one that counts (or null)
-// imp (plain family, n_img == 1): the image comes from pinned HOST memory -- its view rides in the kernel arguments, the
+// imp (plain family, n_img == n_imp <= 2, imgs_dev unused): the images come from pinned HOST memory -- an image's view rides in the kernel arguments, the
 // kernel reads the keypoints over PCIe, leaves them in view.kp, writes *view.n = n, *view.bad = bad0 and a copy of the view
 // at view_dst (where the pack kernel's launch finds it): the copy kernel that used to run in front is gone
 struct KpImport { const float2* src_kp; int n, bad0; ImageView* view_dst; ImageView view; };
 int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words = nullptr, int n_zero = 0,
-                   int* r8zero = nullptr, const KpImport* imp = nullptr);
+                   int* r8zero = nullptr, const KpImport* imp = nullptr, int n_imp = 0);
 // pack boundary-layout float descriptors into biased u16 rows in bucket order;
 // sets the image's own flag (ImageView::bad) and *bad_any when a value is not an integer in [-32768, 32767];
 // dlen > 128 (rows do not fit) flags every image.  bad_img: the n_img flags, contiguous (for that case).
@@ -304,7 +349,8 @@ struct TriItem {
 // split: iterations the lane-per-hypothesis kernel runs before it hands undecided hypotheses to the wave-per-hypothesis
 // kernel (viso_ctx::gn_split; 100 = the lane kernel does everything)
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points);
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points,
+                  const RefitMirror* mir = nullptr, const OutArgs* ride = nullptr, int ride_blocks = 0);
 size_t viso_rot_bytes(int iters);   // bytes of SolverItem::rot
 int launch_circle_join(hipStream_t s, const JoinItem* items_dev, int n_items, const SolverParamsDev& sp);
 int launch_collect_triangulate(hipStream_t s, const TriItem* items_dev, int n_items,

@@ -49,8 +49,9 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 #define VISO_KP_REGS 4
 #endif
 
+struct KpImport2 { KpImport k[2]; };
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
-                                                                   uint32_t* zero_words, int n_zero, int* r8zero, KpImport imp) {
+                                                                   uint32_t* zero_words, int n_zero, int* r8zero, KpImport2 imps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* ykey = reinterpret_cast<uint32_t*>(smem);   // [n rounded up to 64] sortable y of the entry at each position
     __shared__ int s_cnt[VISO_NB + 1];                    // bucket counts -> starts -> running offsets
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     // One image straight from the caller's side (the plain family, KpImport): the view comes with the launch, the keypoints
     // are read from pinned host memory and left in the image's device array on the way, the header words are written here --
     // no copy kernel in front of this one
-    const bool importing = imp.src_kp != nullptr;
+    const bool importing = imps.k[0].src_kp != nullptr;
+    const KpImport& imp = imps.k[blockIdx.x & 1];   // (two at most: the two images of a plain-family call)
     const ImageView I = importing ? imp.view : imgs[blockIdx.x];
     const int n = importing ? imp.n : *I.n;
     if (importing) {
@@ -176,11 +178,11 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     }
 }
 
-int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero, const KpImport* imp) {
+int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero, const KpImport* imp, int n_imp) {
     if (n_img <= 0) return VISO_OK;
-    if (imp && n_img != 1) { viso_set_error("launch_sort_kp: an import is one image"); return VISO_ERR_ARG; }
-    KpImport ki{};
-    if (imp) ki = *imp;
+    if (imp && (n_imp != n_img || n_img > 2)) { viso_set_error("launch_sort_kp: imports are one or two images, the whole launch"); return VISO_ERR_ARG; }
+    KpImport2 ki{};
+    if (imp) { ki.k[0] = imp[0]; if (n_imp > 1) ki.k[1] = imp[1]; }
     if (cap_max > VISO_SORT_MAX) {
         viso_set_error("more than %d keypoints per image is not supported by this build", VISO_SORT_MAX);
         return VISO_ERR_UNSUPPORTED;

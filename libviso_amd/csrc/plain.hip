@@ -211,8 +211,6 @@ struct PlainCache {
     unsigned long long frame_no, circ_seen_no; int circ_seen_cnt;
     bool rs_known, rs_pattern, rs_delta_stable;   // ransac's param / seed seen; the call fitted; the stream key advances regularly
     viso_param rs_p; uint64_t rs_seed, rs_last_frame, rs_delta;
-    hipStream_t side; hipEvent_t side_ev;  // a call's SECOND new image is brought in on a stream of its own, beside the first
-    bool side_join;                        // ... and the context's stream has not been put behind side_ev yet
     int good_streak;                       // launches in a row whose images all fitted the u16 rows
     int distrust;                          // > 0: a flagged image was seen within the last PLAIN_DISTRUST_FRAMES clean launches
     int narrow_streak;                     // stereo launches in a row in which match_stereo_kernel declined no tile (rectified pairs: always)
@@ -220,21 +218,7 @@ struct PlainCache {
     long long spec_served[4], spec_wasted[4];   // [0] temporal match_desc, [1] collect_matches, [2] triangulate_rectified / match_circle, [3] ransac
 };
 
-// ---- the completion signal (common.h, PlainSignal) ------------------------------------------------------------------------
-// Called by EVERY thread of the kernel's every workgroup, behind its last store.
-__device__ __forceinline__ void plain_signal_done(const PlainSignal& g, unsigned nblocks) {
-    if (!g.flag) return;                       // uniform
-    __threadfence_system();                    // this thread's stores (to pinned host memory) are out, system scope
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (atomicAdd(g.ctr, 1) == (int)nblocks - 1) {   // the last workgroup of the launch: every other one has fenced and counted
-            __threadfence_system();                      // (acquire side of the counter: what the others fenced is ordered before the flag)
-            *g.ctr = 0;                                  // for the next signalling kernel (streams run them one after the other)
-            __hip_atomic_store(g.flag, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
+// ---- the completion signal (common.h, PlainSignal; the device side is there too) -------------------------------------------
 int plain_signal_next(viso_ctx* c, PlainSignal* out) {
     if (!c->sig_flag) {
         HIP_TRY(hipSetDevice(c->device));
@@ -320,13 +304,10 @@ static PlainCache* plain_cache(viso_ctx* c) {
 
 void plain_cache_free(viso_ctx* c) {
     if (!c->plain) return;
-    if (c->plain->side) (void)hipStreamSynchronize(c->plain->side);   // its pack kernels read the slots' pinned shadows
     for (int i = 0; i < PLAIN_SLOTS; ++i) {
         if (c->plain->slot[i].pin) (void)hipHostFree(c->plain->slot[i].pin);
         if (c->plain->slot[i].dev) (void)hipFree(c->plain->slot[i].dev);
     }
-    if (c->plain->side) (void)hipStreamDestroy(c->plain->side);
-    if (c->plain->side_ev) (void)hipEventDestroy(c->plain->side_ev);
     for (int i = 0; i < 3; ++i) {
         if (c->plain->frame[i].host) (void)hipHostFree(c->plain->frame[i].host);
         if (c->plain->frame[i].dev) (void)hipFree(c->plain->frame[i].dev);
@@ -397,8 +378,8 @@ extern "C" int viso_plain_cache_stats(int64_t* hits, int64_t* misses) {
 static double g_tr_us[3][6];
 static long g_tr_n[3];
 static int g_tr_on = -1;
-static double g_acq_us[2];
-static long g_acq_n;
+static double g_acq_us[3];
+static long g_acq_n, g_acq_calls;
 static double tr_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" void viso_plain_trace_dump(void) {
     static const char* ph[6] = {"acquire_q", "acquire_t", "setup+blit_in", "launches", "wait", "copy_out"};
@@ -408,41 +389,46 @@ extern "C" void viso_plain_trace_dump(void) {
         for (int j = 0; j < 6; ++j) fprintf(stderr, "  %s %.1f", ph[j], g_tr_us[k][j] / g_tr_n[k]);
         fprintf(stderr, "  (us per call)\n");
     }
-    if (g_acq_n) fprintf(stderr, "uploads: %ld, copy into the shadow %.1f us, sort_kp + pack launches %.1f us\n", g_acq_n, g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n);
-    g_acq_us[0] = g_acq_us[1] = 0; g_acq_n = 0;
+    if (g_acq_n) fprintf(stderr, "uploads: %ld, rows into the shadow %.1f us, pack launch %.1f us; look-ups + keypoints + sort_kp launch %.1f us per call\n", g_acq_n,
+                         g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n, g_acq_us[2] / (g_acq_calls > 0 ? g_acq_calls : 1));
+    memset(g_acq_us, 0, sizeof(g_acq_us)); g_acq_n = 0; g_acq_calls = 0;
     memset(g_tr_us, 0, sizeof(g_tr_us)); memset(g_tr_n, 0, sizeof(g_tr_n));
 }
 
-// The slot that holds (kp, d) -- found by comparing bytes, or filled now: shadow copy, ONE upload of kp | desc | hdr.
-// `keep` is a slot that must not be evicted (the call's other image), -1 for none.
-static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const float* d, int n, int dlen, int extras, int r8s,
-                         int keep, bool* hit, hipStream_t stream) {
+// The slot that holds (kp, d), found by comparing bytes; -1: not resident.
+static int plain_lookup(PlainCache* pc, const float* kp, const float* d, int n, int dlen, int extras, int r8s) {
     const size_t kb = sizeof(float2) * (size_t)n, db = sizeof(float) * (size_t)n * dlen;
-    *hit = false;
     if (pc->enabled)
         for (int i = 0; i < PLAIN_SLOTS; ++i) {
             PlainSlot& s = pc->slot[i];
             if (!s.valid || s.n != n || s.dlen != dlen || s.extras != extras || s.r8s != r8s) continue;
             if ((kb && memcmp(s.pin, kp, kb) != 0) || !big_equal(s.pin + s.o_desc, d, db)) continue;
             pc->hits += 1;   // the stamp stays the upload's: slots are recycled oldest UPLOAD first.  (Refreshed on a hit -- LRU --
-            *hit = true;     // the loop's own order evicts frame t-1's left image when frame t's arrives: its last use was the
-            return i;        // temporal-left call, before the right images' -- and the temporal calls of frame t upload it again.)
-        }
+            return i;        // the loop's own order evicts frame t-1's left image when frame t's arrives: its last use was the
+        }                    // temporal-left call, before the right images' -- and the temporal calls of frame t upload it again.)
     pc->misses += 1;
+    return -1;
+}
+
+// An image that is not resident comes to the device in two pieces.  Keypoints + header (16 KB): sort_kp_kernel fetches them
+// from the pinned shadow itself (KpImport) -- plain_prepare picks the slot (`keep`, `keep2`: slots that must not be evicted, the
+// call's other image; -1 for none), copies the keypoints into the shadow and fills the import.  The f32 descriptor rows
+// (968 KB) are read ONCE, by pack_desc_kernel, which turns them into the u16 rows the matchers use: it reads them straight
+// from the shadow over PCIe -- no copy-engine transfer (25 us on the wire + 20 us of host time in hipMemcpyAsync per image,
+// and every kernel of the call queued behind both) and no second copy of the rows in device memory; plain_finish copies
+// them into the shadow and launches that kernel.  A call's order: prepare both images, ONE sort_kp launch for what is new
+// (it needs the keypoints only and runs while the host copies rows), then rows + pack launch image by image, so that the
+// GPU packs the first image while the host copies the second.  (Only the general path reads f32 rows again -- images
+// with non-integer descriptors -- and then from the shadow: slow, correct.)
+static int plain_prepare(viso_ctx* c, PlainCache* pc, const float* kp, int n, int dlen, int extras, int r8s, int keep, int keep2, KpImport* imp) {
+    const size_t kb = sizeof(float2) * (size_t)n;
     int vi = -1;   // an empty slot, else the one uploaded longest ago
     for (int i = 0; i < PLAIN_SLOTS && vi < 0; ++i)
-        if (i != keep && !pc->slot[i].valid) vi = i;
+        if (i != keep && i != keep2 && !pc->slot[i].valid) vi = i;
     for (int i = 0; i < PLAIN_SLOTS && (vi < 0 || pc->slot[vi].valid); ++i)
-        if (i != keep && (vi < 0 || pc->slot[i].stamp < pc->slot[vi].stamp)) vi = i;
+        if (i != keep && i != keep2 && (vi < 0 || pc->slot[i].stamp < pc->slot[vi].stamp)) vi = i;
     PlainSlot& s = pc->slot[vi];
     s.valid = false;
-    // The image comes to the device in two pieces.  Keypoints + header (16 KB) by a copy kernel.  The f32 descriptor rows
-    // (968 KB) are read ONCE, by pack_desc_kernel, which turns them into the u16 rows the matchers use: it reads them straight
-    // from the pinned shadow over PCIe -- no copy-engine transfer (25 us on the wire + 20 us of host time in
-    // hipMemcpyAsync per image, and every kernel of the call queued behind both) and no second copy of the rows in device
-    // memory.  sort_kp_kernel and pack_desc_kernel of THIS image are launched here, so the GPU works on it while the host
-    // copies the call's other image into its shadow.  (Only the general path reads f32 rows again -- images with non-integer
-    // descriptors -- and then from the shadow: slow, correct.)
     const size_t na = (size_t)(n > 0 ? n : 1);
     const size_t o_hdr = al256(sizeof(float2) * na), o_desc = o_hdr + PLAIN_HDR;
     const size_t pin_need = o_desc + al256(sizeof(float) * na * dlen);
@@ -462,7 +448,6 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
         HIP_TRY(hipMalloc((void**)&s.dev, total + total / 4));
         s.dev_bytes = total + total / 4;
     }
-    const double ta0 = g_tr_on > 0 ? tr_now() : 0;
     if (kb) memcpy(s.pin, kp, kb);
     ImageView v{};
     v.kp = reinterpret_cast<const float2*>(s.dev);
@@ -483,44 +468,38 @@ static int plain_acquire(viso_ctx* c, PlainCache* pc, const float* kp, const flo
     int* hdr = reinterpret_cast<int*>(s.pin + o_hdr);
     hdr[0] = n;
     hdr[1] = dlen > VISO_ROW ? 1 : 0;   // rows that do not fit the packed format: the image takes the general path
-    memcpy(s.pin + o_hdr + 64, &v, sizeof(v));   // the image's view, where sort_kp_kernel / pack_desc_kernel find it
-    // sort_kp_kernel needs the keypoints only: it runs while the host copies the 968 KB of rows into the shadow -- and it
-    // fetches them from the shadow itself (16 KB over PCIe), with the image's view in its arguments and the header words
-    // {n, bad} written on the way: the copy kernel that used to bring keypoints + header over first (7.6 us of the chain
-    // in front of every new image's pack kernel) is gone
-    int r;
-    const ImageView* dview = reinterpret_cast<const ImageView*>(s.dev + o_hdr + 64);
-    KpImport imp{};
-    imp.src_kp = reinterpret_cast<const float2*>(s.pin); imp.n = n; imp.bad0 = hdr[1];
-    imp.view_dst = reinterpret_cast<ImageView*>(s.dev + o_hdr + 64); imp.view = v;
-    if ((r = launch_sort_kp(stream, dview, 1, n > 0 ? n : 1, nullptr, 0, nullptr, &imp)) < 0) return r;
-    // (the rows in two halves, the first packed while the second is copied: two more launches on the host for 6 us less of
-    // the GPU's chain -- 2 356 against 2 337 frames/s, inside the noise; not kept)
-    big_copy(s.pin + o_desc, d, db);
-    const double ta1 = g_tr_on > 0 ? tr_now() : 0;
-    if (dlen <= VISO_ROW && (r = launch_pack(stream, dview, 1, n > 0 ? n : 1, dlen, nullptr, const_cast<int*>(v.bad), extras, r8s, nullptr)) < 0) return r;
-    if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
+    memcpy(s.pin + o_hdr + 64, &v, sizeof(v));
+    // sort_kp_kernel gets the image's view in its arguments, writes the header words {n, bad} and leaves a copy of the view on
+    // the device where pack_desc_kernel's launch finds it (the copy kernel that used to bring keypoints + header over first is gone)
+    *imp = KpImport{};
+    imp->src_kp = reinterpret_cast<const float2*>(s.pin); imp->n = n; imp->bad0 = hdr[1];
+    imp->view_dst = reinterpret_cast<ImageView*>(s.dev + o_hdr + 64); imp->view = v;
     s.n = n; s.dlen = dlen; s.extras = extras; s.r8s = r8s;
     s.bad_host = dlen > VISO_ROW ? 1 : -1;
     s.o_desc = o_desc; s.o_hdr = o_hdr;
     s.v = v;
-    s.stamp = ++pc->clock;
-    s.valid = true;
     return vi;
 }
 
-// ---- results out: every region's rows that exist (counts on the device) into the pinned mirror, ONE launch ----------
-struct OutRegion { const uint32_t* src; uint32_t* dst; const int* cnt; int row_words, max_rows; };
-#define OUT_REGIONS 24
-struct OutArgs { OutRegion r[OUT_REGIONS]; PlainSignal sig; };
-__global__ __launch_bounds__(256) void plain_out_kernel(OutArgs a) {
-    const OutRegion R = a.r[blockIdx.y];
-    int n = R.max_rows;
-    if (R.cnt) { const int c = *R.cnt; n = c < 0 ? 0 : c < n ? c : n; }
-    const unsigned total = (unsigned)n * (unsigned)R.row_words;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) R.dst[i] = R.src[i];
-    plain_signal_done(a.sig, gridDim.x * gridDim.y);
+static int plain_finish(viso_ctx* c, PlainCache* pc, int vi, const float* d, hipStream_t stream) {
+    PlainSlot& s = pc->slot[vi];
+    const int n = s.n, dlen = s.dlen;
+    const double ta0 = g_tr_on > 0 ? tr_now() : 0;
+    // (the rows in two halves, the first packed while the second is copied: two more launches on the host for 6 us less of
+    // the GPU's chain -- 2 356 against 2 337 frames/s, inside the noise; not kept)
+    big_copy(s.pin + s.o_desc, d, sizeof(float) * (size_t)n * dlen);
+    const double ta1 = g_tr_on > 0 ? tr_now() : 0;
+    int r;
+    const ImageView* dview = reinterpret_cast<const ImageView*>(s.dev + s.o_hdr + 64);
+    if (dlen <= VISO_ROW && (r = launch_pack(stream, dview, 1, n > 0 ? n : 1, dlen, nullptr, const_cast<int*>(s.v.bad), s.extras, s.r8s, nullptr)) < 0) return r;
+    if (g_tr_on > 0) { g_acq_us[0] += ta1 - ta0; g_acq_us[1] += tr_now() - ta1; g_acq_n += 1; }
+    s.stamp = ++pc->clock;
+    s.valid = true;
+    return VISO_OK;
 }
+
+// a copy-out (common.h, OutArgs) as a kernel of its own: where the chain has no next kernel for it to ride in
+__global__ __launch_bounds__(256) void plain_out_kernel(OutArgs a) { plain_out_blocks(a, blockIdx.x); }
 
 static bool params_equal(const viso_match_params& a, const viso_match_params& b) {
     return a.enforce_epipolar == b.enforce_epipolar && a.enforce_2nd_best == b.enforce_2nd_best && a.max_neighbors == b.max_neighbors &&
@@ -531,7 +510,7 @@ static bool tri_equal(const viso_param& a, const viso_param& b) {   // the field
     return memcmp(&a.base, &b.base, 8) == 0 && memcmp(&a.f, &b.f, 8) == 0 && memcmp(&a.cu, &b.cu, 8) == 0 && memcmp(&a.cv, &b.cv, 8) == 0;
 }
 
-struct FrameHead { MatchProblem p[PF_PROBS]; TriItem tri; SolverItem rs; };
+struct FrameHead { MatchProblem p[PF_PROBS]; TriItem tri; SolverItem rs; OutArgs outA, outJ; };
 
 // lays a frame's blocks out for `cap` rows per problem (grow only)
 static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
@@ -612,21 +591,6 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
                      const viso_match_params* mp, int variant, int extras, int r8s, int32_t* out_match, int* out_n,
                      bool force_general, double* tt);
 
-// the side stream and its event (first use)
-static int plain_side(PlainCache* pc) {
-    if (pc->side) return VISO_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&pc->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&pc->side_ev, hipEventDisableTiming));
-    return VISO_OK;
-}
-// the context's stream behind what the side stream has brought in for this call (once)
-static int plain_side_join(PlainCache* pc, hipStream_t s) {
-    if (!pc->side_join) return VISO_OK;
-    pc->side_join = false;
-    HIP_TRY(hipStreamWaitEvent(s, pc->side_ev, 0));
-    return VISO_OK;
-}
-
 // An error return must not leave work in flight: the kernels queued so far (copy, sort_kp, pack -- possibly on the side
 // stream) read the slots' pinned shadows and the context's pinned block, a slot may already be marked valid although its
 // pack kernel never ran to the end, and the next call would memcpy over a shadow a queued kernel is still pulling over
@@ -634,8 +598,6 @@ static int plain_side_join(PlainCache* pc, hipStream_t s) {
 // (Errors here are HIP failures; nothing is optimised for them.)
 static void plain_quiesce(viso_ctx* c, PlainCache* pc) {
     (void)hipStreamSynchronize(c->stream);
-    if (pc->side) (void)hipStreamSynchronize(pc->side);
-    pc->side_join = false;
     for (int i = 0; i < PLAIN_SLOTS; ++i) pc->slot[i].valid = false;
     for (int i = 0; i < 3; ++i) { pc->frame[i].valid = false; pc->frame[i].pending_B = false; pc->frame[i].pending_J = false; }
     pc->good_streak = 0;
@@ -685,22 +647,29 @@ static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int 
     if (g_tr_on < 0) { const char* e = getenv("VISO_PLAIN_TRACE"); g_tr_on = e && *e == '1'; }
     double tt[7] = {0, 0, 0, 0, 0, 0, 0};
     if (g_tr_on) tt[0] = tr_now();
-    const int iq = plain_acquire(c, pc, kp1, d1, n1, dlen, extras, r8s, -1, &hit_q, s);
-    if (iq < 0) return iq;
-    if (g_tr_on) tt[1] = tr_now();
-    // When the first image had to be brought in, a second new one goes through a stream of its own: copy kernel, sort_kp_kernel
-    // and pack_desc_kernel of the two images are independent chains (50 us each, the pack kernels pulling their rows over
-    // PCIe), and the first is already running while the host copies the second into its shadow.  The context's stream waits
-    // for the side stream's event before the matcher; nothing else ever runs there, and every call ends behind that wait.
-    hipStream_t s2 = s;
-    if ((r = plain_side(pc)) < 0) return r;
-    if (!hit_q) s2 = pc->side;
-    const int it = plain_acquire(c, pc, kp2, d2, n2, dlen, extras, r8s, iq, &hit_t, s2);
-    if (it < 0) return it;
-    if (s2 != s && !hit_t) {   // the wait itself comes behind the copy of the frame's head (match_run), or at the call's return
-        HIP_TRY(hipEventRecord(pc->side_ev, s2));
-        pc->side_join = true;
+    int iq = plain_lookup(pc, kp1, d1, n1, dlen, extras, r8s);
+    int it = plain_lookup(pc, kp2, d2, n2, dlen, extras, r8s);
+    hit_q = iq >= 0; hit_t = it >= 0;
+    const bool same_image = !hit_q && !hit_t && kp1 == kp2 && d1 == d2 && n1 == n2;   // one upload serves both sides
+    {
+        KpImport imp[2];
+        int n_imp = 0, cap_imp = 1;
+        if (!hit_q) {
+            if ((iq = plain_prepare(c, pc, kp1, n1, dlen, extras, r8s, it, -1, &imp[n_imp])) < 0) return iq;
+            ++n_imp; cap_imp = n1 > cap_imp ? n1 : cap_imp;
+        }
+        if (same_image) it = iq;
+        else if (!hit_t) {
+            if ((it = plain_prepare(c, pc, kp2, n2, dlen, extras, r8s, iq, -1, &imp[n_imp])) < 0) return it;
+            ++n_imp; cap_imp = n2 > cap_imp ? n2 : cap_imp;
+        }
+        // the new images' keypoints: ONE launch, a workgroup per image, while the host copies the rows
+        if (n_imp && (r = launch_sort_kp(s, nullptr, n_imp, cap_imp, nullptr, 0, nullptr, imp, n_imp)) < 0) return r;
     }
+    if (g_tr_on > 0) { g_acq_us[2] += tr_now() - tt[0]; g_acq_calls += 1; }
+    if (!hit_q && (r = plain_finish(c, pc, iq, d1, s)) < 0) return r;
+    if (g_tr_on) tt[1] = tr_now();
+    if (!hit_t && !same_image && (r = plain_finish(c, pc, it, d2, s)) < 0) return r;
     if (g_tr_on) tt[2] = tr_now();
     const bool stereo_call = mp->enforce_epipolar != 0;
     // ---- a temporal call the frame's stereo call has already answered?
@@ -716,7 +685,7 @@ static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int 
                     *out_n = m;
                     cur.used[p] = true;
                     pc->spec_served[0] += 1;
-                    return plain_side_join(pc, s);
+                    return VISO_OK;
                 }
         // the direct path it is; remember what a temporal call looks like, and whether it is the loop's
         pc->tm = *mp; pc->tm_known = true;
@@ -727,7 +696,6 @@ static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int 
         r = match_run(c, pc, pp, iq, it, hit_q, hit_t, n1, n2, dlen, mp, variant, extras, r8s, out_match, out_n, pass == 1, tt);
         if (r != PLAIN_RERUN) break;
     }
-    { const int rj = plain_side_join(pc, s); if (r >= 0 && rj < 0) r = rj; }   // (an error left match_run before its own)
     if (r < 0) return r;
     if (g_tr_on) {
         tt[6] = tr_now();
@@ -770,7 +738,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
             np = 3;
         spec_x = pc->tri_known && pc->x_pattern;
         spec_B = np == 3 && spec_x && prv.have_xX && prv.have[0] && pc->circ_pattern && pc->rs_known && pc->rs_pattern && pc->rs_delta_stable &&
-                 pc->rs_p.ransac_iter >= 0 && pc->rs_p.ransac_iter <= 4096;
+                 pc->rs_p.ransac_iter >= 1 && pc->rs_p.ransac_iter <= 4096;
     } else {
         frame_reset(*f);
     }
@@ -854,8 +822,49 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         H->rs = it;
         (void)prv;
     }
+    // ---- the copy-outs into the frame's pinned mirror (common.h, OutArgs): the lists (and x, X) behind the sort kernel -- riding in
+    // the join kernel's launch when the frame has one, a kernel of their own otherwise; the join and the gathered columns behind
+    // the join kernel, riding in ransac_hyp_kernel's launch.  Each signals: match_circle returns as soon as the join is there,
+    // the RANSAC stage runs on behind the caller's gather loop
+    int seqA = 0;
+    {
+        auto region = [&](OutArgs& o, size_t off, const int* cnt, int row_words, int max_rows) {
+            OutRegion& R = o.r[o.n_regions++];
+            R.src = reinterpret_cast<const uint32_t*>(f->dev + off);
+            R.dst = reinterpret_cast<uint32_t*>(f->host + (off - f->o_misc));
+            R.cnt = cnt; R.row_words = row_words; R.max_rows = max_rows;
+        };
+        OutArgs& oa = H->outA;
+        oa = OutArgs{};
+        region(oa, f->o_misc, nullptr, 40, 1);
+        {   // the two images' own flags: words 40, 41 of the mirror
+            OutRegion& R0 = oa.r[oa.n_regions++];
+            R0.src = reinterpret_cast<const uint32_t*>(sq.v.bad); R0.dst = reinterpret_cast<uint32_t*>(f->host) + 40; R0.cnt = nullptr; R0.row_words = 1; R0.max_rows = 1;
+            OutRegion& R1 = oa.r[oa.n_regions++];
+            R1.src = reinterpret_cast<const uint32_t*>(st.v.bad); R1.dst = reinterpret_cast<uint32_t*>(f->host) + 41; R1.cnt = nullptr; R1.row_words = 1; R1.max_rows = 1;
+        }
+        for (int p = 0; p < np; ++p) region(oa, f->o_sorted[p], dmisc + 16 + 4 * p, 3, f->nq[p]);
+        if (spec_x) {
+            for (int k = 0; k < 4; ++k) region(oa, f->o_x + sizeof(double) * C * k, dmisc + 16, 2, n1);
+            for (int k = 0; k < 3; ++k) region(oa, f->o_X + sizeof(double) * C * k, dmisc + 16, 2, n1);
+        }
+        const size_t tpb = spec_B ? 1024 : 256;   // threads of the workgroups that will do it: four words each
+        oa.gx = (int)((3 * C + 4 * tpb - 1) / (4 * tpb));
+        if ((r = plain_signal_next(c, &oa.sig)) < 0) return r;
+        seqA = oa.sig.seq;
+        if (spec_B) {
+            OutArgs& oj = H->outJ;
+            oj = OutArgs{};
+            region(oj, f->o_misc + 128, nullptr, 8, 1);                          // misc[32..39]: the join's row count
+            region(oj, f->o_circ, dmisc + 32, 6, cap);
+            for (int k = 0; k < 4; ++k) region(oj, f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
+            for (int k = 0; k < 3; ++k) region(oj, f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
+            oj.gx = (int)((6 * C + 1023) / 1024);
+            if ((r = plain_signal_next(c, &oj.sig)) < 0) return r;
+            f->seqJ = oj.sig.seq;
+        }
+    }
     if ((r = plain_blit(s, hin, f->dev, (f->o_misc + 256) / 4)) < 0) return r;
-    if ((r = plain_side_join(pc, s)) < 0) return r;   // the second image's pack kernel (side stream) in front of the matcher
     pp.mark(1);
     if (g_tr_on) tt[3] = tr_now();
     const MatchProblem* dprob = reinterpret_cast<const MatchProblem*>(f->dev);
@@ -877,33 +886,8 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1, reinterpret_cast<const TriItem*>(f->dev + offsetof(FrameHead, tri)), &sp)) < 0) return r;
     } else if ((r = launch_sort(s, dprob, np, cap, need_general ? 0 : 1)) < 0) return r;
     pp.mark(2);
-    int seqA = 0;
-    // ---- ONE read-back: a copy kernel writes the counters and the rows that exist into the frame's pinned mirror
-    {
-        OutArgs oa{};
-        int nr = 0;
-        auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
-            oa.r[nr].src = reinterpret_cast<const uint32_t*>(f->dev + off);
-            oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host + (off - f->o_misc));
-            oa.r[nr].cnt = cnt; oa.r[nr].row_words = row_words; oa.r[nr].max_rows = max_rows;
-            ++nr;
-        };
-        region(f->o_misc, nullptr, 40, 1);
-        {   // the two images' own flags: words 40, 41 of the mirror
-            oa.r[nr].src = reinterpret_cast<const uint32_t*>(sq.v.bad); oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host) + 40;
-            oa.r[nr].cnt = nullptr; oa.r[nr].row_words = 1; oa.r[nr].max_rows = 1; ++nr;
-            oa.r[nr].src = reinterpret_cast<const uint32_t*>(st.v.bad); oa.r[nr].dst = reinterpret_cast<uint32_t*>(f->host) + 41;
-            oa.r[nr].cnt = nullptr; oa.r[nr].row_words = 1; oa.r[nr].max_rows = 1; ++nr;
-        }
-        for (int p = 0; p < np; ++p) region(f->o_sorted[p], dmisc + 16 + 4 * p, 3, f->nq[p]);
-        if (spec_x) {
-            for (int k = 0; k < 4; ++k) region(f->o_x + sizeof(double) * C * k, dmisc + 16, 2, n1);
-            for (int k = 0; k < 3; ++k) region(f->o_X + sizeof(double) * C * k, dmisc + 16, 2, n1);
-        }
-        const unsigned gx = (unsigned)((3 * C + 1023) / 1024);
-        if ((r = plain_signal_next(c, &oa.sig)) < 0) return r;
-        seqA = oa.sig.seq;
-        hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, oa);
+    if (!spec_B) {   // no join kernel to ride in
+        hipLaunchKernelGGL(plain_out_kernel, dim3((unsigned)(H->outA.n_regions * H->outA.gx)), dim3(256), 0, s, H->outA);
         HIP_TRY(hipGetLastError());
     }
     pp.mark(3);
@@ -919,37 +903,19 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
         ca.g_x = reinterpret_cast<const double*>(f->dev + f->o_x); ca.g_ldx = (int)C;
         ca.g_Xp = reinterpret_cast<const double*>(prv.dev + prv.o_X); ca.g_ldXp = prv.cap > 0 ? prv.cap : 1;
         ca.g_xc = reinterpret_cast<double*>(f->dev + f->o_xc); ca.g_Xpc = reinterpret_cast<double*>(f->dev + f->o_Xpc); ca.g_ldc = (int)C;
+        ca.ride = reinterpret_cast<const OutArgs*>(f->dev + offsetof(FrameHead, outA)); ca.ride_blocks = H->outA.n_regions * H->outA.gx;
         if ((r = launch_circle_table(s, ca, rs_tab, rs_tabn)) < 0) return r;
-        OutArgs ob{};
-        int nr = 0;
-        auto region = [&](size_t off, const int* cnt, int row_words, int max_rows) {
-            ob.r[nr].src = reinterpret_cast<const uint32_t*>(f->dev + off);
-            ob.r[nr].dst = reinterpret_cast<uint32_t*>(f->host + (off - f->o_misc));
-            ob.r[nr].cnt = cnt; ob.r[nr].row_words = row_words; ob.r[nr].max_rows = max_rows;
-            ++nr;
-        };
-        // the join and the gathered columns go out first, behind an event of their own: match_circle returns as soon as they are
-        // there, the RANSAC stage runs on behind the caller's gather loop
-        region(f->o_misc + 128, nullptr, 8, 1);                          // misc[32..39]: the join's row count
-        region(f->o_circ, dmisc + 32, 6, cap);
-        for (int k = 0; k < 4; ++k) region(f->o_xc + sizeof(double) * C * k, dmisc + 32, 2, cap);
-        for (int k = 0; k < 3; ++k) region(f->o_Xpc + sizeof(double) * C * k, dmisc + 32, 2, cap);
-        const unsigned gx = (unsigned)((6 * C + 1023) / 1024);
-        if ((r = plain_signal_next(c, &ob.sig)) < 0) return r;
-        f->seqJ = ob.sig.seq;
-        hipLaunchKernelGGL(plain_out_kernel, dim3(gx ? gx : 1, nr), dim3(256), 0, s, ob);
-        HIP_TRY(hipGetLastError());
         SolverParamsDev sp;
         fill_solver_params(&sp, &f->rs_p);
+        RefitMirror rm{};   // the pose and the inliers go into the mirror from the refit kernel itself, which signals
+        rm.res_src = reinterpret_cast<const uint32_t*>(f->dev + f->o_rs); rm.res_dst = reinterpret_cast<uint32_t*>(f->host + (f->o_rs - f->o_misc)); rm.res_words = 32;
+        rm.n_inl = reinterpret_cast<const int*>(f->dev + f->o_rs) + 2;
+        rm.inl_src = reinterpret_cast<const uint32_t*>(f->dev + f->o_rs + 128); rm.inl_dst = reinterpret_cast<uint32_t*>(f->host + (f->o_rs - f->o_misc) + 128); rm.max_inl = cap;
+        if ((r = plain_signal_next(c, &rm.sig)) < 0) return r;
+        f->seqB = rm.sig.seq;
         if ((r = launch_ransac(s, reinterpret_cast<const SolverItem*>(f->dev + offsetof(FrameHead, rs)), 1, f->rs_p.ransac_iter, f->rs_seed, sp,
-                               rs_queue, c->gn_split ? c->gn_split : 1, cap)) < 0) return r;
-        nr = 0;
-        region(f->o_rs, nullptr, 32, 1);
-        region(f->o_rs + 128, reinterpret_cast<const int*>(f->dev + f->o_rs) + 2, 1, cap);
-        if ((r = plain_signal_next(c, &ob.sig)) < 0) return r;
-        f->seqB = ob.sig.seq;
-        hipLaunchKernelGGL(plain_out_kernel, dim3((unsigned)((C + 1023) / 1024 ? (C + 1023) / 1024 : 1), nr), dim3(256), 0, s, ob);
-        HIP_TRY(hipGetLastError());
+                               rs_queue, c->gn_split ? c->gn_split : 1, cap, &rm,
+                               reinterpret_cast<const OutArgs*>(f->dev + offsetof(FrameHead, outJ)), H->outJ.n_regions * H->outJ.gx)) < 0) return r;
         f->have_B = true; f->pending_B = true; f->pending_J = true;
     }
     if (g_tr_on) tt[4] = tr_now();

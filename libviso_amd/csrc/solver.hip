@@ -23,6 +23,8 @@ struct SolverArgs {
     int* queue;   // [0] = number of undecided hypotheses, ZERO when the chain starts (zeroed at allocation, and again by
                   //       ransac_rot_kernel -- the kernel behind the list's only reader -- after saving it to [1]);
                   // [1] = the last chain's count (diagnostics); [2..] = item * iters + h of each undecided hypothesis (any order)
+    RefitMirror mir;   // plain family, n_items == 1: the refit kernel leaves the results in pinned host memory and signals (sig.flag == null: no)
+    const OutArgs* ride; int ride_blocks;   // plain family: a copy-out of the kernel BEFORE the chain rides in ransac_hyp_kernel's launch (common.h, OutArgs)
 };
 
 // ---- stage 0: the sample triples -- no kernel of their own any more --------------------------------------------------
@@ -42,6 +44,10 @@ struct SolverArgs {
 
 __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.ride) {   // uniform
+        const unsigned nhb = (unsigned)((a.n_items * a.iters + 255) / 256);
+        if (blockIdx.x >= nhb) { plain_out_blocks(*a.ride, blockIdx.x - nhb); return; }
+    }
     if (gid >= a.n_items * a.iters) return;
     // a few hundred waves on a serial fp64 chain, usually beside another batch's matcher kernels: win the
     // instruction-issue arbitration on the SIMD (the chain's latency is what the batch waits for)
@@ -738,21 +744,38 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
         refit_item(a, item, tr_s, red, scratch);
         __syncthreads();
     }
+    if (a.mir.sig.flag) {   // uniform (one item, one workgroup): what this workgroup has just written, into the call's mirror
+        __threadfence_block();
+        __syncthreads();
+        const RefitMirror& M = a.mir;
+        for (int i = threadIdx.x; i < M.res_words; i += REFIT_THREADS) M.res_dst[i] = M.res_src[i];
+        int n = *M.n_inl;
+        n = n < 0 ? 0 : n > M.max_inl ? M.max_inl : n;
+        for (int i = threadIdx.x; i < n; i += REFIT_THREADS) M.inl_dst[i] = M.inl_src[i];
+        plain_signal_done(M.sig, gridDim.x);
+    }
 }
 
 
 int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int iters,
-                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points) {
+                  unsigned long long seed, const SolverParamsDev& sp, int* queue, int split, int max_points, const RefitMirror* mir,
+                  const OutArgs* ride, int ride_blocks) {
     if (n_items <= 0) return VISO_OK;
+    if (mir && n_items != 1) { viso_set_error("ransac: a mirror is for one item"); return VISO_ERR_ARG; }
     SolverArgs a;
     a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
+    a.mir = RefitMirror{};
+    if (mir) a.mir = *mir;
+    a.ride = nullptr; a.ride_blocks = 0;
+    if (ride && ride_blocks > 0 && (long long)n_items * iters > 0) { a.ride = ride; a.ride_blocks = ride_blocks; }
+    else if (ride) { viso_set_error("ransac: nothing for the copy-out to ride in"); return VISO_ERR_ARG; }
     a.split = split >= 1 && split <= 100 ? split : VISO_GN_SPLIT;
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
         // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
         // 200 waves go to 50 CUs instead of one to each of 200
-        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256) + (unsigned)a.ride_blocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         // one wave per undecided hypothesis.  After 10 iterations 1-2 % of them are undecided (room for 2.5 %); a shorter
         // first stage hands on more (the waves are light: 117 VGPRs), so the grid grows with what can be expected; waves
@@ -1003,11 +1026,14 @@ extern "C" int viso_ransac_minimize_reproj(const double* X, const double* obs, i
     // one frame's 50 hypotheses are ONE wave of the lane-per-hypothesis kernel (5 us per iteration): hand over to the
     // wave-per-hypothesis kernel after the first iteration (2.7 us each, all hypotheses side by side) unless a split was asked
     // for (viso_ctx_set_gn_split): 203 -> 183 us per call (tools/dropin_probe.py, GN_SPLIT sweep); same hypotheses bit for bit
-    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split ? c->gn_split : 1, m)) < 0) return r;
-    pp.mark(2);
     PlainSignal sig_;
     if ((r = plain_signal_next(c, &sig_)) < 0) return r;
-    if ((r = plain_blit(c->stream, dout, hout, 32, it.n_inl, 1, m, &sig_)) < 0) return r;
+    RefitMirror mir{};   // the result block and the inliers go into pinned memory from the refit kernel itself, which signals
+    mir.res_src = reinterpret_cast<const uint32_t*>(dout); mir.res_dst = reinterpret_cast<uint32_t*>(hout); mir.res_words = 32;
+    mir.n_inl = it.n_inl; mir.inl_src = reinterpret_cast<const uint32_t*>(dout + 128); mir.inl_dst = reinterpret_cast<uint32_t*>(hout + 128); mir.max_inl = m;
+    mir.sig = sig_;
+    if ((r = launch_ransac(c->stream, ditem, 1, iters, seed, sp, dqueue, c->gn_split ? c->gn_split : 1, m, &mir)) < 0) return r;
+    pp.mark(2);
     pp.wait_begin();
     if ((r = plain_signal_wait(c, c->stream, sig_.seq)) < 0) return r;
     pp.wait_end();

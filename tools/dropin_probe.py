@@ -8,8 +8,11 @@ kp = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 import os
 if os.environ.get("GN_SPLIT"): libviso_amd.set_gn_split(int(os.environ["GN_SPLIT"]))
 seq = synth.make_sequence(1000, nf, n_kp=kp)
+if os.environ.get("DIRECT") == "1": drop_in.plain_speculate(False)   # every call does its own work
 # warm
 drop_in.run(seq["kp"][:4], seq["desc"][:4], seq["n"][:4], seq["F"], seq["param"], seed=1)
+if os.environ.get("VISO_PLAIN_TRACE") == "1":   # the first calls create streams and allocate: their own lines, not in the loop's averages
+    print("(warm-up calls:)", file=sys.stderr); libviso_amd.load().viso_plain_trace_dump(); print("(the loop:)", file=sys.stderr)
 o = drop_in.run(seq["kp"], seq["desc"], seq["n"], seq["F"], seq["param"], seed=1)
 import ctypes
 try: libviso_amd.load().viso_plain_trace_dump()
