@@ -485,8 +485,9 @@ static int plain_finish(viso_ctx* c, PlainCache* pc, int vi, const float* d, hip
     PlainSlot& s = pc->slot[vi];
     const int n = s.n, dlen = s.dlen;
     const double ta0 = g_tr_on > 0 ? tr_now() : 0;
-    // (the rows in two halves, the first packed while the second is copied: two more launches on the host for 6 us less of
-    // the GPU's chain -- 2 356 against 2 337 frames/s, inside the noise; not kept)
+    // (the rows in two parts, the first packed while the second is copied -- halves in round 5: 2 356 against 2 337 frames/s; 5/8 + 3/8
+    // of the call's last image in round 6: 2 929 against 2 932, four alternating runs each -- one more launch on the host for a few us
+    // less of the GPU's chain: inside the noise both times; not kept)
     big_copy(s.pin + s.o_desc, d, sizeof(float) * (size_t)n * dlen);
     const double ta1 = g_tr_on > 0 ? tr_now() : 0;
     int r;
