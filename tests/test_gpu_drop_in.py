@@ -263,6 +263,21 @@ def test_a_stereo_pair_that_is_not_rectified_where_rectified_ones_were_expected(
         assert np.array_equal(state["lr"], want)
 
 
+def test_an_image_against_itself_and_against_a_copy_of_itself(viso, oracle, seq):
+    """Both sides of a call the same arrays (one upload serves both), then the same bytes in other arrays (found resident),
+    with and without the image cache: the oracle's matches every time."""
+    tm = MatchParams.temporal()
+    for cache in (True, False):
+        drop_in.plain_cache(cache)
+        for t in (2, 3):
+            n = seq["n"][t, 0]
+            kp, d = np.ascontiguousarray(seq["kp"][t, 0, :n]), np.ascontiguousarray(seq["desc"][t, 0, :n])
+            want = oracle.match_desc(kp, kp, d, d, tm)
+            assert np.array_equal(libviso_amd.match_desc(kp, kp, d, d, tm), want)
+            assert np.array_equal(libviso_amd.match_desc(kp, kp.copy(), d, d.copy(), tm), want)
+            assert np.array_equal(libviso_amd.match_desc(kp.copy(), kp, d.copy(), d, tm), want)
+
+
 def test_frames_of_changing_size_and_empty_images(viso, oracle):
     """Keypoint counts that change from frame to frame (the frame's blocks are re-laid out), an image without keypoints."""
     s = synth.make_sequence(3, 9, n_kp=300, width=500, height=200, ragged=True)
