@@ -724,8 +724,8 @@ def main():
                 "equals_batch_family": same, "max_abs_tr_diff_vs_batch_family": tr_err,
                 "plain_family_stats": st_plain,
                 "bound": "one frame = one unavoidable round trip (the stereo call: 2 x 0.98 MB of descriptors from pageable memory into a pinned "
-                         "shadow, then pulled over PCIe by the pack kernel) + a dependent chain of ~20 small kernels (sort, pack, 3 match_desc problems, "
-                         "sorts, join, RANSAC/GN) of ~350 us on an otherwise idle GPU; the later calls of the frame compare their arguments with what "
+                         "shadow, then pulled over PCIe by the pack kernel) + a dependent chain of 13 small kernels (sort_kp, 2 x pack, head copy, one kernel for "
+                         "the 3 match_desc problems, overflow, sort, join, 5 x RANSAC/GN) of ~210 us on an otherwise idle GPU; the later calls of the frame compare their arguments with what "
                          "the stereo call assumed (memcmp) and return"}
 
     # ---- streaming: every step consumes fresh host frames (pinned, asynchronous, stream ordered) -------------
