@@ -67,7 +67,15 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total, int*
     return base + incl - v;
 }
 
+// LDS = true (the tables fit the CU's LDS -- every list of fewer than CIRCT_LDS_TABN keys): six tables there, key -> row AND
+// key -> the row's value, so that a row of match_lr is joined by three LDS lookups behind one global load, and the thread
+// that finds a joined row gathers its columns on the spot (no second pass over the rows).  The kernel is a chain of
+// dependent memory operations on one workgroup: with the tables in global scratch it was seven L2 round trips long
+// (18 us per frame of the per-call loop; ~10 with the tables in LDS).  LDS = false: three key -> row tables in `tab`.
+#define CIRCT_LDS_TABN 6144   // 6 tables x 4 B x 6144 = 144 KB of the CU's 160
+template <bool LDS>
 __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs a, int* tab, int tabn) {
+    extern __shared__ int s_tab[];
     __shared__ int scratch[16];
     __shared__ int s_dup;
     if (blockIdx.x > 0) { plain_out_blocks(*a.ride, blockIdx.x - 1); return; }   // riders: the copy-out of the kernel before (common.h, OutArgs)
@@ -75,27 +83,33 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
     if (a.n_lrp_p) a.n_lrp = *a.n_lrp_p;
     if (a.n11_p) a.n11 = *a.n11_p;
     if (a.n22_p) a.n22 = *a.n22_p;
-    int* t11 = tab; int* tlrp = tab + tabn; int* t22 = tab + 2 * tabn;
+    int* const T = LDS ? s_tab : tab;
+    int* t11 = T; int* tlrp = T + tabn; int* t22 = T + 2 * tabn;
+    int* v11 = T + 3 * tabn; int* vlrp = T + 4 * tabn; int* v22 = T + 5 * tabn;   // LDS only: the rows' values ([1] of the row)
     if (threadIdx.x == 0) s_dup = 0;
-    for (int i = threadIdx.x; i < 3 * tabn; i += CIRCT_THREADS) tab[i] = -1;
+    for (int i = threadIdx.x; i < 3 * tabn; i += CIRCT_THREADS) T[i] = -1;
     __syncthreads();
     int dup = 0;
     for (int j = threadIdx.x; j < a.n11; j += CIRCT_THREADS) {
-        const int key = a.m11[3 * j];
+        const int key = a.m11[3 * j], val = LDS ? a.m11[3 * j + 1] : 0;
         if (key < 0 || key >= tabn || atomicCAS(&t11[key], -1, j) != -1) dup = 1;
+        else if (LDS) v11[key] = val;
     }
     for (int k = threadIdx.x; k < a.n_lrp; k += CIRCT_THREADS) {
-        const int key = a.lrp[3 * k];
+        const int key = a.lrp[3 * k], val = LDS ? a.lrp[3 * k + 1] : 0;
         if (key < 0 || key >= tabn || atomicCAS(&tlrp[key], -1, k) != -1) dup = 1;
+        else if (LDS) vlrp[key] = val;
     }
     for (int l = threadIdx.x; l < a.n22; l += CIRCT_THREADS) {
-        const int key = a.m22[3 * l];
+        const int key = a.m22[3 * l], val = LDS ? a.m22[3 * l + 1] : 0;
         if (key < 0 || key >= tabn || atomicCAS(&t22[key], -1, l) != -1) dup = 1;
+        else if (LDS) v22[key] = val;
     }
     if (dup) s_dup = 1;
     __threadfence_block();
     __syncthreads();
     int running = 0;
+    const bool gather_here = LDS && a.g_x != nullptr && !s_dup;   // uniform
     if (s_dup) {   // arbitrary lists: the literal loops
         for (int base = 0; base < a.n_lr; base += CIRCT_THREADS) {
             const int i = base + threadIdx.x;
@@ -113,26 +127,39 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
                 ileft = a.lr[3 * i]; iright = a.lr[3 * i + 1];
                 const int j = (ileft >= 0 && ileft < tabn) ? t11[ileft] : -1;
                 if (j >= 0) {
-                    ileft_prev = a.m11[3 * j + 1];
+                    ileft_prev = LDS ? v11[ileft] : a.m11[3 * j + 1];
                     k = (ileft_prev >= 0 && ileft_prev < tabn) ? tlrp[ileft_prev] : -1;
                     if (k >= 0) {
-                        iright_prev = a.lrp[3 * k + 1];
+                        iright_prev = LDS ? vlrp[ileft_prev] : a.lrp[3 * k + 1];
                         const int l = (iright >= 0 && iright < tabn) ? t22[iright] : -1;
-                        ok = l >= 0 && a.m22[3 * l + 1] == iright_prev;
+                        ok = l >= 0 && (LDS ? v22[iright] : a.m22[3 * l + 1]) == iright_prev;
                     }
                 }
+            }
+            double gv[7];
+            if (gather_here && ok) {   // the joined row's columns, asked for before the scan's barriers
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = a.g_x[(size_t)r * a.g_ldx + i];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gv[4 + r] = a.g_Xp[(size_t)r * a.g_ldXp + k];
             }
             int total;
             const int o = running + block_exclusive_scan_1024(ok, &total, scratch);
             if (ok && o < a.cap) {
                 a.rows[6 * o + 0] = ileft; a.rows[6 * o + 1] = iright; a.rows[6 * o + 2] = ileft_prev; a.rows[6 * o + 3] = iright_prev;
                 a.rows[6 * o + 4] = i; a.rows[6 * o + 5] = k;
+                if (gather_here) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.g_xc[(size_t)r * a.g_ldc + o] = gv[r];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) a.g_Xpc[(size_t)r * a.g_ldc + o] = gv[4 + r];
+                }
             }
             running += total;
         }
     }
     if (threadIdx.x == 0) *a.out_n = running;
-    if (a.g_x) {   // uniform: the gather of the joined rows' columns (the rows were written by this workgroup)
+    if (a.g_x && !gather_here) {   // uniform: the gather of the joined rows' columns (the rows were written by this workgroup)
         __threadfence_block();
         __syncthreads();
         const int n = running < a.cap ? running : a.cap;
@@ -147,7 +174,18 @@ __global__ __launch_bounds__(CIRCT_THREADS) void circle_table_kernel(CircleArgs 
 }
 
 int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn) {
-    hipLaunchKernelGGL(circle_table_kernel, dim3(1 + (a.ride ? a.ride_blocks : 0)), dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
+    const dim3 grid(1 + (a.ride ? a.ride_blocks : 0));
+    if (tabn > 0 && tabn <= CIRCT_LDS_TABN) {
+        const size_t lds = sizeof(int) * 6 * (size_t)tabn;
+        static bool attr_set = false;   // (under the PlainLock)
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)circle_table_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 6 * CIRCT_LDS_TABN)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(circle_table_kernel<true>, grid, dim3(CIRCT_THREADS), lds, s, a, tab, tabn);
+    } else {
+        hipLaunchKernelGGL(circle_table_kernel<false>, grid, dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
+    }
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }

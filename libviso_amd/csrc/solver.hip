@@ -570,6 +570,20 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
     return v;
 }
 
+#ifdef VISO_DEBUG_VARIANTS   // timing aid (tools/experiments/refit_phases.py): 100 MHz time stamps of the refit's phases, item 0
+__device__ unsigned long long viso_dbg_clk[16];
+extern "C" int viso_debug_refit_clocks(unsigned long long* out16) {
+    (void)hipDeviceSynchronize();
+    const hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(viso_dbg_clk), sizeof(unsigned long long) * 16, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { fprintf(stderr, "viso_debug_refit_clocks: %s\n", hipGetErrorString(e)); return VISO_ERR_HIP; }
+    return VISO_OK;
+}
+#define DBG_CLK(I) do { if (threadIdx.x == 0 && item == 0) viso_dbg_clk[I] = wall_clock64(); } while (0)
+#define DBG_SET(I, V) do { if (threadIdx.x == 0 && item == 0) viso_dbg_clk[I] = (V); } while (0)
+#else
+#define DBG_CLK(I) do {} while (0)
+#define DBG_SET(I, V) do {} while (0)
+#endif
 // minimize_reproj over an arbitrary active list, one workgroup.  Every thread
 // accumulates its points' contribution to the 21+6 sums, the workgroup reduces
 // them (wave shuffles, then a fixed-order sum over the waves in LDS), the first
@@ -587,6 +601,9 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
     const int row = lane >> 3, col = lane & 7;       // wave 0: this lane's entry of [A | b] (row < 6, col < 7)
     if (n <= 0) return 0;
     for (int it = 0; it < 100; ++it) {
+#ifdef VISO_DEBUG_VARIANTS
+        if (threadIdx.x == 0 && blockIdx.x == 0) viso_dbg_clk[7] = (unsigned long long)(it + 1);
+#endif
         double tr[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) tr[j] = uni(tr_s[j]);
@@ -669,6 +686,7 @@ __device__ int gn_block(const double* X, const double* obs, int ld, const int* a
 
 // ---- stage 3: best hypothesis -> support set -> refit -> final support ------
 __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* red, int* scratch) {
+    DBG_CLK(0);
     const SolverItem S = a.items[item];
     const int m = *S.m_ptr;
     if (m < 3) {   // sequence_odometry's guard (:1283); randomsample(3,m) would not return
@@ -712,19 +730,24 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
     double tr[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
+    DBG_CLK(1);
     int n = block_inliers(tr, a.sp, S.X, S.obs, S.ld, m, S.inl, scratch, nullptr);
     __syncthreads();
+    DBG_CLK(2);
+    DBG_SET(6, (unsigned long long)n);
     int ok = 0;
     if (n >= 6) {
         __threadfence_block();
         ok = gn_block(S.X, S.obs, S.ld, S.inl, n, tr_s, a.sp, red);   // :1572
         __syncthreads();
+        DBG_CLK(3);
         if (ok) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) tr[j] = tr_s[j];
             n = block_inliers(tr, a.sp, S.X, S.obs, S.ld, m, S.inl, scratch, nullptr);   // :1575-1576
         }
     }
+    DBG_CLK(4);
     if (threadIdx.x == 0) {
         for (int j = 0; j < 6; ++j) S.tr[j] = tr_s[j];
         *S.ok = ok;
@@ -754,6 +777,9 @@ __global__ __launch_bounds__(REFIT_THREADS) void ransac_refit_kernel(SolverArgs 
         for (int i = threadIdx.x; i < n; i += REFIT_THREADS) M.inl_dst[i] = M.inl_src[i];
         plain_signal_done(M.sig, gridDim.x);
     }
+#ifdef VISO_DEBUG_VARIANTS
+    if (threadIdx.x == 0 && blockIdx.x == 0) viso_dbg_clk[5] = wall_clock64();
+#endif
 }
 
 
