@@ -177,11 +177,8 @@ int launch_circle_table(hipStream_t s, const CircleArgs& a, int* tab, int tabn) 
     const dim3 grid(1 + (a.ride ? a.ride_blocks : 0));
     if (tabn > 0 && tabn <= CIRCT_LDS_TABN) {
         const size_t lds = sizeof(int) * 6 * (size_t)tabn;
-        static bool attr_set = false;   // (under the PlainLock)
-        if (!attr_set) {
+        if (lds > 40 * 1024)   // (per device, and cheap: asked for whenever the launch needs it, like launch_sort does)
             HIP_TRY(hipFuncSetAttribute((const void*)circle_table_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 6 * CIRCT_LDS_TABN)));
-            attr_set = true;
-        }
         hipLaunchKernelGGL(circle_table_kernel<true>, grid, dim3(CIRCT_THREADS), lds, s, a, tab, tabn);
     } else {
         hipLaunchKernelGGL(circle_table_kernel<false>, grid, dim3(CIRCT_THREADS), 0, s, a, tab, tabn);
