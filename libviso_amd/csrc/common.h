@@ -233,7 +233,7 @@ __device__ __forceinline__ void plain_signal_done(const PlainSignal& g, unsigned
 // ---- results out: every region's rows that exist (counts on the device) into the call's pinned mirror ----------------------
 // A workgroup's path to host memory is narrow (a single one needs 15 us for what 39 spread over the chip write in 4), so the
 // copy is many small workgroups -- and where the chain has a next kernel they RIDE in its launch as extra workgroups (the
-// copy-out of the sort kernel's lists in the join kernel's launch, the join's in ransac_hyp_kernel's): they depend on the
+// copy-out of the sort kernel's lists in the join kernel's launch, the join's in ransac_coop_kernel's): they depend on the
 // kernel before, not on the one they ride in, and the 8.5 us + launch gap of a copy kernel of their own leave the chain.
 // The last kernel of the chain, ransac_refit_kernel, writes its few hundred bytes itself (RefitMirror).
 struct OutRegion { const uint32_t* src; uint32_t* dst; const int* cnt; int row_words, max_rows; };

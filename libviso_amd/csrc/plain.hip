@@ -10,9 +10,10 @@
 // pinned host shadow of what the caller passed; an image is recognised by COMPARING its bytes with a shadow (memcmp of
 // n, keypoints and descriptors: exact, no hashing), which a core does at 40-75 GB/s where the upload runs at 20-45 and
 // drags sort_kp_kernel + pack_desc_kernel behind it (tools/h2d_probe.hip, profiles/r05_drop_in.txt).  A call's small
-// inputs travel in ONE host-to-device copy from pinned memory, its results in ONE device-to-host copy behind ONE
-// synchronize; kernels that cannot have work (the other call kind's, the general path's when both images are known
-// to fit the u16 rows) are not launched.
+// inputs travel in ONE copy kernel's read of a pinned block, its results into a pinned mirror by copy workgroups that ride in
+// the chain's next launch (common.h, OutArgs) and signal the host through a pinned word (PlainSignal) -- no copy engine, no
+// synchronize; kernels that cannot have work (the other call kind's, the general path's when both images are known to
+// fit the u16 rows, the wide-band stereo kernel after rectified pairs) are not launched.
 #include "common.h"
 
 #include <stdio.h>
@@ -188,8 +189,6 @@ struct PlainFrame {
     bool have_B, pending_B, used_circ, used_rs;
     int n_circ;                            // rows of the join (host, once B has been waited for)
     viso_param rs_p; uint64_t rs_seed, rs_frame;
-    hipEvent_t evA;                        // (events of round 5's waits: the copy-out kernels signal themselves now, PlainSignal)
-    hipEvent_t evJ;
     int seqJ, seqB;                        // sequence numbers of the join's copy-out (match_circle waits for this one only; the RANSAC
                                            // stage runs on) and of the RANSAC stage's copy-out
     bool pending_J;
@@ -311,8 +310,6 @@ void plain_cache_free(viso_ctx* c) {
     for (int i = 0; i < 3; ++i) {
         if (c->plain->frame[i].host) (void)hipHostFree(c->plain->frame[i].host);
         if (c->plain->frame[i].dev) (void)hipFree(c->plain->frame[i].dev);
-        if (c->plain->frame[i].evA) (void)hipEventDestroy(c->plain->frame[i].evA);
-        if (c->plain->frame[i].evJ) (void)hipEventDestroy(c->plain->frame[i].evJ);
     }
     free(c->plain);
     c->plain = nullptr;
@@ -543,8 +540,6 @@ static int frame_reserve(viso_ctx* c, PlainFrame& f, int cap) {
         HIP_TRY(hipHostMalloc((void**)&f.host, want, hipHostMallocCoherent));   // read by the host right behind the signal, possibly before the kernel has retired
         f.host_bytes = want;
     }
-    if (!f.evA) HIP_TRY(hipEventCreateWithFlags(&f.evA, hipEventDisableTiming));
-    if (!f.evJ) HIP_TRY(hipEventCreateWithFlags(&f.evJ, hipEventDisableTiming));
     f.cap = cap;
     return VISO_OK;
 }
@@ -825,7 +820,7 @@ static int match_run(viso_ctx* c, PlainCache* pc, PlainProf& pp, int iq, int it,
     }
     // ---- the copy-outs into the frame's pinned mirror (common.h, OutArgs): the lists (and x, X) behind the sort kernel -- riding in
     // the join kernel's launch when the frame has one, a kernel of their own otherwise; the join and the gathered columns behind
-    // the join kernel, riding in ransac_hyp_kernel's launch.  Each signals: match_circle returns as soon as the join is there,
+    // the join kernel, riding in ransac_coop_kernel's launch.  Each signals: match_circle returns as soon as the join is there,
     // the RANSAC stage runs on behind the caller's gather loop
     int seqA = 0;
     {

@@ -24,7 +24,8 @@ struct SolverArgs {
                   //       ransac_rot_kernel -- the kernel behind the list's only reader -- after saving it to [1]);
                   // [1] = the last chain's count (diagnostics); [2..] = item * iters + h of each undecided hypothesis (any order)
     RefitMirror mir;   // plain family, n_items == 1: the refit kernel leaves the results in pinned host memory and signals (sig.flag == null: no)
-    const OutArgs* ride; int ride_blocks;   // plain family: a copy-out of the kernel BEFORE the chain rides in ransac_hyp_kernel's launch (common.h, OutArgs)
+    const OutArgs* ride; int ride_blocks;   // plain family: a copy-out of the kernel BEFORE the chain rides in ransac_coop_kernel's launch (common.h, OutArgs):
+    int coop_blocks;                         // ... as the workgroups behind the kernel's own coop_blocks
 };
 
 // ---- stage 0: the sample triples -- no kernel of their own any more --------------------------------------------------
@@ -44,10 +45,6 @@ struct SolverArgs {
 
 __global__ __launch_bounds__(256) void ransac_hyp_kernel(SolverArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a.ride) {   // uniform
-        const unsigned nhb = (unsigned)((a.n_items * a.iters + 255) / 256);
-        if (blockIdx.x >= nhb) { plain_out_blocks(*a.ride, blockIdx.x - nhb); return; }
-    }
     if (gid >= a.n_items * a.iters) return;
     // a few hundred waves on a serial fp64 chain, usually beside another batch's matcher kernels: win the
     // instruction-issue arbitration on the SIMD (the chain's latency is what the batch waits for)
@@ -152,10 +149,13 @@ __global__ __launch_bounds__(256) void ransac_coop_kernel(SolverArgs a) {
     // a SMALL grid walks the list of undecided hypotheses (a launch with one wave per hypothesis would push
     // thousands of workgroups, nearly all of which leave at once, through a GPU that is busy with another batch's
     // matcher)
+    // riders (plain family): the copy-out of the join kernel's results.  Here rather than in ransac_hyp_kernel's launch: that
+    // kernel is 9 us of one wave's work, the copy-out 11 -- it set the kernel's duration, in the chain the caller waits for
+    if (a.ride && (int)blockIdx.x >= a.coop_blocks) { plain_out_blocks(*a.ride, blockIdx.x - (unsigned)a.coop_blocks); return; }
     const int n_undecided = a.queue[0];
     const int row = lane >> 3, col = lane & 7;       // this lane's entry of [A | b] (row < 6, col < 7)
     const int mrow = min(row, 5), mcol = min(col, 6);
-    for (int qi = (int)blockIdx.x * 4 + wv; qi < n_undecided; qi += (int)gridDim.x * 4) {
+    for (int qi = (int)blockIdx.x * 4 + wv; qi < n_undecided; qi += a.coop_blocks * 4) {
     const int gid = a.queue[2 + qi];
     const int item = gid / a.iters, h = gid % a.iters;
     const SolverItem S = a.items[item];
@@ -368,12 +368,14 @@ __device__ __forceinline__ float inl_add_abs(float acc, float a, float b) {   //
 __device__ __forceinline__ float inl_fma_abs0(float a, float b, float c) { float d; asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float inl_fma_abs1(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
-__global__ __launch_bounds__(64) void inlier_count_kernel(SolverArgs a, int chunks) {
+__global__ __launch_bounds__(64) void inlier_count_kernel(SolverArgs a, int chunks, int pg) {
     // ONE wave per workgroup: nothing is shared between waves, and a finished wave's slot is refilled at once — with four
     // waves per workgroup the waves of a CU started, reached their fp64 tail and ended together, and the latencies at both
     // ends (the chain of dependent loads at the start, the trip to the fp64 rotations at the end) were paid by idle SIMDs
     typedef unsigned long long u64;
-    const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    // pg > 1 (a launch of a frame or two: launch_inlier_count): the hypothesis pairs of a 64-point chunk go to pg waves instead
+    // of one -- a lone wave walks its pairs at the latency of their scalar loads, nothing else on its SIMD to hide it
+    const int pgi = blockIdx.x % pg, chunk = (blockIdx.x / pg) % chunks, item = blockIdx.x / (pg * chunks);
     const SolverItem S = a.items[item];
     const int lane = threadIdx.x;
     const int i = chunk * 64 + lane;
@@ -422,14 +424,15 @@ __global__ __launch_bounds__(64) void inlier_count_kernel(SolverArgs a, int chun
     for (int kb = 0; kb < npair; kb += 64) {   // blocks of 64 pairs: lane p of vcnt holds the counts of pair kb + p, 16 bits each
     int vcnt = 0;
     u64 qa = 0, qb = 0;   // per lane: pairs of the block whose first / second hypothesis tier 1 left undecided for the lane's point
-    const int ke = min(npair, kb + 64);
+    const int ke_all = min(npair, kb + 64);
+    const int kb0 = kb + (int)((long long)(ke_all - kb) * pgi / pg), ke = kb + (int)((long long)(ke_all - kb) * (pgi + 1) / pg);   // this wave's pairs of the block
     // did the two hypotheses of pair kb + lane converge?  Asked for here, used when the lane flushes the pair's counts: a
     // failed hypothesis (and the padding of an odd count) has the identity in the rotation store, is counted like any
     // other and dropped at the end — the loop has no case for it (the scalar unit issues one instruction per cycle for the
     // whole CU, as the four SIMDs do together: every scalar instruction of the loop counts like a vector one)
     const bool ok0 = kb + lane < ke && S.ok_h[2 * (kb + lane)] != 0;
     const bool ok1 = kb + lane < ke && 2 * (kb + lane) + 1 < iters && S.ok_h[2 * (kb + lane) + 1] != 0;
-    for (int kp = kb; kp < ke; ++kp) {
+    for (int kp = kb0; kp < ke; ++kp) {
         const crot_t F = Fall + (size_t)kp * (INL_PAIR_F / 2);
         const inl_f2 r0 = F[0], r1 = F[1], r2 = F[2], r3 = F[3], r4 = F[4], r5 = F[5], r6 = F[6], r7 = F[7], r8 = F[8],
                      tx = F[9], ty = F[10], tz = F[11];
@@ -504,7 +507,10 @@ static int launch_inlier_count(hipStream_t s, const SolverArgs& a, int max_point
     const int chunks = (max_points + 63) / 64;
     if (chunks <= 0) return VISO_OK;
     if ((long long)a.n_items * chunks > 0x7fffffffLL) { viso_set_error("ransac: too many points in one launch"); return VISO_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(a.n_items * chunks)), dim3(64), 0, s, a, chunks);
+    const int npair = (a.iters + 1) / 2;
+    int pg = 1;   // a launch that cannot fill the chip: more waves, fewer pairs each (the same verdicts, the same atomic adds)
+    if ((long long)a.n_items * chunks <= 512) pg = npair >= 20 ? 5 : npair >= 8 ? 2 : 1;
+    hipLaunchKernelGGL(inlier_count_kernel, dim3((unsigned)(a.n_items * chunks * pg)), dim3(64), 0, s, a, chunks, pg);
     HIP_TRY(hipGetLastError());
     return VISO_OK;
 }
@@ -792,25 +798,27 @@ int launch_ransac(hipStream_t s, const SolverItem* items_dev, int n_items, int i
     a.items = items_dev; a.n_items = n_items; a.iters = iters; a.seed = seed; a.sp = sp; a.queue = queue;
     a.mir = RefitMirror{};
     if (mir) a.mir = *mir;
-    a.ride = nullptr; a.ride_blocks = 0;
+    a.ride = nullptr; a.ride_blocks = 0; a.coop_blocks = 0;
     if (ride && ride_blocks > 0 && (long long)n_items * iters > 0) { a.ride = ride; a.ride_blocks = ride_blocks; }
     else if (ride) { viso_set_error("ransac: nothing for the copy-out to ride in"); return VISO_ERR_ARG; }
     a.split = split >= 1 && split <= 100 ? split : VISO_GN_SPLIT;
     const long long nh = (long long)n_items * iters;
     if (nh > 0x7fffffffLL) { viso_set_error("ransac: too many hypotheses in one launch"); return VISO_ERR_UNSUPPORTED; }
     if (nh > 0) {
-        // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
-        // 200 waves go to 50 CUs instead of one to each of 200
-        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256) + (unsigned)a.ride_blocks), dim3(256), 0, s, a);
-        HIP_TRY(hipGetLastError());
-        // one wave per undecided hypothesis.  After 10 iterations 1-2 % of them are undecided (room for 2.5 %); a shorter
-        // first stage hands on more (the waves are light: 117 VGPRs), so the grid grows with what can be expected; waves
-        // without an entry leave at once, entries beyond the grid are taken in further turns of the same waves
+        // ransac_coop_kernel's grid: one wave per undecided hypothesis.  After 10 iterations 1-2 % of them are undecided (room
+        // for 2.5 %); a shorter first stage hands on more (the waves are light: 117 VGPRs), so the grid grows with what can
+        // be expected; waves without an entry leave at once, entries beyond the grid are taken in further turns of the same
+        // waves (the kernel strides by coop_blocks: riders may sit behind them in the launch)
         const int div = a.split >= 10 ? 40 : a.split >= 6 ? 16 : a.split >= 4 ? 6 : 3;
         long long cb = (nh / div + 3) / 4;
         if (cb < 128) cb = 128;
         if (cb > (nh + 3) / 4) cb = (nh + 3) / 4;
-        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb), dim3(256), 0, s, a);
+        a.coop_blocks = (int)cb;
+        // four waves per workgroup: a 256-register wave halves what its SIMD can hold of another batch's matcher, so the
+        // 200 waves go to 50 CUs instead of one to each of 200
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ransac_coop_kernel, dim3((unsigned)cb + (unsigned)a.ride_blocks), dim3(256), 0, s, a);
         int ri = hipGetLastError() == hipSuccess ? VISO_OK : VISO_ERR_HIP;
         if (ri >= 0) ri = launch_inlier_count(s, a, max_points);
         if (ri < 0) {   // the chain broke behind ransac_hyp_kernel: the list would stay filled for the next one
