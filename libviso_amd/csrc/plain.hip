@@ -377,6 +377,8 @@ static long g_tr_n[3];
 static int g_tr_on = -1;
 static double g_acq_us[3];
 static long g_acq_n, g_acq_calls;
+static double g_wait_us[2];   // waits of the frame's later calls: [0] match_circle for the join, [1] ransac_minimize_reproj for the stage
+static long g_wait_n[2];
 static double tr_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" void viso_plain_trace_dump(void) {
     static const char* ph[6] = {"acquire_q", "acquire_t", "setup+blit_in", "launches", "wait", "copy_out"};
@@ -388,6 +390,10 @@ extern "C" void viso_plain_trace_dump(void) {
     }
     if (g_acq_n) fprintf(stderr, "uploads: %ld, rows into the shadow %.1f us, pack launch %.1f us; look-ups + keypoints + sort_kp launch %.1f us per call\n", g_acq_n,
                          g_acq_us[0] / g_acq_n, g_acq_us[1] / g_acq_n, g_acq_us[2] / (g_acq_calls > 0 ? g_acq_calls : 1));
+    if (g_wait_n[0] || g_wait_n[1])
+        fprintf(stderr, "waits behind the stereo call: match_circle for the join %.1f us (%ld), ransac_minimize_reproj for the stage %.1f us (%ld)\n",
+                g_wait_n[0] ? g_wait_us[0] / g_wait_n[0] : 0.0, g_wait_n[0], g_wait_n[1] ? g_wait_us[1] / g_wait_n[1] : 0.0, g_wait_n[1]);
+    memset(g_wait_us, 0, sizeof(g_wait_us)); memset(g_wait_n, 0, sizeof(g_wait_n));
     memset(g_acq_us, 0, sizeof(g_acq_us)); g_acq_n = 0; g_acq_calls = 0;
     memset(g_tr_us, 0, sizeof(g_tr_us)); memset(g_tr_n, 0, sizeof(g_tr_n));
 }
@@ -555,7 +561,9 @@ static void frame_reset(PlainFrame& f) {
 // the second part of a frame's chain has finished: its counters are in the mirror
 static int frame_wait_J(viso_ctx* c, PlainFrame& f) {   // the join (and the gathered columns) are in the mirror
     if (!f.pending_J) return VISO_OK;
+    const double tw0 = g_tr_on > 0 ? tr_now() : 0;
     { const int r_ = plain_signal_wait(c, c->stream, f.seqJ); if (r_ < 0) return r_; }
+    if (g_tr_on > 0) { g_wait_us[0] += tr_now() - tw0; g_wait_n[0] += 1; }
     f.pending_J = false;
     const int* om = reinterpret_cast<const int*>(f.host);
     f.n_circ = om[32];
@@ -563,7 +571,9 @@ static int frame_wait_J(viso_ctx* c, PlainFrame& f) {   // the join (and the gat
 }
 static int frame_wait_B(viso_ctx* c, PlainFrame& f) {
     if (!f.pending_B) return VISO_OK;
+    const double tw0 = g_tr_on > 0 ? tr_now() : 0;
     { const int r_ = plain_signal_wait(c, c->stream, f.seqB); if (r_ < 0) return r_; }   // the chain's last kernel: everything before it on the stream is done
+    if (g_tr_on > 0) { g_wait_us[1] += tr_now() - tw0; g_wait_n[1] += 1; }
     f.pending_B = false; f.pending_J = false;
     const int* om = reinterpret_cast<const int*>(f.host);
     f.n_circ = om[32];
