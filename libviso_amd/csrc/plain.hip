@@ -377,6 +377,8 @@ static long g_tr_n[3];
 static int g_tr_on = -1;
 static double g_acq_us[3];
 static long g_acq_n, g_acq_calls;
+static double g_srv_us[2];    // temporal calls answered from the frame: [0] the two look-ups, [1] the rest
+static long g_srv_n;
 static double g_wait_us[2];   // waits of the frame's later calls: [0] match_circle for the join, [1] ransac_minimize_reproj for the stage
 static long g_wait_n[2];
 static double tr_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -393,6 +395,8 @@ extern "C" void viso_plain_trace_dump(void) {
     if (g_wait_n[0] || g_wait_n[1])
         fprintf(stderr, "waits behind the stereo call: match_circle for the join %.1f us (%ld), ransac_minimize_reproj for the stage %.1f us (%ld)\n",
                 g_wait_n[0] ? g_wait_us[0] / g_wait_n[0] : 0.0, g_wait_n[0], g_wait_n[1] ? g_wait_us[1] / g_wait_n[1] : 0.0, g_wait_n[1]);
+    if (g_srv_n) fprintf(stderr, "temporal calls answered from the frame: %ld, look-ups (byte comparison of both images) %.1f us, the rest %.1f us\n", g_srv_n, g_srv_us[0] / g_srv_n, g_srv_us[1] / g_srv_n);
+    g_srv_us[0] = g_srv_us[1] = 0; g_srv_n = 0;
     memset(g_wait_us, 0, sizeof(g_wait_us)); memset(g_wait_n, 0, sizeof(g_wait_n));
     memset(g_acq_us, 0, sizeof(g_acq_us)); g_acq_n = 0; g_acq_calls = 0;
     memset(g_tr_us, 0, sizeof(g_tr_us)); memset(g_tr_n, 0, sizeof(g_tr_n));
@@ -691,6 +695,7 @@ static int match_desc_locked(viso_ctx* c, PlainCache* pc, const float* kp1, int 
                     *out_n = m;
                     cur.used[p] = true;
                     pc->spec_served[0] += 1;
+                    if (g_tr_on > 0) { g_srv_us[0] += tt[2] - tt[0]; g_srv_us[1] += tr_now() - tt[2]; g_srv_n += 1; }
                     return VISO_OK;
                 }
         // the direct path it is; remember what a temporal call looks like, and whether it is the loop's
