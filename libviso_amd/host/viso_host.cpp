@@ -17,6 +17,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <memory>
 #include <thread>
 
 namespace viso {
@@ -64,33 +65,32 @@ void match_desc(const KeyPoints& kp1, const KeyPoints& kp2, const Descriptors& d
     const int dlen = d1.rows ? d1.cols : d2.cols;
     if (kp1.empty()) return;
     std::vector<float> k1 = kp2mat(kp1), k2 = kp2mat(kp2);
-    std::vector<int32_t> out(kp1.size() * 3);
+    // Match (Vec3i) is a contiguous int triple: the rows are written straight into the list (the adapter pushes them back one by one
+    // only because cv::Vec3i has no such guarantee on paper)
+    static_assert(sizeof(Match) == 3 * sizeof(int32_t), "Match must be three contiguous ints");
+    match.resize(kp1.size());
     int n = 0;
     viso_match_params mp = to_abi(sp);
     hip_check(viso_match_desc(k1.data(), (int)kp1.size(), k2.data(), (int)kp2.size(), d1.ptr(), d2.ptr(),
-                              dlen > 0 ? dlen : 1, &mp, out.data(), &n), "match_desc");
+                              dlen > 0 ? dlen : 1, &mp, &match[0][0], &n), "match_desc");
     match.resize((size_t)n);
-    for (int i = 0; i < n; ++i) match[(size_t)i] = {out[3 * i], out[3 * i + 1], out[3 * i + 2]};
 }
 
-static std::vector<int32_t> flat(const Matches& m) {
-    std::vector<int32_t> v(m.size() * 3);
-    for (size_t i = 0; i < m.size(); ++i) { v[3 * i] = m[i][0]; v[3 * i + 1] = m[i][1]; v[3 * i + 2] = m[i][2]; }
-    return v;
-}
+static const int32_t* rows_of(const Matches& m) { return m.empty() ? nullptr : &m[0][0]; }   // adapters/viso_hip_adapter.inc: &v[0][0]
 
 void match_circle(const Matches& match_lr, const Matches& match_lr_prev, const Matches& match11,
                   const Matches& match22, std::vector<Vec4i>& circ_match, Matches& match_pcl) {
-    std::vector<int32_t> a = flat(match_lr), b = flat(match_lr_prev), c = flat(match11), d = flat(match22);
-    int cap = (int)std::max<size_t>(16, match_lr.size() * 2), n = 0;
+    int cap = (int)match_lr.size() + 16, n = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        std::vector<int32_t> circ((size_t)cap * 4), pcl((size_t)cap * 2);
-        int r = viso_match_circle(a.data(), (int)match_lr.size(), b.data(), (int)match_lr_prev.size(),
-                                  c.data(), (int)match11.size(), d.data(), (int)match22.size(),
-                                  circ.data(), pcl.data(), cap, &n);
+        std::unique_ptr<int32_t[]> circ(new int32_t[(size_t)cap * 4]), pcl(new int32_t[(size_t)cap * 2]);
+        int r = viso_match_circle(rows_of(match_lr), (int)match_lr.size(), rows_of(match_lr_prev), (int)match_lr_prev.size(),
+                                  rows_of(match11), (int)match11.size(), rows_of(match22), (int)match22.size(),
+                                  circ.get(), pcl.get(), cap, &n);
         if (r == VISO_ERR_ARG && n > cap) { cap = n; continue; }   // duplicate keys produced more rows: retry
         hip_check(r, "match_circle");
         // the reference appends (push_back) to both outputs, :233-234
+        circ_match.reserve(circ_match.size() + (size_t)n);
+        match_pcl.reserve(match_pcl.size() + (size_t)n);
         for (int i = 0; i < n; ++i) {
             circ_match.push_back({circ[4 * i], circ[4 * i + 1], circ[4 * i + 2], circ[4 * i + 3]});
             match_pcl.push_back({pcl[2 * i], pcl[2 * i + 1], 0});
@@ -104,8 +104,7 @@ void collect_matches(const KeyPoints& kp1, const KeyPoints& kp2, const Matches& 
     x.create(4, (int)match.size());
     if (match.empty()) return;
     std::vector<float> k1 = kp2mat(kp1), k2 = kp2mat(kp2);
-    std::vector<int32_t> m = flat(match);
-    int r = viso_collect_matches(k1.data(), (int)kp1.size(), k2.data(), (int)kp2.size(), m.data(),
+    int r = viso_collect_matches(k1.data(), (int)kp1.size(), k2.data(), (int)kp2.size(), rows_of(match),
                                  (int)match.size(), x.ptr());
     if (r == VISO_ERR_ARG) throw std::out_of_range("collect_matches: match index out of range");   // vector::at
     hip_check(r, "collect_matches");
