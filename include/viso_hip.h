@@ -254,8 +254,9 @@ typedef struct viso_plain_times {
  *                  byte for byte what was assumed (the functions are pure: same results as the direct path, which any
  *                  other argument takes).  Guessing starts after the call sequence has been seen once and stops when a
  *                  guess goes unused.  viso_plain_speculate(0) / $VISO_PLAIN_SPECULATE=0: every call direct.
- *   waiting        a call returns when its results are in pinned host memory: its last kernel says so in a pinned word the
- *                  host spins on (a few microseconds sooner than hipStreamSynchronize sees it; after 20 ms the stream is
+ *   waiting        a call returns when its results are in pinned host memory: the workgroups that write them there (they ride in
+ *                  the launch of the chain's next kernel; the last kernel writes its own) say so in a pinned word the host
+ *                  spins on (a few microseconds sooner than hipStreamSynchronize sees it; after 20 ms the stream is
  *                  synchronised instead).  $VISO_PLAIN_SIGNAL=0: always hipStreamSynchronize.
  * Both only change when the work is done, never a result (tests/test_gpu_drop_in.py runs every combination).  The
  * speculation statistics: served[0..3] = calls answered from a frame (temporal match_desc, collect_matches,
@@ -267,7 +268,8 @@ int64_t viso_plain_general_reruns(void);   /* calls repeated because their launc
                                               after several rectified ones */
 int viso_plain_speculate(int enable);
 int viso_plain_speculate_stats(int64_t served_wasted[8]);
-/* $VISO_PLAIN_TRACE=1: host microseconds of viso_match_desc by phase; this prints and zeroes them (stderr). */
+/* $VISO_PLAIN_TRACE=1: host microseconds of viso_match_desc by phase, of the temporal calls answered from a frame, and the waits of
+   match_circle / ransac_minimize_reproj behind the stereo call; this prints and zeroes them (stderr). */
 void viso_plain_trace_dump(void);
 int viso_plain_profile(int enable);                        /* 1: zero the sums and start; 0: stop */
 int viso_plain_profile_get(int fn, viso_plain_times* out); /* fn: VISO_PLAIN_* */
