@@ -8,11 +8,33 @@
 #include "common.h"
 #include "match_dev.h"
 
+#ifdef VISO_DEBUG_VARIANTS   // (tools/experiments/frame_phases.py) time stamps of the phases of one interior tile of the first temporal problem, wave 0
+__device__ unsigned long long viso_dbg_frame_uclk[8];
+#define MU_CLK(I) do { if (mu_vblock == 1 + 8 * 12 && threadIdx.x == 0) viso_dbg_frame_uclk[I] = wall_clock64(); } while (0)
+#endif
 #define MU_KERNEL_SIG static __device__ __forceinline__ void match_union8_part(const BatchMatchArgs& a, const int mu_vblock)
 #define MU_BLOCK mu_vblock
 #define MU_NO_LAUNCHER
 #include "match_union8.hip"
 
+#ifdef VISO_DEBUG_VARIANTS   // timing aid (tools/experiments/frame_phases.py): 100 MHz time stamps of the phases of the stereo part's first tile
+__device__ unsigned long long viso_dbg_frame_clk[16];
+__device__ unsigned long long viso_dbg_frame_blk[2][256];   // start / end of every workgroup of the last launch
+extern "C" int viso_debug_frame_uclocks(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(viso_dbg_frame_uclk), sizeof(unsigned long long) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+}
+extern "C" int viso_debug_frame_blocks(unsigned long long* out512) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(viso_dbg_frame_blk), sizeof(unsigned long long) * 512, 0, hipMemcpyDeviceToHost) == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+}
+extern "C" int viso_debug_frame_clocks(unsigned long long* out16) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(viso_dbg_frame_clk), sizeof(unsigned long long) * 16, 0, hipMemcpyDeviceToHost) == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+}
+#define ST_CLK(I) do { if (st_vblock == 0 && threadIdx.x == 0) viso_dbg_frame_clk[I] = wall_clock64(); } while (0)
+#endif
+#define ST_GATE_PAIRS
 #define ST_KERNEL_SIG static __device__ __forceinline__ void match_stereo_part(const BatchMatchArgs& a, const int st_vblock)
 #define ST_BLOCK st_vblock
 #define ST_NO_LAUNCHER
@@ -20,8 +42,16 @@
 
 // at FIRST: match_union8's body reads its planes' shift from the kernel-argument segment at offsetof(BatchMatchArgs, r8s)
 __global__ __launch_bounds__(256) void match_frame_kernel(BatchMatchArgs at, BatchMatchArgs as, int n_stereo) {
+#ifdef VISO_DEBUG_VARIANTS
+    if (threadIdx.x == 0 && blockIdx.x < 256) { viso_dbg_frame_blk[0][blockIdx.x] = wall_clock64(); viso_dbg_frame_blk[1][blockIdx.x] = 0; }
+#endif
     if ((int)blockIdx.x < n_stereo) match_stereo_part(as, (int)blockIdx.x);
     else match_union8_part(at, (int)blockIdx.x - n_stereo);
+#ifdef VISO_DEBUG_VARIANTS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) atomicMax(&viso_dbg_frame_blk[1][blockIdx.x], (unsigned long long)wall_clock64());
+    if (blockIdx.x == 0 && threadIdx.x == 0) viso_dbg_frame_clk[8] = wall_clock64();
+    if ((int)blockIdx.x == n_stereo && threadIdx.x == 0) viso_dbg_frame_clk[9] = wall_clock64();   // the first union8 tile's end
+#endif
 }
 
 // at / as: the temporal and the stereo launch's arguments as launch_match_batch prepares them (as.bpp is set here, like

@@ -50,14 +50,33 @@ __device__ __forceinline__ uint32_t st_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// inclusive prefix sum over the wave (values < 2^16)
-__device__ __forceinline__ int st_scan_incl(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < VISO_WAVE; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+// inclusive prefix sum over the wave (values < 2^16): row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source add
+// 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- six DPP adds in place of six ds_bpermute round
+// trips.  A tile is a latency chain and the kernel is latency bound: its wave-wide steps are written for latency
+__device__ __forceinline__ int st_scan_incl(int v, int) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
+}
+// minimum / maximum of a float over the wave, to every lane: quad, half-row and row exchanges as DPP operands, then the four rows'
+// values as scalars (fminf / fmaxf ignore a NaN operand: the same result as any other order of the same operations)
+template <bool MAX>
+__device__ __forceinline__ float st_wave_ext(float v) {
+#define ST_EXT_STEP(CTRL) do { const float o_ = __uint_as_float(st_dpp<CTRL>(__float_as_uint(v))); v = MAX ? fmaxf(v, o_) : fminf(v, o_); } while (0)
+    ST_EXT_STEP(0xB1);    // quad_perm [1,0,3,2]
+    ST_EXT_STEP(0x4E);    // quad_perm [2,3,0,1]
+    ST_EXT_STEP(0x141);   // row_half_mirror
+    ST_EXT_STEP(0x140);   // row_mirror
+#undef ST_EXT_STEP
+    const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    const float d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
+    return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
 }
 
 __device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
@@ -67,6 +86,9 @@ __device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
     return f <= 0.f ? 0 : (f >= (float)(ST_NBY - 1) ? ST_NBY - 1 : (int)f);
 }
 
+#ifndef ST_CLK
+#define ST_CLK(I) do {} while (0)   // (match_frame.hip, debug builds: time stamps of the first tile's phases)
+#endif
 // (match_frame.hip includes this file with ST_KERNEL_SIG / ST_BLOCK defined: see match_union8.hip)
 #ifndef ST_KERNEL_SIG
 #define ST_KERNEL_SIG __global__ __launch_bounds__(ST_THREADS) void match_stereo_kernel(BatchMatchArgs a)
@@ -85,11 +107,19 @@ ST_KERNEL_SIG {
         tile = (slot % a.bpp) * ST_WAVES + wave;
         if (prob >= a.n_probs) return;
     }
+    ST_CLK(0);
     const MatchProblem P = a.probs[prob];
     const MatchParamsDev& mp = a.mp[P.pidx];
     if (mp.epi == 0) return;                        // temporal problems: the other kernels
-    if ((*P.q.bad | *P.t.bad) != 0) return;         // non-integer descriptors: the general kernel does this problem
+    // Everything that depends on the problem alone is asked for TOGETHER, ahead of the branches that need only part of it: a
+    // tile is a chain of dependent loads (problem -> counts -> query -> bucket starts -> window), the kernel is latency bound,
+    // and loads the compiler may not move across an early return each cost a round trip of their own (eight of them before
+    // the window arrived; five now).  (xinfo, rank[0] exist for any image, also one without keypoints: arrays of >= 1 entry.)
+    const int badq = *P.q.bad, badt = *P.t.bad;
     const int n1 = *P.q.n, n2 = *P.t.n;
+    const float tx0 = P.t.xinfo[0], tscale = P.t.xinfo[1];
+    const int trank0 = P.t.rank[0];
+    if ((badq | badt) != 0) return;                 // non-integer descriptors: the general kernel does this problem
     const int q0 = tile * ST_QPW;
     if (q0 >= n1) return;
     const int q1 = min(q0 + ST_QPW, n1);
@@ -99,15 +129,12 @@ ST_KERNEL_SIG {
     const bool live = j < q1;
     const float2 qv = live ? P.q.skp[j] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
     const int orig = live ? P.q.sidx[j] : -1;
+    float2 kp0 = make_float2(0.f, 0.f);             // the target image's first keypoint (Q1), with the queries: it waits for rank[0] only
+    if (n2 > 0) kp0 = P.t.skp[trank0];
     const float radius = mp.radius;
     const int K = mp.K;
     // ---- tile: x range -> window, y range -> band
-    float xa = qv.x, xb = qv.x, ya = qv.y, yb = qv.y;
-#pragma unroll
-    for (int m = 1; m < VISO_WAVE; m <<= 1) {
-        xa = fminf(xa, __shfl_xor(xa, m)); xb = fmaxf(xb, __shfl_xor(xb, m));
-        ya = fminf(ya, __shfl_xor(ya, m)); yb = fmaxf(yb, __shfl_xor(yb, m));
-    }
+    const float xa = st_wave_ext<false>(qv.x), xb = st_wave_ext<true>(qv.x), ya = st_wave_ext<false>(qv.y), yb = st_wave_ext<true>(qv.y);
     const bool ynan = __any(live && qv.y != qv.y);
     float band = __builtin_huge_valf();
     if (!ynan) band = epipolar_band(mp.F, mp.sampson_thresh, xa, xb, ya, yb, radius);
@@ -121,16 +148,14 @@ ST_KERNEL_SIG {
     int lo = 0, W = 0;
     if (n2 > 0 && xa == xa && radius >= 0.f) {
         const float slack = (fabsf(xa) + fabsf(xb) + fabsf(radius)) * 1e-6f + 1e-6f;
-        const float x0 = P.t.xinfo[0], scale = P.t.xinfo[1];
-        lo = P.t.bstart[bucket_of(xa - radius - slack, x0, scale)];
-        W = P.t.bstart[bucket_of(xb + radius + slack, x0, scale) + 1] - lo;
+        lo = P.t.bstart[bucket_of(xa - radius - slack, tx0, tscale)];
+        W = P.t.bstart[bucket_of(xb + radius + slack, tx0, tscale) + 1] - lo;
     }
     lo = __builtin_amdgcn_readfirstlane(lo);
     W = __builtin_amdgcn_readfirstlane(W);
     // Q1 (src/viso.cpp:693): (d <= radius && d < d0cut) as one unsigned compare of the bits of d (see match_union.hip)
     uint32_t thr = __float_as_uint(radius) + 1u;
     if (n2 > 0) {
-        const float2 kp0 = P.t.skp[P.t.rank[0]];
         const float d0 = l1_kp(qv.x, qv.y, kp0);
         if (d0 <= radius) thr = __float_as_uint(d0);
     }
@@ -145,6 +170,7 @@ ST_KERNEL_SIG {
     uint32_t d1 = 0xffffffffu, d2 = 0xffffffffu, bw = 0, tie = 0;
     int cnt_ub = 0, nscored = 0;
 
+    ST_CLK(1);
     for (int cb = 0; cb < W; cb += ST_WCAP) {
         const int cw = min(W - cb, ST_WCAP);
         // ---- y index of the chunk: bucket sort inside the wave
@@ -157,10 +183,7 @@ ST_KERNEL_SIG {
             e_kp[i] = w < cw ? P.t.skp[lo + cb + w] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
             y0 = fminf(y0, e_kp[i].y); y1 = fmaxf(y1, e_kp[i].y);
         }
-#pragma unroll
-        for (int m = 1; m < VISO_WAVE; m <<= 1) {
-            y0 = fminf(y0, __shfl_xor(y0, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
-        }
+        y0 = st_wave_ext<false>(y0); y1 = st_wave_ext<true>(y1);
         float yscale = 0.f;
         if (y1 > y0) yscale = (float)ST_NBY / (y1 - y0);
         if (!(yscale > 0.f) || !(yscale < 3.0e38f)) yscale = 0.f;
@@ -192,6 +215,7 @@ ST_KERNEL_SIG {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        ST_CLK(2);
         // ---- walk: the buckets the lane's band touches.  A lane keeps ST_SLOTS candidates per pass; where keypoints
         // are dense and a band holds more, the walk / gate / score / reduce sequence below repeats for the next
         // ST_SLOTS of them (`skip`): sparse data makes one pass
@@ -214,8 +238,19 @@ ST_KERNEL_SIG {
                 }
             }
         }
+        ST_CLK(3);
         // ---- the exact gate on what is left (src/viso.cpp:695-701), compaction in place
         int n2g = 0;
+#ifdef ST_GATE_PAIRS   // two candidates per step: their fp64 chains (a division each) interleave -- for a tile that is alone on its SIMD
+        for (int s = 0; __any(s < n); s += 2) {
+            const bool v0 = s < n, v1 = s + 1 < n;
+            const int i0 = v0 ? L.slot[s][lane] : 0, i1 = v1 ? L.slot[s + 1][lane] : 0;
+            const float2 t0 = L.ykp[i0], t1 = L.ykp[i1];
+            const double sd0 = sampson_dev(mp.F, qv.x, qv.y, t0.x, t0.y), sd1 = sampson_dev(mp.F, qv.x, qv.y, t1.x, t1.y);
+            if (v0 && isfinite(sd0) && !(sd0 > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i0; ++n2g; }
+            if (v1 && isfinite(sd1) && !(sd1 > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i1; ++n2g; }
+        }
+#else
         for (int s = 0; __any(s < n); ++s) {
             if (s < n) {
                 const int i = L.slot[s][lane];
@@ -224,6 +259,8 @@ ST_KERNEL_SIG {
                 if (isfinite(sd) && !(sd > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i; ++n2g; }
             }
         }
+#endif
+        ST_CLK(4);
         // ---- flat pair list of the tile
         const int incl = st_scan_incl(n2g, lane);
         const int base = incl - n2g;
@@ -287,6 +324,7 @@ ST_KERNEL_SIG {
 #undef ST_ISSUE
         }
         __builtin_amdgcn_wave_barrier();
+        ST_CLK(5);
         // ---- reduce: the lane's own SADs into its running order statistics
         for (int s = 0; s < n2g; ++s) {
             const uint32_t f = L.flat[base + s];
@@ -303,6 +341,7 @@ ST_KERNEL_SIG {
         if (!__any(seen > skip + ST_SLOTS)) break;
         }   // skip
     }
+    ST_CLK(6);
     // ---- K cap: exact in-radius count where the bound does not settle it (dense clusters only)
     int cnt = cnt_ub;
     {
@@ -323,6 +362,7 @@ ST_KERNEL_SIG {
             if (lane == ql) cnt = c;
         }
     }
+    ST_CLK(7);
     // ---- results
     unsigned long long scored = 0;
     if (live) {

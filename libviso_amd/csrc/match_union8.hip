@@ -120,6 +120,9 @@ __device__ __forceinline__ constexpr int mu_qlane(int k) { return (k & 3) + 32 *
 
 // (match_frame.hip includes this file with MU_KERNEL_SIG / MU_BLOCK defined: the same body as a device function that takes its
 // block number as an argument -- one launch for a single frame's stereo and temporal problems.  Here: the kernel.)
+#ifndef MU_CLK
+#define MU_CLK(I) do {} while (0)   // (match_frame.hip, debug builds: time stamps of one tile's phases)
+#endif
 #ifndef MU_KERNEL_SIG
 #define MU_KERNEL_SIG __global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(MU_THREADS) void match_union8_kernel(BatchMatchArgs a)
 #define MU_BLOCK blockIdx.x
@@ -141,6 +144,7 @@ MU_KERNEL_SIG {
         qblk = slot % a.bpp;
         if (prob >= a.n_probs) return;
     }
+    MU_CLK(0);
     const MatchProblem P = a.probs[prob];
     if ((*P.q.bad | *P.t.bad) != 0) return;   // non-integer descriptors: the general kernel does this problem
     const int n1 = *P.q.n, n2 = *P.t.n;
@@ -280,6 +284,7 @@ MU_KERNEL_SIG {
         po = *(const __attribute__((address_space(1))) int*)(qsidx_b + (uint32_t)jc_ * 4u);             \
         po = j_ < q1 ? po : -1;                                                                           \
     } while (0)
+    MU_CLK(1);
     MU_PREFETCH(0);
 
 #pragma unroll   // both rounds inline: left rolled (the compiler's choice once the body grew) the loop spills 22 registers
@@ -710,6 +715,7 @@ MU_KERNEL_SIG {
                 if (slow) scored += (unsigned long long)my_cnt;
             }
         }
+        MU_CLK(2 + r);
     }
     // scored pairs of the tile's queries whose result stands (partial sums in every lane)
 #pragma unroll
