@@ -51,12 +51,7 @@ __device__ __forceinline__ int circle_row(const CircleArgs& a, int i, int off) {
 #define CIRCT_THREADS 1024
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total, int* scratch) {   // scratch: 16 ints of LDS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const int incl = (int)viso_wave_scan((uint32_t)v);
     if (lane == 63) scratch[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;

@@ -216,6 +216,65 @@ int plain_signal_wait(viso_ctx* c, hipStream_t s, int seq);
 int plain_blit(hipStream_t s, const void* src, void* dst, size_t head_words, const int* n_rows = nullptr, int row_words = 0, int max_rows = 0,
                const PlainSignal* sig = nullptr);
 #ifdef __HIPCC__
+// Wave-wide steps as DPP operands (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 / :31): the total -- or the
+// inclusive prefix -- is in lane 63 after six dependent VALU instructions, where six ds_bpermute round trips (__shfl_xor /
+// __shfl_up) take about ten times as long.  The per-image, per-tile and per-problem kernels are chains of such steps between
+// their loads; in the latency-bound ones (match_stereo_kernel, the sorts) and for ONE frame (the per-call path) those chains
+// are the kernel's duration.  Lanes without a source take the identity.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t viso_dpp(uint32_t v, uint32_t ident) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+#define VISO_WAVE_STEPS(OP) OP(0x111, 0xf); OP(0x112, 0xf); OP(0x114, 0xf); OP(0x118, 0xf); OP(0x142, 0xa); OP(0x143, 0xc)
+__device__ __forceinline__ uint32_t viso_wave_min63(uint32_t v) {   // valid in lane 63
+#define OP_(C, M) v = min(v, viso_dpp<C, M>(v, 0xffffffffu))
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+__device__ __forceinline__ uint32_t viso_wave_max63(uint32_t v) {   // valid in lane 63
+#define OP_(C, M) v = max(v, viso_dpp<C, M>(v, 0u))
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+__device__ __forceinline__ uint32_t viso_wave_scan(uint32_t v) {    // inclusive prefix sum (lane 63: the total)
+#define OP_(C, M) v += viso_dpp<C, M>(v, 0u)
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+__device__ __forceinline__ unsigned long long viso_wave_sum63(unsigned long long v) {   // valid in lane 63
+#define OP_(C, M) v += ((unsigned long long)viso_dpp<C, M>((uint32_t)(v >> 32), 0u) << 32) | viso_dpp<C, M>((uint32_t)v, 0u)
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+__device__ __forceinline__ unsigned long long viso_wave_max63(unsigned long long v) {   // valid in lane 63
+#define OP_(C, M) do { const unsigned long long o_ = ((unsigned long long)viso_dpp<C, M>((uint32_t)(v >> 32), 0u) << 32) | viso_dpp<C, M>((uint32_t)v, 0u); v = o_ > v ? o_ : v; } while (0)
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+__device__ __forceinline__ float viso_wave_fsum63(float v) {        // valid in lane 63 (the order of the additions is this function's)
+#define OP_(C, M) v += __uint_as_float(viso_dpp<C, M>(__float_as_uint(v), 0u))
+    VISO_WAVE_STEPS(OP_);
+#undef OP_
+    return v;
+}
+// minimum / maximum of a float over the wave, to EVERY lane: quad, half-row and row exchanges as DPP operands, then the four rows'
+// values as scalars (fminf / fmaxf ignore a NaN operand: the same result as any other order of the same operations)
+template <bool MAX>
+__device__ __forceinline__ float viso_wave_fext(float v) {
+#define OP_(C) do { const float o_ = __uint_as_float(viso_dpp<C, 0xf>(__float_as_uint(v), 0u)); v = MAX ? fmaxf(v, o_) : fminf(v, o_); } while (0)
+    OP_(0xB1); OP_(0x4E); OP_(0x141); OP_(0x140);   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+#undef OP_
+    const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    const float d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
+    return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
+}
 // Called by EVERY thread of the kernel's every workgroup, behind its last store.
 __device__ __forceinline__ void plain_signal_done(const PlainSignal& g, unsigned nblocks) {
     if (!g.flag) return;                       // uniform

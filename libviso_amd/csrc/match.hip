@@ -106,13 +106,10 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         if (k.x == k.x) { xmn = fminf(xmn, k.x); xmx = fmaxf(xmx, k.x); nvx += 1.f; }
         if (fabsf(k.y) < 3.0e38f) { ymn = fminf(ymn, k.y); ymx = fmaxf(ymx, k.y); }
     });
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        xmn = fminf(xmn, __shfl_xor(xmn, m)); xmx = fmaxf(xmx, __shfl_xor(xmx, m));
-        ymn = fminf(ymn, __shfl_xor(ymn, m)); ymx = fmaxf(ymx, __shfl_xor(ymx, m));
-        nvx += __shfl_xor(nvx, m);
-    }
-    if (lane == 0) { s_red[0][wv] = xmn; s_red[1][wv] = xmx; s_red[2][wv] = ymn; s_red[3][wv] = ymx; s_red[4][wv] = nvx; }
+    xmn = viso_wave_fext<false>(xmn); xmx = viso_wave_fext<true>(xmx);
+    ymn = viso_wave_fext<false>(ymn); ymx = viso_wave_fext<true>(ymx);
+    nvx = viso_wave_fsum63(nvx);   // a count of at most a few thousand, as a float: exact in any order
+    if (lane == 63) { s_red[0][wv] = xmn; s_red[1][wv] = xmx; s_red[2][wv] = ymn; s_red[3][wv] = ymx; s_red[4][wv] = nvx; }
     for (int b = threadIdx.x; b <= VISO_NB; b += VISO_IMG_THREADS) s_cnt[b] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -139,12 +136,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         int c[4], tot = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { c[k] = s_cnt[lane * 4 + k]; tot += c[k]; }
-        int incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        const int incl = (int)viso_wave_scan((uint32_t)tot);
         int run = incl - tot;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s_cnt[lane * 4 + k] = run; I.bstart[lane * 4 + k] = run; run += c[k]; }
@@ -834,12 +826,7 @@ __device__ __forceinline__ void match_tile_slot(const MatchArgs& a, int vb, uint
     // x range of the tile (any 64 consecutive bucket-order entries; the reductions ignore NaN x)
     if (wave == 0) {
         float x = (q0 + lane < q1) ? P.q.skp[q0 + lane].x : __builtin_nanf("");
-        float mn = x, mx = x;
-#pragma unroll
-        for (int m = 1; m < VISO_WAVE; m <<= 1) {
-            mn = fminf(mn, __shfl_xor(mn, m));
-            mx = fmaxf(mx, __shfl_xor(mx, m));
-        }
+        const float mn = viso_wave_fext<false>(x), mx = viso_wave_fext<true>(x);
         if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
     }
     __syncthreads();
@@ -1112,12 +1099,8 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
             if (valid) keys[wbase + mbcnt(m)] = k;
         }
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        dmn = min(dmn, (uint32_t)__shfl_xor((int)dmn, o)); dmx = max(dmx, (uint32_t)__shfl_xor((int)dmx, o));
-        dsum += (unsigned long long)__shfl_xor((long long)dsum, o);
-    }
-    if (lane == 0) { s_red[0][wv] = dmn; s_red[1][wv] = dmx; s_sum[wv] = dsum; }
+    dmn = viso_wave_min63(dmn); dmx = viso_wave_max63(dmx); dsum = viso_wave_sum63(dsum);
+    if (lane == 63) { s_red[0][wv] = dmn; s_red[1][wv] = dmx; s_sum[wv] = dsum; }
     __syncthreads();
     const int mv = s_cnt;
     if (threadIdx.x == 0) *P.m_cnt = mv;
@@ -1139,10 +1122,9 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
                 const unsigned long long off = (keys[e] >> 32) - dmn;
                 if (off <= 2 * mean_off) { ts += off; ++tn; }
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { ts += (unsigned long long)__shfl_xor((long long)ts, o); tn += (unsigned int)__shfl_xor((int)tn, o); }
+            ts = viso_wave_sum63(ts); tn = viso_wave_scan(tn);
             __syncthreads();
-            if (lane == 0) { s_sum[wv] = ts; s_red[0][wv] = tn; }
+            if (lane == 63) { s_sum[wv] = ts; s_red[0][wv] = tn; }
             __syncthreads();
             ts = 0; tn = 0;
 #pragma unroll
@@ -1167,13 +1149,12 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
             int c[VISO_SORT_NB / 64], tot = 0, big = 0;
 #pragma unroll
             for (int q = 0; q < VISO_SORT_NB / 64; ++q) { c[q] = s_start[lane * (VISO_SORT_NB / 64) + q]; tot += c[q]; big = max(big, c[q]); }
-            int incl = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; big = max(big, __shfl_xor(big, o)); }
+            const int incl = (int)viso_wave_scan((uint32_t)tot);
+            big = (int)viso_wave_max63((uint32_t)big);
             int run = incl - tot;
 #pragma unroll
             for (int q = 0; q < VISO_SORT_NB / 64; ++q) { s_start[lane * (VISO_SORT_NB / 64) + q] = run; run += c[q]; }
-            if (lane == 0) s_maxb = big;
+            if (lane == 63) s_maxb = big;
         }
         __syncthreads();
         use_fast = s_maxb <= VISO_SORT_BMAX;

@@ -34,7 +34,6 @@ extern "C" int viso_debug_frame_clocks(unsigned long long* out16) {
 }
 #define ST_CLK(I) do { if (st_vblock == 0 && threadIdx.x == 0) viso_dbg_frame_clk[I] = wall_clock64(); } while (0)
 #endif
-#define ST_GATE_PAIRS
 #define ST_KERNEL_SIG static __device__ __forceinline__ void match_stereo_part(const BatchMatchArgs& a, const int st_vblock)
 #define ST_BLOCK st_vblock
 #define ST_NO_LAUNCHER

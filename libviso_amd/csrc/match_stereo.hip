@@ -50,34 +50,9 @@ __device__ __forceinline__ uint32_t st_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// inclusive prefix sum over the wave (values < 2^16): row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source add
-// 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- six DPP adds in place of six ds_bpermute round
-// trips.  A tile is a latency chain and the kernel is latency bound: its wave-wide steps are written for latency
-__device__ __forceinline__ int st_scan_incl(int v, int) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-// minimum / maximum of a float over the wave, to every lane: quad, half-row and row exchanges as DPP operands, then the four rows'
-// values as scalars (fminf / fmaxf ignore a NaN operand: the same result as any other order of the same operations)
-template <bool MAX>
-__device__ __forceinline__ float st_wave_ext(float v) {
-#define ST_EXT_STEP(CTRL) do { const float o_ = __uint_as_float(st_dpp<CTRL>(__float_as_uint(v))); v = MAX ? fmaxf(v, o_) : fminf(v, o_); } while (0)
-    ST_EXT_STEP(0xB1);    // quad_perm [1,0,3,2]
-    ST_EXT_STEP(0x4E);    // quad_perm [2,3,0,1]
-    ST_EXT_STEP(0x141);   // row_half_mirror
-    ST_EXT_STEP(0x140);   // row_mirror
-#undef ST_EXT_STEP
-    const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
-    const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
-    const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
-    const float d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
-    return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
-}
+// (wave-wide scans and extrema: viso_wave_scan / viso_wave_fext, common.h -- DPP operands, not ds_bpermute round trips: a tile is a
+// latency chain and the kernel is latency bound)
+__device__ __forceinline__ int st_scan_incl(int v, int) { return (int)viso_wave_scan((uint32_t)v); }
 
 __device__ __forceinline__ int st_bucket(float y, float y0, float scale) {
     if (y != y) return ST_NBY - 1;
@@ -134,7 +109,7 @@ ST_KERNEL_SIG {
     const float radius = mp.radius;
     const int K = mp.K;
     // ---- tile: x range -> window, y range -> band
-    const float xa = st_wave_ext<false>(qv.x), xb = st_wave_ext<true>(qv.x), ya = st_wave_ext<false>(qv.y), yb = st_wave_ext<true>(qv.y);
+    const float xa = viso_wave_fext<false>(qv.x), xb = viso_wave_fext<true>(qv.x), ya = viso_wave_fext<false>(qv.y), yb = viso_wave_fext<true>(qv.y);
     const bool ynan = __any(live && qv.y != qv.y);
     float band = __builtin_huge_valf();
     if (!ynan) band = epipolar_band(mp.F, mp.sampson_thresh, xa, xb, ya, yb, radius);
@@ -183,7 +158,7 @@ ST_KERNEL_SIG {
             e_kp[i] = w < cw ? P.t.skp[lo + cb + w] : make_float2(__builtin_nanf(""), __builtin_nanf(""));
             y0 = fminf(y0, e_kp[i].y); y1 = fmaxf(y1, e_kp[i].y);
         }
-        y0 = st_wave_ext<false>(y0); y1 = st_wave_ext<true>(y1);
+        y0 = viso_wave_fext<false>(y0); y1 = viso_wave_fext<true>(y1);
         float yscale = 0.f;
         if (y1 > y0) yscale = (float)ST_NBY / (y1 - y0);
         if (!(yscale > 0.f) || !(yscale < 3.0e38f)) yscale = 0.f;
@@ -241,7 +216,7 @@ ST_KERNEL_SIG {
         ST_CLK(3);
         // ---- the exact gate on what is left (src/viso.cpp:695-701), compaction in place
         int n2g = 0;
-#ifdef ST_GATE_PAIRS   // two candidates per step: their fp64 chains (a division each) interleave -- for a tile that is alone on its SIMD
+        // two candidates per step: their fp64 chains (a division each) interleave
         for (int s = 0; __any(s < n); s += 2) {
             const bool v0 = s < n, v1 = s + 1 < n;
             const int i0 = v0 ? L.slot[s][lane] : 0, i1 = v1 ? L.slot[s + 1][lane] : 0;
@@ -250,16 +225,6 @@ ST_KERNEL_SIG {
             if (v0 && isfinite(sd0) && !(sd0 > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i0; ++n2g; }
             if (v1 && isfinite(sd1) && !(sd1 > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i1; ++n2g; }
         }
-#else
-        for (int s = 0; __any(s < n); ++s) {
-            if (s < n) {
-                const int i = L.slot[s][lane];
-                const float2 t = L.ykp[i];
-                const double sd = sampson_dev(mp.F, qv.x, qv.y, t.x, t.y);
-                if (isfinite(sd) && !(sd > mp.sampson_thresh)) { L.slot[n2g][lane] = (uint16_t)i; ++n2g; }
-            }
-        }
-#endif
         ST_CLK(4);
         // ---- flat pair list of the tile
         const int incl = st_scan_incl(n2g, lane);
@@ -384,9 +349,8 @@ ST_KERNEL_SIG {
             scored = (unsigned long long)nscored;
         }
     }
-#pragma unroll
-    for (int m = 1; m < VISO_WAVE; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
-    if (lane == 0 && scored) atomicAdd(P.scored, scored);
+    scored = viso_wave_sum63(scored);
+    if (lane == 63 && scored) atomicAdd(P.scored, scored);
 }
 
 #ifndef ST_NO_LAUNCHER

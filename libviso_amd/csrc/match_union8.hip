@@ -158,12 +158,7 @@ MU_KERNEL_SIG {
     if (wave == 0) {
         const bool live = q0 + lane < q1;
         const float qx = live ? P.q.skp[q0 + lane].x : __builtin_nanf("");
-        float mn = qx, mx = qx;
-#pragma unroll
-        for (int m = 1; m < VISO_WAVE; m <<= 1) {
-            mn = fminf(mn, __shfl_xor(mn, m));
-            mx = fmaxf(mx, __shfl_xor(mx, m));
-        }
+        const float mn = viso_wave_fext<false>(qx), mx = viso_wave_fext<true>(qx);
         if (lane == 0) { s_xr[0] = mn; s_xr[1] = mx; }
     }
     if (threadIdx.x <= MU_NBY) s_ys[threadIdx.x] = 0;
@@ -216,12 +211,7 @@ MU_KERNEL_SIG {
     __syncthreads();
     if (wave == 0) {
         const int h = s_ys[lane];
-        int incl = h;
-#pragma unroll
-        for (int d = 1; d < VISO_WAVE; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        const int incl = (int)viso_wave_scan((uint32_t)h);
         s_ys[lane] = incl - h;
         if (lane == VISO_WAVE - 1) s_ys[MU_NBY] = incl;
     }
@@ -718,9 +708,8 @@ MU_KERNEL_SIG {
         MU_CLK(2 + r);
     }
     // scored pairs of the tile's queries whose result stands (partial sums in every lane)
-#pragma unroll
-    for (int m = 1; m < VISO_WAVE; m <<= 1) scored += (unsigned long long)__shfl_xor((long long)scored, m);
-    if (lane == 0 && scored) atomicAdd(P.scored, scored);
+    scored = viso_wave_sum63(scored);
+    if (lane == 63 && scored) atomicAdd(P.scored, scored);
 }
 
 #ifndef MU_NO_LAUNCHER

@@ -710,13 +710,9 @@ __device__ void refit_item(const SolverArgs& a, int item, double* tr_s, double* 
             const unsigned long long kh = c > 0 ? ((unsigned long long)(unsigned)c << 32) | (unsigned)~h : 0ull;
             key = kh > key ? kh : key;
         }
-#pragma unroll
-        for (int mk = 32; mk >= 1; mk >>= 1) {
-            const unsigned long long o = __shfl_xor(key, mk);
-            key = o > key ? o : key;
-        }
+        key = viso_wave_max63(key);
         unsigned long long* wkey = reinterpret_cast<unsigned long long*>(red);   // red is free until gn_block
-        if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
+        if ((threadIdx.x & 63) == 63) wkey[threadIdx.x >> 6] = key;
         __syncthreads();
         key = wkey[0];
 #pragma unroll
