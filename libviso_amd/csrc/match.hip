@@ -49,6 +49,16 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
 #define VISO_KP_REGS 4
 #endif
 
+#ifdef VISO_DEBUG_VARIANTS   // timing aid (tools/experiments/sortkp_phases.py): 100 MHz time stamps of sort_kp_kernel's phases, workgroup 0
+__device__ unsigned long long viso_dbg_sortkp_clk[8];
+extern "C" int viso_debug_sortkp_clocks(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(viso_dbg_sortkp_clk), sizeof(unsigned long long) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+}
+#define SK_CLK(I) do { if (blockIdx.x == 0 && threadIdx.x == 0) viso_dbg_sortkp_clk[I] = wall_clock64(); } while (0)
+#else
+#define SK_CLK(I) do {} while (0)
+#endif
 struct KpImport2 { KpImport k[2]; };
 __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageView* imgs, int n_img, int n64_alloc,
                                                                    uint32_t* zero_words, int n_zero, int* r8zero, KpImport2 imps) {
@@ -58,6 +68,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     __shared__ float s_red[5][VISO_IMG_THREADS / 64];
     __shared__ float s_x[2];
     if ((int)blockIdx.x >= n_img) return;
+    SK_CLK(0);
     if (r8zero && blockIdx.x == 0 && threadIdx.x < 4) r8zero[threadIdx.x] = 0;   // a run whose pack kernels count magnitudes (VISO_R8_*)
     if (zero_words) {   // this workgroup's slice of the run's counters (first kernel of a run: everything that counts comes later)
         const int per = (n_zero + n_img - 1) / n_img;
@@ -106,6 +117,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         if (k.x == k.x) { xmn = fminf(xmn, k.x); xmx = fmaxf(xmx, k.x); nvx += 1.f; }
         if (fabsf(k.y) < 3.0e38f) { ymn = fminf(ymn, k.y); ymx = fmaxf(ymx, k.y); }
     });
+    SK_CLK(1);
     xmn = viso_wave_fext<false>(xmn); xmx = viso_wave_fext<true>(xmx);
     ymn = viso_wave_fext<false>(ymn); ymx = viso_wave_fext<true>(ymx);
     nvx = viso_wave_fsum63(nvx);   // a count of at most a few thousand, as a float: exact in any order
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         I.xinfo[0] = x0; I.xinfo[1] = scale; I.xinfo[2] = c; I.xinfo[3] = d; I.xinfo[4] = e;
     }
     __syncthreads();
+    SK_CLK(2);
     const float x0 = s_x[0], scale = s_x[1];
     // ---- counting sort by column bucket
     walk([&](int, float2 k) { atomicAdd(&s_cnt[bucket_of(k.x, x0, scale)], 1); });
@@ -143,6 +156,7 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
         if (lane == 63) { s_cnt[VISO_NB] = run; I.bstart[VISO_NB] = n; }
     }
     __syncthreads();
+    SK_CLK(3);
     const int n64 = (n + 63) & ~63;
     walk([&](int i, float2 k) {
         const int p = atomicAdd(&s_cnt[bucket_of(k.x, x0, scale)], 1);   // running offset of the bucket
@@ -156,18 +170,26 @@ __global__ __launch_bounds__(VISO_IMG_THREADS) void sort_kp_kernel(const ImageVi
     });
     for (int j = n + threadIdx.x; j < n64; j += VISO_IMG_THREADS) ykey[j] = 0xffffffffu;
     __syncthreads();
+    SK_CLK(4);
     // ---- y order inside every block of 64 positions (the matcher kernels score rounds of y-adjacent queries of such
-    // a block: their candidate sets overlap by ~2/3).  Any total order is valid; (y, position) is used.
+    // a block: their candidate sets overlap by ~2/3).  Any total order is valid; (y without its six lowest bits, position) is used:
+    // ONE 32-bit key per entry, unique inside the block, so that a rank is a count of plain unsigned compares.
+    // A wave takes a block: every lane holds the key of its own position and meets the block's 64 keys as SCALARS (v_readlane with a
+    // constant lane: no LDS read per comparison -- walking the block through LDS was 6.8 of this kernel's 17.7 us for an image
+    // of 2000 keypoints, its largest phase).  j walks in steps of the workgroup size, a multiple of 64: a wave's lanes are one block.
+    static_assert(VISO_IMG_THREADS % 64 == 0, "a wave must cover one 64-block");
     for (int j = threadIdx.x; j < n64; j += VISO_IMG_THREADS) {
         const int base = j & ~63, me = j & 63;
-        const uint32_t key = ykey[j];
+        const uint32_t key = (ykey[j] & ~63u) | (uint32_t)me;   // (entries past n keep the largest keys: they are the block's last positions)
         int rank = 0;
+#pragma unroll
         for (int m = 0; m < 64; ++m) {
-            const uint32_t km = ykey[base + m];
-            rank += (km < key || (km == key && m < me)) ? 1 : 0;
+            const uint32_t km = (uint32_t)__builtin_amdgcn_readlane((int)key, m);
+            rank += km < key ? 1 : 0;
         }
         I.qord[base + rank] = (uint8_t)me;
     }
+    SK_CLK(5);
 }
 
 int launch_sort_kp(hipStream_t s, const ImageView* imgs_dev, int n_img, int cap_max, uint32_t* zero_words, int n_zero, int* r8zero, const KpImport* imp, int n_imp) {
