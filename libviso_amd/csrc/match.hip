@@ -1069,6 +1069,16 @@ __device__ __forceinline__ void sort_tri_row(const TriItem& T, const SolverParam
     }
 }
 
+#ifdef VISO_DEBUG_VARIANTS   // timing aid (tools/experiments/sortkp_phases.py): time stamps of sort_matches_kernel's phases, workgroup 1
+__device__ unsigned long long viso_dbg_sortm_clk[12];
+extern "C" int viso_debug_sortm_clocks(unsigned long long* out12) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out12, HIP_SYMBOL(viso_dbg_sortm_clk), sizeof(unsigned long long) * 12, 0, hipMemcpyDeviceToHost) == hipSuccess ? VISO_OK : VISO_ERR_HIP;
+}
+#define SM_CLK(I) do { if (blockIdx.x == 1 && threadIdx.x == 0) viso_dbg_sortm_clk[I] = wall_clock64(); } while (0)
+#else
+#define SM_CLK(I) do {} while (0)
+#endif
 __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const MatchProblem* probs,
                                                                          int n_probs, int npad_alloc, int fast, int flagged_empty,
                                                                          const TriItem* tri, SolverParamsDev tri_sp) {
@@ -1081,6 +1091,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
     __shared__ int s_maxb;
     const int prob = blockIdx.x;
     if (prob >= n_probs) return;
+    SM_CLK(0);
     const MatchProblem P = probs[prob];
     const bool do_tri = tri != nullptr && prob == 0;   // uniform
     TriItem T{};
@@ -1121,6 +1132,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
             if (valid) keys[wbase + mbcnt(m)] = k;
         }
     }
+    SM_CLK(1);
     dmn = viso_wave_min63(dmn); dmx = viso_wave_max63(dmx); dsum = viso_wave_sum63(dsum);
     if (lane == 63) { s_red[0][wv] = dmn; s_red[1][wv] = dmx; s_sum[wv] = dsum; }
     __syncthreads();
@@ -1136,6 +1148,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
         // Bucket map, monotone in the distance: the accepted matches sit in a narrow peak with a few far outliers, so
         // VISO_SORT_FINE buckets of one power-of-two width cover [dmn, dmn + 2 (mean - dmn)] (at most [dmn, dmx]) and
         // the tail behind them goes to log-linear buckets (32 per octave).
+        SM_CLK(2);
         unsigned long long mean_off = dsum / (unsigned long long)mv - dmn;
         for (int trim = 0; trim < 2; ++trim) {   // the mean of what lies within twice the mean, twice: outliers drop out
             unsigned long long ts = 0;
@@ -1153,6 +1166,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
             for (int w = 0; w < VISO_SORT_THREADS / 64; ++w) { ts += s_sum[w]; tn += s_red[0][w]; }
             mean_off = tn ? ts / tn : 0;
         }
+        SM_CLK(3);
         const unsigned long long span = min((unsigned long long)(dmx - dmn), 2 * mean_off + 1);
         int sh = 0;
         while (sh < 32 && (span >> sh) >= (unsigned long long)VISO_SORT_FINE) ++sh;
@@ -1167,6 +1181,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
 #define SORT_BUCKET(D) bucket_of_dist((uint32_t)(D))
         for (int e = threadIdx.x; e < mv; e += VISO_SORT_THREADS) atomicAdd(&s_start[SORT_BUCKET(keys[e] >> 32)], 1);
         __syncthreads();
+        SM_CLK(4);
         if (wv == 0) {   // exclusive scan of the bucket counts (32 per lane + wave scan), largest bucket
             int c[VISO_SORT_NB / 64], tot = 0, big = 0;
 #pragma unroll
@@ -1180,6 +1195,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
         }
         __syncthreads();
         use_fast = s_maxb <= VISO_SORT_BMAX;
+        SM_CLK(5);
         if (use_fast) {
             // scatter into bucket order: the running offset of bucket b ends up at the bucket's END = start of b + 1
             for (int e = threadIdx.x; e < mv; e += VISO_SORT_THREADS) {
@@ -1187,6 +1203,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
                 bkeys[atomicAdd(&s_start[SORT_BUCKET(k >> 32)], 1)] = k;
             }
             __syncthreads();
+            SM_CLK(6);
             for (int p = threadIdx.x; p < mv; p += VISO_SORT_THREADS) {
                 const unsigned long long k = bkeys[p];
                 const int b = SORT_BUCKET(k >> 32);
@@ -1206,6 +1223,7 @@ __global__ __launch_bounds__(VISO_SORT_THREADS) void sort_matches_kernel(const M
                 P.pos[i1] = r;
                 if (do_tri) sort_tri_row(T, tri_sp, r, i1, rr.x);
             }
+            SM_CLK(7);
             return;
         }
 #undef SORT_BUCKET
